@@ -1,0 +1,222 @@
+"""Oracle: HUA epistemic-uncertainty scoring.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Three samplers for the stochastic part of `ComputeObjUnc` (Lambda_L2.py:489-537):
+  * sampler='torch'   -- torch.distributions.Dirichlet, exactly what the reference calls
+                         (statistical parity with the golden MC-500 values);
+  * sampler='philox'  -- numpy restatement of the build's counter-based sampler
+                         (Philox4x32-10 -> Box-Muller -> Marsaglia-Tsang gamma), the SAME
+                         algorithm as aod_meh_hua_amd/csrc/hua.hip, stream keyed by
+                         (seed, image id, anchor id, object id, sample, class, attempt) so
+                         the HIP kernel is checked value-for-value, not only statistically;
+  * closed form       -- epi_inf = H(a/S) - psi(S+1) + sum (a_k/S) psi(a_k+1)  (MC limit).
+"""
+import numpy as np
+import torch
+from scipy.special import digamma
+
+FLT_MIN = np.float32(np.finfo(np.float32).tiny)
+ONE_MINUS_EPS = np.float32(1.0) - np.float32(np.finfo(np.float32).eps)
+NUM_SAMPLES = 500
+
+
+# ------------------------------------------------------------------ Philox4x32-10
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al. 2011); all args uint32 arrays (broadcastable)."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32) for c in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over='ignore'):
+        for _ in range(10):
+            p0 = c0.astype(np.uint64) * _M0
+            p1 = c2.astype(np.uint64) * _M1
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32(k0 + _W0)
+            k1 = np.uint32(k1 + _W1)
+    return c0, c1, c2, c3
+
+
+def _u01(x):
+    """uint32 -> float32 in (0, 1]: (x >> 8 + 1) * 2^-24 (never 0, so log() is finite)."""
+    return ((x >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
+
+
+def philox_gamma(alpha, c1, c2, c3, seed, max_attempts=64):
+    """Gamma(alpha, 1) variates, float32, Marsaglia-Tsang (2000) with the alpha<1 boost
+    gamma(alpha) = gamma(alpha+1) * u^(1/alpha).  One Philox call per attempt `t` at counter
+    (t, c1, c2, c3): words -> (u_a, u_b) Box-Muller normal, u_c accept test, u_d boost (t=0 only).
+    """
+    alpha = np.asarray(alpha, dtype=np.float32)
+    k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    boost = alpha < 1
+    a = np.where(boost, alpha + np.float32(1), alpha).astype(np.float32)
+    d = (a - np.float32(1.0 / 3.0)).astype(np.float32)
+    c = (np.float32(1.0) / np.sqrt(np.float32(9.0) * d)).astype(np.float32)
+    out = np.zeros(alpha.shape, dtype=np.float32)
+    done = np.zeros(alpha.shape, dtype=bool)
+    ub = np.ones(alpha.shape, dtype=np.float32)
+    for t in range(max_attempts):
+        r0, r1, r2, r3 = philox4x32(np.uint32(t), c1, c2, c3, k0, k1)
+        u_a, u_b, u_c = _u01(r0), _u01(r1), _u01(r2)
+        if t == 0:
+            ub = _u01(r3)
+        x = (np.sqrt(np.float32(-2.0) * np.log(u_a)) * np.cos(np.float32(2.0 * np.pi) * u_b)).astype(np.float32)
+        v = (np.float32(1.0) + c * x).astype(np.float32)
+        v3 = (v * v * v).astype(np.float32)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ok = (v > 0) & (np.log(u_c) < np.float32(0.5) * x * x + d - d * v3 + d * np.log(v3))
+        newly = ok & ~done
+        out = np.where(newly, (d * v3).astype(np.float32), out)
+        done |= ok
+        if done.all():
+            break
+    with np.errstate(divide='ignore', over='ignore', under='ignore'):
+        boosted = (out * np.exp(np.log(ub) / alpha)).astype(np.float32)
+    return np.where(boost, boosted, out).astype(np.float32)
+
+
+def philox_dirichlet_stats(alpha, image_id, anchor_id, obj_id, seed, num_samples=NUM_SAMPLES):
+    """Per pair: (aleatoric, epistemic) from `num_samples` Dirichlet(alpha) draws.
+    alpha [P, C] float32; anchor_id/obj_id [P].  Samples are normalised gammas clamped to
+    [FLT_MIN, 1-eps] like torch._sample_dirichlet; entropies in float32."""
+    alpha = np.asarray(alpha, dtype=np.float32)
+    P, C = alpha.shape
+    s = np.arange(num_samples, dtype=np.uint32)[:, None, None]
+    k = np.arange(C, dtype=np.uint32)[None, None, :]
+    obj = np.asarray(obj_id, dtype=np.uint32)[None, :, None]
+    c1 = (obj << np.uint32(16)) | (s << np.uint32(5)) | k
+    c2 = np.asarray(anchor_id, dtype=np.uint32)[None, :, None]
+    g = philox_gamma(np.broadcast_to(alpha[None], (num_samples, P, C)), c1, c2, np.uint32(image_id), seed)
+    g = np.maximum(g, FLT_MIN)
+    p = g / g.sum(-1, keepdims=True, dtype=np.float32)
+    p = np.clip(p, FLT_MIN, ONE_MINUS_EPS).astype(np.float32)
+    ent = -(p * np.log(p)).sum(-1, dtype=np.float32)          # [S, P]
+    ale = ent.mean(0, dtype=np.float32)
+    avg = p.mean(0, dtype=np.float32)
+    total = -(avg * np.log(avg)).sum(-1, dtype=np.float32)
+    return ale, (total - ale).astype(np.float32)
+
+
+def epistemic_closed_form(alpha):
+    """MC limit of (total - aleatoric): H(a/S) - [psi(S+1) - sum (a_k/S) psi(a_k+1)]  (float64)."""
+    a = np.asarray(alpha, dtype=np.float64)
+    S = a.sum(-1, keepdims=True)
+    m = a / S
+    total = -(m * np.log(m)).sum(-1)
+    ale = digamma(S[..., 0] + 1) - (m * digamma(a + 1)).sum(-1)
+    return total - ale
+
+
+# --------------------------------------------------------------- ComputeObjUnc (a15)
+def start_end(level_sizes, s):
+    """mmdet/utils/functions.py:438-444 StartEnd."""
+    start = sum(level_sizes[:s])
+    return start, start + level_sizes[s]
+
+
+def build_pairs(level_any_fg, pos_bbox, topk_scores, lam, idx):
+    """For one (image, level): Lambda_L2.py:497-518.  Returns None if the level is skipped, else
+    dict(cand, obj, alpha, cls, anchor).  topk_scores [k, C] (normalised), lam [k], pos_bbox [k, O]."""
+    if not bool(level_any_fg):
+        return None
+    if pos_bbox.numel() == 0 or len(pos_bbox.nonzero()) == 0:
+        return None
+    fg = pos_bbox & (topk_scores.max(dim=1)[0] > 0.3)[:, None].expand_as(pos_bbox)
+    nz = fg.nonzero()
+    cand, obj = nz[:, 0], nz[:, 1]
+    if len(cand) == 0:
+        return None
+    ps = topk_scores[cand]
+    pl = lam[cand]
+    lam_hat = pl.mean() / (pl + 1e-7) * 25
+    return dict(cand=cand, obj=obj, alpha=ps * lam_hat[:, None], cls=ps.argmax(dim=1), anchor=idx[cand])
+
+
+def compute_obj_unc(pre, pos_bboxes, sampler='torch', seed=20, image_ids=None, level_offsets=None,
+                    num_samples=NUM_SAMPLES):
+    """Lambda_L2Net.ComputeObjUnc (Lambda_L2.py:489-537).
+    `pre` = oracle.detect.pre_nms output; pos_bboxes[b] bool [cand_total, O_b].
+    Returns (bins, pairs): bins[b][obj][level] = {cls(int): epi_mean(float)}; pairs = list of per
+    (b, level) dicts incl. per-pair epi (for value-level checks of the HIP kernel)."""
+    S = len(pre['scores'])
+    B = pre['scores'][0].shape[0]
+    sizes = [x.shape[1] for x in pre['scores']]
+    bins = [[[{} for _ in range(S)] for _ in range(pos_bboxes[b].size(1))] for b in range(B)]
+    all_pairs = []
+    for s in range(S):
+        for b in range(B):
+            st, en = start_end(sizes, s)
+            pr = build_pairs(pre['level_any_fg'][s][b], pos_bboxes[b][st:en], pre['scores'][s][b],
+                             pre['lam'][s][b], pre['idx'][s][b])
+            if pr is None:
+                continue
+            alpha = pr['alpha']
+            if sampler == 'torch':
+                smp = torch.distributions.Dirichlet(alpha).sample(torch.tensor([num_samples]))
+                avg = smp.mean(dim=0)
+                total = (-avg * avg.log()).sum(dim=1)
+                ale = (-smp * smp.log()).sum(dim=-1).mean(dim=0)
+                epi = total - ale
+            elif sampler == 'philox':
+                img = b if image_ids is None else int(image_ids[b])
+                off = 0 if level_offsets is None else int(level_offsets[s])
+                ale, epi = philox_dirichlet_stats(alpha.numpy(), img, pr['anchor'].numpy() + off,
+                                                  pr['obj'].numpy(), seed, num_samples)
+                ale, epi = torch.from_numpy(ale), torch.from_numpy(epi)
+            elif sampler == 'closed':
+                epi = torch.from_numpy(epistemic_closed_form(alpha.numpy()).astype(np.float32))
+                ale = torch.zeros_like(epi)
+            else:
+                raise ValueError(sampler)
+            pr.update(epi=epi, ale=ale, level=s, image=b)
+            all_pairs.append(pr)
+            for o in pr['obj'].unique():
+                om = pr['obj'] == o
+                for c in pr['cls'][om].unique():
+                    m = om & (pr['cls'] == c)
+                    bins[b][int(o)][s][int(c)] = float(epi[m].mean())
+    return bins, all_pairs
+
+
+_AGG = {'Sum': lambda v: float(np.sum(np.asarray(v, np.float32), dtype=np.float32)),
+        'Avg': lambda v: float(np.mean(np.asarray(v, np.float32), dtype=np.float32)),
+        'Max': lambda v: float(np.max(np.asarray(v, np.float32)))}
+
+
+def extract_agg_func(type_str):
+    """mmdet/utils/functions.py:425-436 ExtractAggFunc."""
+    out = {}
+    for name in ('object', 'scale', 'class'):
+        for part in type_str.split('_'):
+            if name in part:
+                out[name] = _AGG[part.replace(name, '')]
+    return out
+
+
+def aggregate_obj_scale_unc(bins, type_str='objectSum_scaleMax_classSum', clsW=False):
+    """Lambda_L2Net.AggregateObjScaleUnc (Lambda_L2.py:597-619)."""
+    f = extract_agg_func(type_str)
+    out = []
+    for img in bins:
+        objs, seen = [], set()
+        for obj in img:
+            scales = []
+            for lvl in obj:
+                vals = list(lvl.values())
+                seen.update(lvl.keys())
+                if vals:
+                    scales.append(f['class'](vals))
+            if scales:
+                objs.append(f['scale'](scales))
+        v = f['object'](objs) if objs else 0
+        if clsW:
+            v *= len(seen)
+        out.append(v)
+    return out

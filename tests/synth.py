@@ -1,0 +1,81 @@
+"""Seeded synthetic inputs shared by tools/golden/make_golden.py (which feeds them to the
+reference) and by the parity tests (which feed them to the oracle / the HIP path).
+Pure data recipes: CPU torch.Generator streams, identical on every box with this image."""
+import numpy as np
+import torch
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def metas(B, H, W, scale=1.0):
+    return [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
+                 scale_factor=np.full(4, scale, np.float32), flip=False, flip_direction=None,
+                 filename=f'synth_{i}.jpg', ori_filename=f'synth_{i}.jpg') for i in range(B)]
+
+
+def images(B, H, W, seed=20):
+    return torch.randn(B, 3, H, W, generator=gen(seed))
+
+
+def random_gts(B, H, W, seed=20, gmin=1, gmax=5, num_classes=20):
+    """SURVEY 8d C1 recipe: G~U{gmin..gmax}, w,h ~ U(H/16, 3H/4), clipped inside the image."""
+    g = gen(seed)
+    boxes, labels = [], []
+    for _ in range(B):
+        G = int(torch.randint(gmin, gmax + 1, (1,), generator=g))
+        wh = torch.rand(G, 2, generator=g) * torch.tensor([W * 0.6875, H * 0.6875]) + torch.tensor([W / 16., H / 16.])
+        xy = torch.rand(G, 2, generator=g) * (torch.tensor([float(W), float(H)]) - wh)
+        boxes.append(torch.cat([xy, xy + wh], dim=1))
+        labels.append(torch.randint(0, num_classes, (G,), generator=g))
+    return boxes, labels
+
+
+def assign_cases(H=128, W=128):
+    """Three images for the assigner: G=0; a gt whose best IoU < 0.5 (tiny box) next to
+    a normal one; duplicate gts (tie rule: later gt wins) plus an anchor-aligned gt."""
+    b0 = torch.zeros(0, 4)
+    l0 = torch.zeros(0, dtype=torch.long)
+    b1 = torch.tensor([[3., 5., 9., 12.], [20., 30., 90., 100.]])
+    l1 = torch.tensor([4, 11])
+    # an exact level-0 anchor (stride 8, cell (2,3), ratio 1 scale 4: 32x32 centred at (24,16)) twice + shifted
+    b2 = torch.tensor([[8., 0., 40., 32.], [8., 0., 40., 32.], [40., 40., 104., 120.]])
+    l2 = torch.tensor([2, 7, 19])
+    return [b0, b1, b2], [l0, l1, l2]
+
+
+def loss_inputs(N=1024, C=20, seed=21):
+    g = gen(seed)
+    logits = torch.randn(N, C, generator=g) * 2.0
+    labels = torch.randint(0, C + 1, (N,), generator=g)          # C == background
+    labels[torch.rand(N, generator=g) < 0.6] = C
+    lw = (torch.rand(N, generator=g) > 0.1).float()
+    bpred = torch.randn(N, 4, generator=g) * 0.5
+    btgt = torch.randn(N, 4, generator=g) * 0.5
+    bw = ((labels < C).float() * lw)[:, None].expand(N, 4).contiguous()
+    lam = torch.rand(N, generator=g) * 0.3
+    return dict(logits=logits, labels=labels, label_weights=lw, bbox_pred=bpred, bbox_targets=btgt,
+                bbox_weights=bw, lam=lam, num_total_samples=max(int((labels < C).sum()), 1))
+
+
+def planted_heads(B=2, H=128, W=128, C=20, A=9, seed=22, n_plant=6):
+    """Planted-logit head outputs (SURVEY 8c 'scoring'): cls = 0.5*N(0,1) with +8.0 on a few
+    (anchor, class) 3x3 patches so that some anchors pass 0.3 / NMS finds objects;
+    reg = 0.1*N(0,1); L = U(.01,.31).  Returns NCHW lists like the head does."""
+    g = gen(seed)
+    cls, reg, Ls = [], [], []
+    for s in (8, 16, 32, 64, 128):
+        h, w = max(H // s, 1), max(W // s, 1)
+        c = 0.5 * torch.randn(B, A * C, h, w, generator=g)
+        for b in range(B):
+            for _ in range(n_plant if h >= 4 else (1 if h >= 2 else 0)):
+                a = int(torch.randint(0, A, (1,), generator=g))
+                k = int(torch.randint(0, C, (1,), generator=g))
+                y = int(torch.randint(0, h, (1,), generator=g))
+                x = int(torch.randint(0, w, (1,), generator=g))
+                c[b, a * C + k, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] += 8.0
+        cls.append(c)
+        reg.append(0.1 * torch.randn(B, A * 4, h, w, generator=g))
+        Ls.append(torch.rand(B, A, h, w, generator=g) * 0.3 + 0.01)
+    return cls, reg, Ls
