@@ -1,0 +1,83 @@
+"""ctypes binding of libaodhip.so (the C ABI declared in include/aod_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built library, or
+calling an op on a non-GPU tensor, raises.  Tensors are passed as raw device pointers; kernels
+are enqueued on torch's current HIP stream."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libaodhip.so')
+
+
+class AodHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f'{LIB_PATH} is missing: run `python -m aod_meh_hua_amd.build` (hipcc, gfx950). '
+                      'There is no CPU fallback for the MEH/HUA hot path.')
+lib = C.CDLL(LIB_PATH)
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
+                ('src_row0', C.c_int64), ('dst_row0', C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('C', C.c_int32), ('N', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('stride', C.c_int32),
+                ('pad', C.c_int32), ('dil', C.c_int32), ('transposed', C.c_int32), ('relu', C.c_int32),
+                ('out_f32', C.c_int32), ('nseg', C.c_int32), ('seg', ConvSeg * 8)]
+
+
+P, I32, I64, F32, U64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+_SIGS = {
+    'aod_version': (C.c_int, []),
+    'aod_conv2d': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P]),
+    'aod_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P]),
+    'aod_pack_weight_fwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    'aod_pack_weight_dgrad': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    'aod_unpack_wgrad': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_nchw_f32_to_nhwc_bf16': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    'aod_maxpool3x3s2': (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    'aod_upsample2x_add': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_upsample2x_add_bwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_act_bwd': (C.c_int, [P, P, P, P, P, P, P, P, P, P, I64, I32, I32, I32, P]),
+    'aod_add_relu': (C.c_int, [P, P, P, I64, P]),
+    'aod_loss_partials_len': (SZ, [I64]),
+    'aod_edl_focal_l1_fwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, P]),
+    'aod_edl_focal_l1_bwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, F32, P, P, I32, I32, I32, I32, P]),
+    'aod_meh_loss_fwd': (C.c_int, [P, P, P, I64, P, P, P]),
+    'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
+    'aod_sgd_multi': (C.c_int, [P, P, I32, I64, F32, F32, F32, I32, F32, P]),
+}
+for _n, (_r, _a) in _SIGS.items():
+    if hasattr(lib, _n):
+        getattr(lib, _n).restype = _r
+        getattr(lib, _n).argtypes = _a
+lib.aod_last_error.restype = C.c_char_p
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: no CPU path exists."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AodHipError('aod_meh_hua_amd ops need tensors on the MI355X (cuda:N); got a CPU tensor. There is no CPU fallback.')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, name='aod'):
+    if rc != 0:
+        raise AodHipError(f'{name} failed ({rc}): {lib.aod_last_error().decode()}')
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,257 @@
+// HBM-bound elementwise / reduction kernels around the conv stack (NHWC bf16, 16-B lanes).
+#include "common.h"
+
+static inline int grid_for(long long nvec) {
+  long long b = (nvec + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC bf16 (padded C)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int HW, int Cpad) {
+  const long long n = (long long)B * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, px = i - b * HW;
+    bf16_t* o = dst + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) o[c] = (c < C) ? (bf16_t)src[(b * C + c) * HW + px] : (bf16_t)0.f;
+  }
+}
+extern "C" int aod_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int B, int C, int H, int W, int Cpad, aod_stream_t stream) {
+  AOD_CHECK_ARG(src && dst && Cpad >= C, "nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, C, H * W, Cpad);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 s2 p1
+__global__ void maxpool_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int H, int W, int C8, int OH, int OW) {
+  const long long n = (long long)B * OH * OW * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = i % C8; long long r = i / C8;
+    const int ox = r % OW; r /= OW;
+    const int oy = r % OH; const int b = r / OH;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = oy * 2 - 1 + dy;
+      if ((unsigned)y >= (unsigned)H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = ox * 2 - 1 + dx;
+        if ((unsigned)x >= (unsigned)W) continue;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (((long long)b * H + y) * W + x) * C8 * 8 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)m[j];
+    *reinterpret_cast<bf16x8*>(dst + i * 8) = o;
+  }
+}
+extern "C" int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod_stream_t stream) {
+  AOD_CHECK_ARG(src && dst && C % 8 == 0, "maxpool: C must be a multiple of 8");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long long)B * OH * OW * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, B, H, W, C / 8, OH, OW);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- FPN nearest-upsample add (F.interpolate(size=..., 'nearest'))
+// src index = floor(dst * h / H) (torch nearest); exact 2x when H == 2h.
+__global__ void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int h, int w, int C8, int H, int W) {
+  const long long n = (long long)B * H * W * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = i % C8; long long r = i / C8;
+    const int x = r % W; r /= W;
+    const int y = r % H; const int b = r / H;
+    const int sy = min((int)(((long long)y * h) / H), h - 1), sx = min((int)(((long long)x * w) / W), w - 1);
+    const bf16x8 s = *reinterpret_cast<const bf16x8*>(src + ((((long long)b * h + sy) * w + sx) * C8 + c) * 8);
+    bf16x8 d = *reinterpret_cast<bf16x8*>(dst + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = (bf16_t)((float)d[j] + (float)s[j]);
+    *reinterpret_cast<bf16x8*>(dst + i * 8) = d;
+  }
+}
+extern "C" int aod_upsample2x_add(const void* src, void* dst, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(src && dst && C % 8 == 0, "upsample_add: C must be a multiple of 8");
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((long long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, B, h, w, C / 8, H, W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+// adjoint: g_src[b,sy,sx,c] += sum over dst pixels mapping to (sy,sx) of g_dst
+__global__ void upsample_add_bwd_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gs, int B, int h, int w, int C8, int H, int W) {
+  const long long n = (long long)B * h * w * C8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = i % C8; long long r = i / C8;
+    const int sx = r % w; r /= w;
+    const int sy = r % h; const int b = r / h;
+    // dst rows y with floor(y*h/H) == sy  <=>  y in [ceil(sy*H/h), ceil((sy+1)*H/h))
+    const int y0 = (int)(((long long)sy * H + h - 1) / h), y1 = min(H, (int)(((long long)(sy + 1) * H + h - 1) / h));
+    const int x0 = (int)(((long long)sx * W + w - 1) / w), x1 = min(W, (int)(((long long)(sx + 1) * W + w - 1) / w));
+    float a[8];
+    bf16x8 cur = *reinterpret_cast<bf16x8*>(gs + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (float)cur[j];
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(gd + ((((long long)b * H + y) * W + x) * C8 + c) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = (bf16_t)a[j];
+    *reinterpret_cast<bf16x8*>(gs + i * 8) = cur;
+  }
+}
+extern "C" int aod_upsample2x_add_bwd(const void* g_dst, void* g_src, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(g_dst && g_src && C % 8 == 0, "upsample_add_bwd: C must be a multiple of 8");
+  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for((long long)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)g_dst, (bf16_t*)g_src, B, h, w, C / 8, H, W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- add + relu
+__global__ void add_relu_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, long long nvec) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + i * 8), y = *reinterpret_cast<const bf16x8*>(b + i * 8);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)fmaxf((float)x[j] + (float)y[j], 0.f);
+    *reinterpret_cast<bf16x8*>(o + i * 8) = r;
+  }
+}
+extern "C" int aod_add_relu(const void* a, const void* b, void* out, int64_t n, aod_stream_t stream) {
+  AOD_CHECK_ARG(a && b && out && n % 8 == 0, "add_relu: n must be a multiple of 8");
+  hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long long)(n / 8));
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- activation / BN(eval) backward + column reductions
+// Block = 256 threads = 32 column-chunks (8 cols each) x 8 row lanes; each block owns a 256-column
+// panel x a strip of rows; column sums are reduced through LDS then one atomicAdd per column per block.
+template <bool G_F32>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ g_, const bf16_t* __restrict__ a, const bf16_t* __restrict__ z,
+                                                      const float* __restrict__ scale, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, bf16_t* __restrict__ dz,
+                                                      bf16_t* __restrict__ gm_out, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                      long long M, int N, int relu, int rows_per_block) {
+  __shared__ float sb[8][256 + 8], sg[8][256 + 8];
+  const int t = threadIdx.x;
+  const int cc = t & 31, rl = t >> 5;
+  const int n = blockIdx.x * 256 + cc * 8;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  float sbv[8], sgv[8], sc[8], mu[8], is[8];
+  const bool nok = n < N;   // N % 8 == 0
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sbv[j] = 0.f; sgv[j] = 0.f; sc[j] = 1.f; mu[j] = 0.f; is[j] = 0.f; }
+  if (nok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (scale) sc[j] = scale[n + j];
+      if (z) { mu[j] = mean[n + j]; is[j] = invstd[n + j]; }
+    }
+    for (long long m = r0 + rl; m < r1; m += 8) {
+      const long long off = m * N + n;
+      float g[8];
+      if (G_F32) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>((const float*)g_ + off), g1 = *reinterpret_cast<const f32x4*>((const float*)g_ + off + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; }
+      } else {
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>((const bf16_t*)g_ + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
+      }
+      if (relu) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = ((float)av[j] > 0.f) ? g[j] : 0.f;
+      }
+      if (gm_out) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)g[j];
+        *reinterpret_cast<bf16x8*>(gm_out + off) = o;
+      }
+      if (z) {
+        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sgv[j] += g[j] * ((float)zv[j] - mu[j]) * is[j];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sbv[j] += g[j]; o[j] = (bf16_t)(g[j] * sc[j]); }
+      if (dz) *reinterpret_cast<bf16x8*>(dz + off) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sb[rl][cc * 8 + j] = sbv[j]; sg[rl][cc * 8 + j] = sgv[j]; }
+  __syncthreads();
+  {
+    const int col = t, nn = blockIdx.x * 256 + col;
+    if (nn < N) {
+      float b = 0.f, gsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { b += sb[r][col]; gsum += sg[r][col]; }
+      if (dbeta) atomicAdd(dbeta + nn, b);
+      if (dgamma && z) atomicAdd(dgamma + nn, gsum);
+    }
+  }
+}
+extern "C" int aod_act_bwd(const void* g, const void* a, const void* z, const float* scale, const float* mean, const float* invstd,
+                           void* dz, void* gmask_out, float* dbeta, float* dgamma, int64_t M, int N, int relu, int g_is_f32,
+                           aod_stream_t stream) {
+  AOD_CHECK_ARG(g && N % 8 == 0 && M >= 0, "act_bwd: N must be a multiple of 8");
+  AOD_CHECK_ARG(!relu || a, "act_bwd: relu needs the forward output");
+  AOD_CHECK_ARG(!z || (mean && invstd), "act_bwd: z needs mean/invstd");
+  if (M == 0) return 0;
+  const int panels = (N + 255) / 256;
+  long long want = 2048 / panels;
+  if (want < 1) want = 1;
+  long long rpb = (M + want - 1) / want;
+  if (rpb < 64) rpb = 64;
+  rpb = (rpb + 7) / 8 * 8;
+  const int gy = (int)((M + rpb - 1) / rpb);
+  if (g_is_f32)
+    hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(panels, gy), dim3(256), 0, (hipStream_t)stream, g, (const bf16_t*)a, (const bf16_t*)z, scale, mean,
+                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb);
+  else
+    hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(panels, gy), dim3(256), 0, (hipStream_t)stream, g, (const bf16_t*)a, (const bf16_t*)z, scale, mean,
+                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- multi-tensor SGD (torch.optim.SGD semantics)
+__global__ void sgd_multi_kernel(void* const* __restrict__ ptrs, const long long* __restrict__ sizes, int blocks_per_tensor,
+                                 float lr, float momentum, float wd, int first_step, float grad_scale) {
+  const int ti = blockIdx.x / blocks_per_tensor, bi = blockIdx.x % blocks_per_tensor;
+  float* p = (float*)ptrs[3 * ti];
+  const float* g = (const float*)ptrs[3 * ti + 1];
+  float* mbuf = (float*)ptrs[3 * ti + 2];
+  const long long n = sizes[ti];
+  for (long long i = (long long)bi * blockDim.x + threadIdx.x; i < n; i += (long long)blocks_per_tensor * blockDim.x) {
+    const float pv = p[i];
+    const float d = g[i] * grad_scale + wd * pv;
+    const float b = first_step ? d : momentum * mbuf[i] + d;
+    mbuf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+extern "C" int aod_sgd_multi(void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+                             float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream) {
+  AOD_CHECK_ARG(ptrs_dev && sizes_dev && ntensors > 0, "sgd_multi: bad args");
+  int bpt = (int)((max_size + 256 * 8 - 1) / (256 * 8));
+  if (bpt < 1) bpt = 1;
+  if (bpt > 64) bpt = 64;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(ntensors * bpt), dim3(256), 0, (hipStream_t)stream, ptrs_dev, (const long long*)sizes_dev, bpt,
+                     lr, momentum, weight_decay, first_step, grad_scale);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,236 @@
+// Fused EDL softmax-focal + L1 loss (forward / backward) and MEH loss for gfx950.
+// HBM-bound: one pass over the fp32 logits.  Rows are staged through LDS with coalesced 16-B
+// loads, then one thread owns one anchor row (C = 20 logits) in registers.
+// Compiled with -ffp-contract=off: the formulas follow the reference op order.
+#include "common.h"
+
+#define FLT_MIN_F 1.17549435e-38f
+constexpr int LB = 256;     // rows per block
+constexpr int MAXC = 96;
+
+__device__ __forceinline__ float focal_pow(float b, float gamma) { return gamma == 2.f ? b * b : powf(b, gamma); }
+
+// per-row forward core: fills p[] (softmax) and returns row loss; lsum_w = sum_c l_c
+template <int MAXC_>
+__device__ __forceinline__ float edl_row_fwd(const float* x, int C, long long label, float gamma, float alpha, float* p) {
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float S = 0.f;
+  for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); S += p[c]; }
+  float tot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float pr = p[c] / S;
+    p[c] = pr;
+    const float z = logf(pr / (1.f - pr + 1e-9f) + 1e-9f);
+    const float q = 1.f / (1.f + expf(-z));
+    float l;
+    if (label == c) l = -alpha * focal_pow(1.f - q, gamma) * logf(fmaxf(q, FLT_MIN_F));
+    else l = -(1.f - alpha) * focal_pow(q, gamma) * logf(fmaxf(1.f - q, FLT_MIN_F));
+    tot += l;
+  }
+  return tot;
+}
+
+__global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
+                                                        const float* __restrict__ lw, const float* __restrict__ bp,
+                                                        const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
+                                                        float gamma, float alpha, float* __restrict__ loss_noR, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  const int P = C | 1;  // odd pitch -> conflict-free row reads
+  const long long r0 = (long long)blockIdx.x * LB;
+  const int nr = (int)min((long long)LB, nrows - r0);
+  const float* src = cls + r0 * C;
+  const int tot = nr * C;
+  for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
+  __syncthreads();
+  float s_cls = 0.f, s_box = 0.f, s_nor = 0.f;
+  if ((int)threadIdx.x < nr) {
+    const long long r = r0 + threadIdx.x;
+    float x[MAXC], p[MAXC];
+    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
+    const float l = edl_row_fwd<MAXC>(x, C, labels[r], gamma, alpha, p);
+    loss_noR[r] = l;
+    s_nor = l;
+    s_cls = l * lw[r];
+    if (bp) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(bp + r * 4), b = *reinterpret_cast<const f32x4*>(bt + r * 4),
+                  w = *reinterpret_cast<const f32x4*>(bw + r * 4);
+      for (int j = 0; j < 4; ++j) s_box += fabsf(a[j] - b[j]) * w[j];
+    }
+  }
+  // block reduction (fixed order -> deterministic)
+  __shared__ float red[3][LB / 64];
+  s_cls = wave_sum(s_cls); s_box = wave_sum(s_box); s_nor = wave_sum(s_nor);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_cls; red[1][threadIdx.x >> 6] = s_box; red[2][threadIdx.x >> 6] = s_nor; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = 0.f;
+    for (int i = 0; i < LB / 64; ++i) v += red[threadIdx.x][i];
+    partials[(long long)blockIdx.x * 3 + threadIdx.x] = v;
+  }
+}
+
+// second stage: one block sums the per-block partials in a fixed order and ADDS into out[k]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, long long nblocks, int k, float* __restrict__ out) {
+  __shared__ float red[4];
+  for (int j = 0; j < k; ++j) {
+    float v = 0.f;
+    for (long long i = threadIdx.x; i < nblocks; i += 256) v += partials[i * k + j];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] += red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
+extern "C" size_t aod_loss_partials_len(int64_t nrows) { return (size_t)((nrows + LB - 1) / LB) * 3; }
+
+extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
+                                    const float* bbox_tgt, const float* bbox_w, int64_t nrows, int C, float gamma, float alpha,
+                                    float* loss_noR, float* sums3, float* partials, aod_stream_t stream) {
+  if (nrows == 0) return 0;
+  AOD_CHECK_ARG(cls && labels && label_w && loss_noR && sums3 && partials, "edl_fwd: null pointer");
+  AOD_CHECK_ARG(C >= 1 && C <= MAXC, "edl_fwd: C=%d out of range", C);
+  AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_fwd: bbox_pred needs targets and weights");
+  if (nrows == 0) return 0;
+  const long long nb = (nrows + LB - 1) / LB;
+  hipLaunchKernelGGL(edl_l1_fwd_kernel, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+                     label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 3, sums3);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward.  Output element (row r, class c) lives at (r / A) * pitch + (r % A) * C + c so that the
+// gradient lands directly in the conv's [pixels, A*C (padded)] dZ layout, bf16 or fp32.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
+                                                        const float* __restrict__ lw, const float* __restrict__ bp,
+                                                        const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
+                                                        float gamma, float alpha, const float* __restrict__ g_cls,
+                                                        const float* __restrict__ g_bbox, const float* __restrict__ g_noR, float g_noR_s,
+                                                        void* __restrict__ grad_cls, void* __restrict__ grad_bbox, int A, int pitch_cls,
+                                                        int pitch_box) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  const int P = C | 1;
+  const long long r0 = (long long)blockIdx.x * LB;
+  const int nr = (int)min((long long)LB, nrows - r0);
+  const float* src = cls + r0 * C;
+  const int tot = nr * C;
+  for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x < nr) {
+    const long long r = r0 + threadIdx.x;
+    float x[MAXC], p[MAXC], gp[MAXC];
+    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float S = 0.f;
+    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); S += p[c]; }
+    const long long label = labels[r];
+    const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[r] : g_noR_s);
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float pr = p[c] / S;
+      p[c] = pr;
+      const float om = 1.f - pr + 1e-9f;
+      const float u = pr / om;
+      const float z = logf(u + 1e-9f);
+      const float q = 1.f / (1.f + expf(-z));
+      float gz;   // d l / d z  (mmcv sigmoid_focal_loss backward)
+      if (label == c) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * logf(fmaxf(q, FLT_MIN_F)));
+      else gz = -(1.f - alpha) * focal_pow(q, gamma) * (gamma * (1.f - q) * logf(fmaxf(1.f - q, FLT_MIN_F)) - q);
+      // dz/dp = (1+eps) / ((1-p+eps)^2 (u+eps))
+      const float g = coef * gz * (1.f + 1e-9f) / (om * om * (u + 1e-9f));
+      gp[c] = g;
+      dot += pr * g;
+    }
+    const long long obase = (r / A) * pitch_cls + (r % A) * C;
+    for (int c = 0; c < C; ++c) {
+      const float gx = p[c] * (gp[c] - dot);
+      if (OUT_BF16) ((bf16_t*)grad_cls)[obase + c] = (bf16_t)gx;
+      else ((float*)grad_cls)[obase + c] = gx;
+    }
+    if (bp && grad_bbox) {
+      const float gb = g_bbox[0];
+      const long long bb = (r / A) * pitch_box + (r % A) * 4;
+      for (int j = 0; j < 4; ++j) {
+        const float d = bp[r * 4 + j] - bt[r * 4 + j];
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float gx = sgn * bw[r * 4 + j] * gb;
+        if (OUT_BF16) ((bf16_t*)grad_bbox)[bb + j] = (bf16_t)gx;
+        else ((float*)grad_bbox)[bb + j] = gx;
+      }
+    }
+  }
+}
+
+extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
+                                    const float* bbox_tgt, const float* bbox_w, int64_t nrows, int C, float gamma, float alpha,
+                                    const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar, void* grad_cls,
+                                    void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
+  if (nrows == 0) return 0;
+  AOD_CHECK_ARG(cls && labels && label_w && g_cls && grad_cls, "edl_bwd: null pointer");
+  AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_bwd: bad C/A/pitch");
+  AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && g_bbox && pitch_box >= A * 4), "edl_bwd: bbox args");
+  if (nrows == 0) return 0;
+  const long long nb = (nrows + LB - 1) / LB;
+  if (out_bf16)
+    hipLaunchKernelGGL((edl_l1_bwd_kernel<true>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,
+                       (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR,
+                       g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box);
+  else
+    hipLaunchKernelGGL((edl_l1_bwd_kernel<false>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,
+                       (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR,
+                       g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- MEH loss
+__global__ __launch_bounds__(256) void meh_fwd_kernel(const float* __restrict__ lam, const float* __restrict__ loss, const float* __restrict__ bw4,
+                                                      long long n, float* __restrict__ partials) {
+  float s = 0.f;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float d = fabsf(lam[i] + 1e-9f - loss[i]) * bw4[i * 4];
+    s = d * d;
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+template <bool OUT_BF16>
+__global__ void meh_bwd_kernel(const float* __restrict__ lam, const float* __restrict__ loss, const float* __restrict__ bw4, long long n,
+                               const float* __restrict__ g, void* __restrict__ grad, int A, int pitch) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float w = bw4[i * 4];
+    const float v = g[0] * 2.f * w * w * (lam[i] + 1e-9f - loss[i]);
+    const long long o = (i / A) * pitch + (i % A);
+    if (OUT_BF16) ((bf16_t*)grad)[o] = (bf16_t)v; else ((float*)grad)[o] = v;
+  }
+}
+extern "C" int aod_meh_loss_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n, float* out_sum, float* partials,
+                                aod_stream_t stream) {
+  AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && out_sum && partials, "meh_fwd: null pointer");
+  if (n == 0) return 0;
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(meh_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 1, out_sum);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n, const float* g, void* grad_lam,
+                                int out_bf16, int A, int pitch, aod_stream_t stream) {
+  AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && g && grad_lam && A >= 1 && pitch >= A, "meh_bwd: bad args");
+  if (n == 0) return 0;
+  const long long nb = (n + 255) / 256;
+  if (out_bf16) hipLaunchKernelGGL((meh_bwd_kernel<true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, g, grad_lam, A, pitch);
+  else hipLaunchKernelGGL((meh_bwd_kernel<false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, g, grad_lam, A, pitch);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

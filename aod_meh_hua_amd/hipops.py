@@ -1,0 +1,209 @@
+"""Thin functional layer over the C ABI (no autograd here): shape bookkeeping + pointer passing.
+
+Activations are "row tensors": a flat [rows, C] bf16 buffer holding one or more NHWC blocks
+(`Seg` records).  A single-image-batch tensor [B, C, H, W] in torch.channels_last memory format
+is the same bytes as rows [B*H*W, C]."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _C
+from ._C import ConvDesc, ConvSeg, call, ptr, stream
+
+
+@dataclass(frozen=True)
+class Seg:
+    B: int
+    H: int
+    W: int
+    row0: int = 0
+
+    @property
+    def rows(self):
+        return self.B * self.H * self.W
+
+
+def out_hw(h, w, R, S, stride, pad, dil):
+    return ((h + 2 * pad - dil * (R - 1) - 1) // stride + 1, (w + 2 * pad - dil * (S - 1) - 1) // stride + 1)
+
+
+def out_segs(segs: Sequence[Seg], R, S, stride, pad, dil) -> List[Seg]:
+    out, r = [], 0
+    for s in segs:
+        oh, ow = out_hw(s.H, s.W, R, S, stride, pad, dil)
+        out.append(Seg(s.B, oh, ow, r))
+        r += s.B * oh * ow
+    return out
+
+
+def make_desc(C_, N, R, S, stride, pad, dil, src_segs: Sequence[Seg], dst_segs: Sequence[Seg], transposed=False,
+              relu=False, out_f32=False) -> ConvDesc:
+    d = ConvDesc()
+    d.C, d.N, d.R, d.S, d.stride, d.pad, d.dil = C_, N, R, S, stride, pad, dil
+    d.transposed, d.relu, d.out_f32, d.nseg = int(transposed), int(relu), int(out_f32), len(src_segs)
+    assert 1 <= len(src_segs) <= 8 and len(src_segs) == len(dst_segs)
+    for i, (s, o) in enumerate(zip(src_segs, dst_segs)):
+        d.seg[i] = ConvSeg(s.B, s.H, s.W, o.H, o.W, s.row0, o.row0)
+    return d
+
+
+def pack_weight_fwd(w_oihw: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    O, I, R, S = w_oihw.shape
+    cpad = cpad or (I + 7) // 8 * 8
+    out = torch.empty(O, R, S, cpad, dtype=torch.bfloat16, device=w_oihw.device)
+    call('aod_pack_weight_fwd', ptr(w_oihw.contiguous()), ptr(out), O, I, R, S, cpad, stream())
+    return out
+
+
+def pack_weight_dgrad(w_oihw: torch.Tensor, opad: Optional[int] = None) -> torch.Tensor:
+    O, I, R, S = w_oihw.shape
+    opad = opad or (O + 7) // 8 * 8
+    out = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=w_oihw.device)
+    call('aod_pack_weight_dgrad', ptr(w_oihw.contiguous()), ptr(out), O, I, R, S, opad, stream())
+    return out
+
+
+def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, pre_scale=None, pre_shift=None,
+                res=None, mask=None, post_scale=None, relu=False, out_f32=False, save_z=False, out=None,
+                dst_segs=None, out_rows=None):
+    """Forward conv on row tensors.  Returns (y_rows, dst_segs[, z_rows])."""
+    Cin = x_rows.shape[1]
+    dst_segs = dst_segs or out_segs(src_segs, R, S, stride, pad, dil)
+    rows = out_rows if out_rows is not None else sum(s.rows for s in dst_segs)
+    if out is None:
+        out = torch.empty(rows, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
+    z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
+    d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
+    call('aod_conv2d', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift), ptr(res),
+         ptr(mask), ptr(post_scale), ptr(z), stream())
+    return (out, dst_segs, z) if save_z else (out, dst_segs)
+
+
+def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,
+                      post_scale=None, out=None, x_rows_total=None):
+    """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad]."""
+    Npad = dz_rows.shape[1]
+    rows = x_rows_total if x_rows_total is not None else sum(s.rows for s in x_segs)
+    if out is None:
+        out = torch.empty(rows, Cin, dtype=torch.bfloat16, device=dz_rows.device)
+    d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
+    call('aod_conv2d', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
+         ptr(post_scale), None, stream())
+    return out
+
+
+def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None):
+    """dW[Npad][R][S][C] fp32 (accumulated into `dw` if given)."""
+    Cin, Npad = x_rows.shape[1], dz_rows.shape[1]
+    if dw is None:
+        dw = torch.zeros(Npad, R, S, Cin, dtype=torch.float32, device=x_rows.device)
+    d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
+    call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), stream())
+    return dw
+
+
+def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False):
+    Opad, R, S, Ipad = dw_orsi.shape
+    if grad_oihw is None:
+        grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
+    call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), stream())
+    return grad_oihw
+
+
+def nchw_to_rows(img_f32, cpad=8):
+    B, Cc, H, W = img_f32.shape
+    out = torch.empty(B * H * W, cpad, dtype=torch.bfloat16, device=img_f32.device)
+    call('aod_nchw_f32_to_nhwc_bf16', ptr(img_f32.contiguous()), ptr(out), B, Cc, H, W, cpad, stream())
+    return out, [Seg(B, H, W, 0)]
+
+
+def rows_to_nchw(rows, seg: Seg):
+    """View rows of one segment as a [B, C, H, W] channels_last tensor (no copy)."""
+    Cc = rows.shape[1]
+    return rows[seg.row0:seg.row0 + seg.rows].view(seg.B, seg.H, seg.W, Cc).permute(0, 3, 1, 2)
+
+
+def maxpool3x3s2(x_rows, seg: Seg):
+    Cc = x_rows.shape[1]
+    oh, ow = out_hw(seg.H, seg.W, 3, 3, 2, 1, 1)
+    out = torch.empty(seg.B * oh * ow, Cc, dtype=torch.bfloat16, device=x_rows.device)
+    call('aod_maxpool3x3s2', ptr(x_rows), ptr(out), seg.B, seg.H, seg.W, Cc, stream())
+    return out, Seg(seg.B, oh, ow, 0)
+
+
+def upsample_add_(dst_rows, dst_seg: Seg, src_rows, src_seg: Seg):
+    call('aod_upsample2x_add', ptr(src_rows), ptr(dst_rows), dst_seg.B, src_seg.H, src_seg.W, dst_rows.shape[1],
+         dst_seg.H, dst_seg.W, stream())
+    return dst_rows
+
+
+def upsample_add_bwd_(g_src_rows, src_seg: Seg, g_dst_rows, dst_seg: Seg):
+    call('aod_upsample2x_add_bwd', ptr(g_dst_rows), ptr(g_src_rows), dst_seg.B, src_seg.H, src_seg.W,
+         g_dst_rows.shape[1], dst_seg.H, dst_seg.W, stream())
+    return g_src_rows
+
+
+def add_relu(a, b):
+    out = torch.empty_like(a)
+    call('aod_add_relu', ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    return out
+
+
+def act_bwd(g, a=None, z=None, scale=None, mean=None, invstd=None, relu=True, want_gm=False, want_dz=True):
+    """Returns (dz, gm, dbeta, dgamma).  g [M, N] bf16 or fp32."""
+    M, N = g.shape
+    dz = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_dz else None
+    gm = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_gm else None
+    dbeta = torch.zeros(N, dtype=torch.float32, device=g.device)
+    dgamma = torch.zeros(N, dtype=torch.float32, device=g.device) if z is not None else None
+    call('aod_act_bwd', ptr(g), ptr(a), ptr(z), ptr(scale), ptr(mean), ptr(invstd), ptr(dz), ptr(gm), ptr(dbeta),
+         ptr(dgamma), M, N, int(relu), int(g.dtype == torch.float32), stream())
+    return dz, gm, dbeta, dgamma
+
+
+def edl_focal_l1_fwd(cls, labels, label_w, bbox_pred=None, bbox_tgt=None, bbox_w=None, gamma=2.0, alpha=0.25, sums=None):
+    """cls [rows, C] fp32.  Returns (loss_noR [rows], sums[3] = (sum l*w, sum |d|*bw, sum noR))."""
+    rows, Cc = cls.shape
+    loss_noR = torch.empty(rows, dtype=torch.float32, device=cls.device)
+    if sums is None:
+        sums = torch.zeros(3, dtype=torch.float32, device=cls.device)
+    part = torch.empty(max(int(_C.lib.aod_loss_partials_len(rows)), 1), dtype=torch.float32, device=cls.device)
+    call('aod_edl_focal_l1_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
+         gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream())
+    return loss_noR, sums
+
+
+def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g_bbox, g_noR=None, g_noR_scalar=0.0,
+                     gamma=2.0, alpha=0.25, out_bf16=False, A=1, pitch_cls=None, pitch_box=None, grad_cls=None, grad_bbox=None):
+    rows, Cc = cls.shape
+    pitch_cls = pitch_cls or A * Cc
+    pitch_box = pitch_box or A * 4
+    dt = torch.bfloat16 if out_bf16 else torch.float32
+    if grad_cls is None:
+        grad_cls = torch.zeros(rows // A, pitch_cls, dtype=dt, device=cls.device)
+    if grad_bbox is None and bbox_pred is not None:
+        grad_bbox = torch.zeros(rows // A, pitch_box, dtype=dt, device=cls.device)
+    call('aod_edl_focal_l1_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
+         gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
+         pitch_cls, pitch_box, stream())
+    return grad_cls, grad_bbox
+
+
+def meh_loss_fwd(lam, loss_noR, bbox_w4, out_sum=None):
+    n = lam.numel()
+    if out_sum is None:
+        out_sum = torch.zeros(1, dtype=torch.float32, device=lam.device)
+    part = torch.empty(max(int(_C.lib.aod_loss_partials_len(n)), 1), dtype=torch.float32, device=lam.device)
+    call('aod_meh_loss_fwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), n, ptr(out_sum), ptr(part), stream())
+    return out_sum
+
+
+def meh_loss_bwd(lam, loss_noR, bbox_w4, g, out_bf16=False, A=1, pitch=None, grad=None):
+    n = lam.numel()
+    pitch = pitch or A
+    if grad is None:
+        grad = torch.zeros(n // A, pitch, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=lam.device)
+    call('aod_meh_loss_bwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), n, ptr(g), ptr(grad), int(out_bf16), A, pitch, stream())
+    return grad

@@ -1,0 +1,187 @@
+/* libaodhip.so -- C ABI of the MI355X (gfx950) kernels behind the MEH/HUA hot path.
+ *
+ * The reference (MoonLab-YH/AOD_MEH_HUA) is pure Python; its native work is dispatched to
+ * third-party libraries (cuDNN via torch, mmcv-full 1.3.8 CUDA ops, torch.distributions).
+ * Each entry point below names the reference call site (file:line under /root/reference)
+ * whose native dispatch it replaces.  INTEGRATION.md shows the Python (ctypes) binding a
+ * maintainer of the reference would add at each site.
+ *
+ * Conventions (every entry point):
+ *   - returns 0 on success, -1 bad argument/shape, -2 workspace too small, -3 HIP error
+ *     (message via aod_last_error());
+ *   - caller owns all memory (device pointers, pre-allocated outputs); no internal
+ *     allocation, no host sync; kernels are enqueued on `stream` (a hipStream_t);
+ *   - activations are NHWC ("channels-last") bf16 unless stated; weights are handed over in
+ *     the reference's OIHW fp32 master layout and re-packed by aod_pack_weight_*;
+ *   - int64 label / index tensors keep the reference's dtypes.
+ */
+#ifndef AOD_HIP_H
+#define AOD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* aod_stream_t; /* hipStream_t */
+
+const char* aod_last_error(void);
+int aod_version(void);
+
+/* ------------------------------------------------------------------ convolution (K1-K3, K5)
+ * One pyramid segment = one [B, H, W, C] NHWC block inside a flat [rows, C] buffer.  A launch may
+ * cover up to 8 segments that share weights (the five FPN levels of the head towers,
+ * mmdet/models/dense_heads/Lambda_L2.py:79-103 multi_apply over levels). */
+typedef struct {
+  int32_t B, H, W;        /* source block geometry (input of fwd; dZ of dgrad)                */
+  int32_t OH, OW;         /* destination block geometry (output of fwd; dX of dgrad)          */
+  int64_t src_row0;       /* first row of this block in the source buffer                     */
+  int64_t dst_row0;       /* first row of this block in the destination buffer                */
+} aod_conv_seg_t;
+
+typedef struct {
+  int32_t C, N;           /* GEMM K-side channels (source channels), output channels          */
+  int32_t R, S;           /* filter taps                                                      */
+  int32_t stride, pad, dil;
+  int32_t transposed;     /* 0: y = conv(x, w).  1: dgrad (dX = conv_transpose(dZ, w)); `w`
+                             must then be the [C_in][R][S][C_out] packing (aod_pack_weight_dgrad) */
+  int32_t relu;           /* apply max(v, 0) last                                             */
+  int32_t out_f32;        /* destination dtype: 0 bf16, 1 fp32                                */
+  int32_t nseg;
+  aod_conv_seg_t seg[8];
+} aod_conv_desc_t;
+
+/* replaces: F.conv2d dispatched by mmcv ConvModule / nn.Conv2d in
+ *   mmdet/models/backbones/resnet.py:165-205,262-301,598-610 (+ frozen-stat BN :647-656 folded
+ *   into pre_scale/pre_shift), mmdet/models/necks/fpn.py:156-202,
+ *   mmdet/models/dense_heads/Lambda_L2.py:85-103.
+ * v = acc * pre_scale[n] + pre_shift[n] + res[m][n]; if (mask) v = mask[m][n] > 0 ? v : 0;
+ * v *= post_scale[n]; if (relu) v = max(v, 0); dst[m][n] = v; optional zraw[m][n] = acc (bf16).
+ * Any of pre_scale/pre_shift/res/mask/post_scale/zraw may be NULL. */
+int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
+               const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
+               const float* post_scale, void* zraw, aod_stream_t stream);
+
+/* replaces: the weight-gradient half of autograd's conv backward (cuDNN wgrad) for the same
+ * call sites.  dw_f32 is [N][R][S][C] fp32 and is ACCUMULATED into (caller zeroes it);
+ * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */
+int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz, float* dw_f32,
+                     aod_stream_t stream);
+
+/* OIHW fp32 -> [O][R][S][Ipad] bf16 (forward) / [I][R][S][Opad] bf16 (dgrad); pads zero-filled, multiples of 8 */
+int aod_pack_weight_fwd(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Ipad, aod_stream_t stream);
+int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Opad, aod_stream_t stream);
+/* [O][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient, grad_oihw (+)= ; accumulate != 0 adds */
+int aod_unpack_wgrad(const float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ layout / elementwise
+ * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the
+ * implicit layout of `img` in SSL_L_single_stage.py:45-49 extract_feat. */
+int aod_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int B, int C, int H, int W, int Cpad, aod_stream_t stream);
+/* MaxPool 3x3 s2 p1, NHWC bf16 (resnet.py:610). */
+int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod_stream_t stream);
+/* FPN top-down: dst[b,y,x,c] += src[b,y/2,x/2,c] (nearest 2x, fpn.py:163-172) and its adjoint */
+int aod_upsample2x_add(const void* src, void* dst, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+int aod_upsample2x_add_bwd(const void* g_dst, void* g_src_accum, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+/* Backward of y = act(z*scale+shift [+res]) in eval-mode BN (resnet.py:262-301):
+ * gm = g * (a > 0 if relu);  dz = gm * scale[n];  dbeta[n] += sum_m gm;  dgamma[n] += sum_m gm * (z - mean[n]) * invstd[n].
+ * gmask_out (optional) receives gm (gradient for the residual branch); z/mean/invstd NULL -> bias-only mode
+ * (ConvModule bias+ReLU, Lambda_L2.py:44-51): dz = gm, dbeta = column sum.  dbeta/dgamma are fp32, accumulated. */
+int aod_act_bwd(const void* g, const void* a, const void* z, const float* scale, const float* mean, const float* invstd,
+                void* dz, void* gmask_out, float* dbeta, float* dgamma, int64_t M, int N, int relu, int g_is_f32,
+                aod_stream_t stream);
+/* out = relu(a + b) bf16 and backward mask (bottleneck join, resnet.py:292-299) */
+int aod_add_relu(const void* a, const void* b, void* out, int64_t n, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ losses (K6-K8)
+ * replaces: mmcv.ops.sigmoid_focal_loss fwd/bwd CUDA kernels + softmax/log chain at
+ *   mmdet/models/losses/EDL_Softmax_FocalLoss.py:9-27,51-69, L1 at smooth_l1_loss.py:33-45,
+ *   reductions at losses/utils.py:28-54, called from Lambda_L2.py:112-121.
+ * cls [Nrows, C] fp32 logits, labels int64 (C == background), label_w fp32, bbox_* [Nrows,4] fp32.
+ * Outputs: loss_noR[Nrows]; sums[0] += sum(l*w), sums[1] += sum(|p-t|*bw), sums[2] += sum(loss_noR)
+ * (deterministic two-stage reduction; `partials` is a caller workspace of aod_loss_partials_len floats). */
+size_t aod_loss_partials_len(int64_t nrows);
+int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, const float* label_w,
+                         const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
+                         int64_t nrows, int C, float gamma, float alpha,
+                         float* loss_noR, float* sums3, float* partials, aod_stream_t stream);
+/* grad_cls = d(sum(l*w))*g_cls + d(sum_rows loss_noR * g_noR[row]);  grad_bbox = sign(p-t)*bw*g_bbox.
+ * g_cls, g_bbox: device scalars (already divided by avg_factor); g_noR: device [Nrows] or NULL,
+ * g_noR_scalar: used when g_noR is NULL.  Output element (row r, col c) is written at
+ * (r / A) * pitch + (r % A) * C + c -- i.e. straight into the prediction conv's [pixels, pitch] dZ
+ * buffer (pitch = A*C rounded up to 8, pad columns pre-zeroed by the caller) -- as bf16 or fp32. */
+int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, const float* label_w,
+                         const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
+                         int64_t nrows, int C, float gamma, float alpha,
+                         const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar,
+                         void* grad_cls, void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box,
+                         aod_stream_t stream);
+/* MEH loss (Lambda_L2.py:235-241): out_sum[0] += sum(((|lam+1e-9-loss|)*w)^2), w = bbox_w4[i*4];
+ * grad = g[0]*2*w^2*(lam+1e-9-loss) written at (i / A) * pitch + i % A.  partials: >= aod_loss_partials_len(n) floats */
+int aod_meh_loss_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n,
+                     float* out_sum, float* partials, aod_stream_t stream);
+int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n,
+                     const float* g, void* grad_lam, int out_bf16, int A, int pitch, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ geometry (K9, K10)
+ * replaces: AnchorGenerator.grid_anchors/valid_flags (core/anchor/anchor_generator.py:308-438),
+ *   MaxIoUAssigner.assign (core/bbox/assigners/max_iou_assigner.py:60-210) + bbox_overlaps
+ *   (iou2d_calculator.py:212-252) + PseudoSampler + bbox2delta (delta_xywh_bbox_coder.py:98-140)
+ *   + unmap, as driven by L_anchor_head.py:155-257.  Bit-exact integer outputs.
+ * anchors [A,4] fp32; valid [B,A] uint8; gts packed [B, Gmax, 4] fp32 with gt_count[B], gt_labels [B,Gmax] int64.
+ * outputs: assigned [B,A] int64, labels [B,A] int64, label_w [B,A] f32, bbox_t [B,A,4], bbox_w [B,A,4],
+ * num_pos [B] int32.  ws: workspace of aod_assign_ws_bytes(B, Gmax). */
+int aod_grid_anchors(const float* base_anchors, int nbase, int fh, int fw, int stride, float* out, aod_stream_t stream);
+size_t aod_assign_ws_bytes(int B, int Gmax);
+int aod_max_iou_assign(const float* anchors, const uint8_t* valid, int64_t A, int B,
+                       const float* gts, const int32_t* gt_count, const int64_t* gt_labels, int Gmax,
+                       float pos_thr, float neg_thr, float min_pos_iou, int gt_max_assign_all, int num_classes,
+                       const float* means4, const float* stds4,
+                       int64_t* assigned, int64_t* labels, float* label_w, float* bbox_t, float* bbox_w,
+                       int32_t* num_pos, void* ws, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ scoring (K11-K13)
+ * replaces Lambda_L2.py:264-304 (softmax, normalise, row max, per-level top-k, gather, decode) */
+int aod_softmax_rowmax(const float* cls, int64_t nrows, int C, float* alphas_or_null, float* rowmax, aod_stream_t stream);
+/* per (image) stable top-k (ties -> lower index) of score[B, A] -> idx[B, k] int32 (descending) */
+size_t aod_topk_ws_bytes(int B, int64_t A);
+int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, void* ws, aod_stream_t stream);
+/* gather + decode one level: out boxes [B,k,4] (clipped to img_hw[b], divided by scale[b][4]), scores [B,k,C+1]
+ * (normalised softmax + zero bg column), lam [B,k] */
+int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors,
+                      const int32_t* idx, int B, int64_t A, int k, int C, const float* img_hw, const float* scale4,
+                      const float* means4, const float* stds4, float wh_ratio_clip,
+                      float* boxes, float* scores, float* lam, aod_stream_t stream);
+/* multiclass_nms (core/post_processing/bbox_nms.py:7-93 -> mmcv batched_nms/nms_cpu semantics).
+ * boxes [B,n,4], scores [B,n,C+1]; outputs dets [B,max_num,5], det_labels [B,max_num] int64,
+ * keep [B,max_num] int64 (index into the score>thr list), num_det [B] int32. */
+size_t aod_nms_ws_bytes(int B, int n, int C);
+int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, int C, float score_thr, float iou_thr,
+                       int max_num, float* dets, int64_t* det_labels, int64_t* keep, int32_t* num_det,
+                       void* ws, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ HUA (K13-K15)
+ * replaces GetObjectIdx + ComputeObjUnc + AggregateObjScaleUnc (Lambda_L2.py:343-349,489-537,597-619;
+ * torch._sample_dirichlet): per image, (candidate,object) pairs -> 500 Dirichlet samples -> epistemic ->
+ * (object, level, class) bins -> class/scale/object aggregation -> unc[B].
+ * level_start[L+1]: candidate offsets of the concatenated levels; level_any_fg [B,L] uint8 (Lambda_L2.py:497-502);
+ * cand_anchor [B,n] int32 global anchor id (RNG key); image_ids [B] int64 (RNG key); agg = 3 codes (class,scale,object)
+ * each 0 Sum / 1 Avg / 2 Max.  pair_out (optional, [B, max_pairs, 4] f32: cand, obj, ale, epi) for tests. */
+size_t aod_hua_ws_bytes(int B, int n, int max_obj, int L, int C);
+int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor,
+                  const float* dets, const int32_t* num_det, const int32_t* level_start, const uint8_t* level_any_fg,
+                  const int64_t* image_ids, int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr,
+                  float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3, int clsW,
+                  float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer (K16)
+ * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61) over a table of tensors:
+ * ptrs[3*i+{0,1,2}] = param, grad, momentum buffer (device pointers stored in device memory), sizes[i]. */
+int aod_sgd_multi(void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+                  float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,258 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Conv kernels compute bf16 x bf16 -> fp32; the oracle is torch's fp32 CPU conv evaluated on the
+SAME bf16-rounded operands, so the only differences are fp32 summation order and the final
+bf16 rounding of the output (2^-9 relative) -- tolerances below are set for that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses as olosses
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def ho():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from aod_meh_hua_amd import hipops
+    return hipops
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc_rows(x_nchw):
+    B, C, H, W = x_nchw.shape
+    return x_nchw.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def rows_nchw(rows, B, H, W):
+    return rows.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def close(a, b, rtol, atol):
+    a, b = a.float().cpu(), b.float().cpu()
+    ok = torch.allclose(a, b, rtol=rtol, atol=atol)
+    if not ok:
+        d = (a - b).abs()
+        i = d.argmax()
+        print('max abs diff', float(d.max()), 'at', int(i), float(a.flatten()[i]), float(b.flatten()[i]), 'ref absmax', float(b.abs().max()))
+    return ok
+
+
+CONV_CASES = [
+    # B, C, H, W, N, R, stride, pad, dil
+    (2, 64, 16, 16, 64, 1, 1, 0, 1),
+    (2, 64, 16, 16, 256, 3, 1, 1, 1),
+    (3, 256, 20, 12, 256, 3, 1, 1, 1),      # ragged M (720 rows), K = 2304
+    (2, 128, 17, 19, 128, 3, 2, 1, 1),      # stride 2, odd sizes
+    (2, 256, 16, 16, 512, 1, 2, 0, 1),      # 1x1 stride 2 (downsample)
+    (1, 8, 40, 40, 64, 7, 2, 3, 1),         # stem-like (C padded to 8, K = 392: K tail)
+    (2, 256, 9, 9, 180, 3, 1, 1, 1),        # retina_cls: N = 180 (N tail)
+    (2, 256, 9, 9, 36, 3, 1, 1, 1),
+    (2, 256, 9, 9, 9, 3, 1, 1, 1),          # retina_L: N = 9 (scalar store path)
+    (1, 512, 10, 10, 1024, 3, 1, 6, 6),     # dilated (SSD fc6-like)
+    (4, 2048, 4, 4, 256, 3, 2, 1, 1),       # FPN extra conv on C5, K = 18432
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward(ho, case):
+    B, C, H, W, N, R, stride, pad, dil = case
+    g = synth.gen(100 + N + C)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(N, C, R, R, generator=g) / np.sqrt(C * R * R))
+    out_f32 = N in (180, 36, 9)
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    xr = nhwc_rows(x).cuda().to(torch.bfloat16)
+    wp = ho.pack_weight_fwd(w.cuda())
+    y, segs = ho.conv2d_rows(xr, [ho.Seg(B, H, W)], wp, N, R, R, stride, pad, dil, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = rows_nchw(y, B, segs[0].H, segs[0].W)
+    assert got.shape == ref.shape
+    assert close(got, ref, rtol=1e-2 if not out_f32 else 1e-4, atol=1e-2 if not out_f32 else 1e-4)
+
+
+def test_conv_epilogue_bn_res_relu_and_z(ho):
+    B, C, H, W, N = 2, 128, 12, 12, 256
+    g = synth.gen(7)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(N, C, 1, 1, generator=g) / np.sqrt(C))
+    scale = torch.rand(N, generator=g) + 0.5
+    shift = torch.randn(N, generator=g)
+    res = bf(torch.randn(B, N, H, W, generator=g))
+    z_ref = F.conv2d(x, w)
+    ref = F.relu(z_ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    y, segs, z = ho.conv2d_rows(nhwc_rows(x).cuda().bfloat16(), [ho.Seg(B, H, W)], ho.pack_weight_fwd(w.cuda()), N, 1, 1,
+                                pre_scale=scale.cuda(), pre_shift=shift.cuda(), res=nhwc_rows(res).cuda().bfloat16(), relu=True, save_z=True)
+    torch.cuda.synchronize()
+    assert close(rows_nchw(y, B, H, W), ref, 1e-2, 2e-2)
+    assert close(rows_nchw(z, B, H, W), z_ref, 1e-2, 1e-2)
+
+
+def test_conv_pyramid_segments_share_weights(ho):
+    """Level-batched launch: 5 pyramid levels in one flat row buffer == 5 separate convs."""
+    B, C, N = 2, 256, 256
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    g = synth.gen(11)
+    xs = [bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes]
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9))
+    bias = torch.randn(N, generator=g)
+    segs, r = [], 0
+    for h, w_ in sizes:
+        segs.append(ho.Seg(B, h, w_, r))
+        r += B * h * w_
+    rows = torch.cat([nhwc_rows(x) for x in xs]).cuda().bfloat16()
+    y, osegs = ho.conv2d_rows(rows, segs, ho.pack_weight_fwd(w.cuda()), N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=True)
+    torch.cuda.synchronize()
+    for x, s in zip(xs, osegs):
+        ref = F.relu(F.conv2d(x, w, bias, 1, 1))
+        assert close(ho.rows_to_nchw(y, s), ref, 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_dgrad_and_wgrad(ho, case):
+    B, C, H, W, N, R, stride, pad, dil = case
+    if C == 8:
+        Creal = 3
+    else:
+        Creal = C
+    g = synth.gen(200 + N + C)
+    x = bf(torch.randn(B, Creal, H, W, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(N, Creal, R, R, generator=g) / np.sqrt(Creal * R * R)).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad, dil)
+    dz = bf(torch.randn(y.shape, generator=g))
+    y.backward(dz)
+    OH, OW = y.shape[-2:]
+    Npad = (N + 7) // 8 * 8
+    dz_rows = torch.zeros(B * OH * OW, Npad)
+    dz_rows[:, :N] = nhwc_rows(dz)
+    dz_rows = dz_rows.cuda().bfloat16()
+    xpad = torch.zeros(B, C, H, W)
+    xpad[:, :Creal] = x.detach()
+    x_rows = nhwc_rows(xpad).cuda().bfloat16()
+    xs, zs = [ho.Seg(B, H, W)], [ho.Seg(B, OH, OW)]
+    # wgrad
+    dw = ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, R, R, stride, pad, dil)
+    gw = ho.unpack_wgrad(dw, N, Creal)
+    torch.cuda.synchronize()
+    scale = float(w.grad.abs().max())
+    assert close(gw, w.grad, 5e-3, 5e-3 * scale)
+    # dgrad
+    wd = ho.pack_weight_dgrad(w.detach().cuda(), Npad)
+    wd_full = wd
+    if Creal != C:   # pad the "input channel" axis of the dgrad packing so that dX has C columns
+        wd_full = torch.zeros(C, R, R, Npad, dtype=torch.bfloat16, device='cuda')
+        wd_full[:Creal] = wd
+    dx = ho.conv2d_dgrad_rows(dz_rows, zs, xs, wd_full, C, R, R, stride, pad, dil)
+    torch.cuda.synchronize()
+    got = rows_nchw(dx, B, H, W)[:, :Creal]
+    assert close(got, x.grad, 1e-2, 1e-2 * float(x.grad.abs().max()))
+
+
+def test_elementwise_ops(ho):
+    g = synth.gen(5)
+    B, C, H, W = 2, 64, 13, 11
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    xr = nhwc_rows(x).cuda().bfloat16()
+    y, s = ho.maxpool3x3s2(xr, ho.Seg(B, H, W))
+    assert torch.equal(rows_nchw(y, B, s.H, s.W).float().cpu(), F.max_pool2d(x, 3, 2, 1))
+    img = torch.randn(2, 3, 10, 12, generator=g)
+    r, sg = ho.nchw_to_rows(img.cuda(), 8)
+    back = rows_nchw(r, 2, 10, 12).float().cpu()
+    assert torch.equal(back[:, :3], bf(img)) and (back[:, 3:] == 0).all()
+    # upsample-add and adjoint (exact 2x and the ragged 7 -> 13 case of F.interpolate(size=...))
+    for (h, w, Hh, Ww) in ((4, 5, 8, 10), (7, 6, 13, 11)):
+        src = bf(torch.randn(B, C, h, w, generator=g))
+        dst = bf(torch.randn(B, C, Hh, Ww, generator=g))
+        ref = bf(dst + F.interpolate(src, size=(Hh, Ww), mode='nearest'))
+        d = nhwc_rows(dst).cuda().bfloat16()
+        ho.upsample_add_(d, ho.Seg(B, Hh, Ww), nhwc_rows(src).cuda().bfloat16(), ho.Seg(B, h, w))
+        assert torch.equal(rows_nchw(d, B, Hh, Ww).float().cpu(), ref)
+        gd = bf(torch.randn(B, C, Hh, Ww, generator=g))
+        s_ = src.clone().requires_grad_(True)
+        F.interpolate(s_, size=(Hh, Ww), mode='nearest').backward(gd)
+        gs = torch.zeros(B * h * w, C, device='cuda', dtype=torch.bfloat16)
+        ho.upsample_add_bwd_(gs, ho.Seg(B, h, w), nhwc_rows(gd).cuda().bfloat16(), ho.Seg(B, Hh, Ww))
+        assert close(rows_nchw(gs, B, h, w), s_.grad, 1e-2, 2e-2)
+    a, b = bf(torch.randn(1000, 64, generator=g)), bf(torch.randn(1000, 64, generator=g))
+    assert torch.equal(ho.add_relu(a.cuda().bfloat16(), b.cuda().bfloat16()).float().cpu(), bf(F.relu(a + b)))
+
+
+def test_act_bwd_bn_and_bias(ho):
+    g = synth.gen(6)
+    M, N = 1500, 320
+    z = bf(torch.randn(M, N, generator=g))
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    mean, var = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    zz = z.clone().requires_grad_(True)
+    gm_, bt_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = F.relu((zz - mean) * invstd * gm_ + bt_)
+    gout = bf(torch.randn(M, N, generator=g))
+    a.backward(gout)
+    dz, gmk, dbeta, dgamma = ho.act_bwd(gout.cuda().bfloat16(), bf(a.detach()).cuda().bfloat16(), z.cuda().bfloat16(),
+                                        (gamma * invstd).cuda(), mean.cuda(), invstd.cuda(), relu=True, want_gm=True)
+    torch.cuda.synchronize()
+    assert close(dz, zz.grad, 1e-2, 1e-2)
+    assert close(dbeta, bt_.grad, 1e-3, 1e-2) and close(dgamma, gm_.grad, 1e-3, 2e-2)
+    assert close(gmk, gout * (a.detach() > 0), 1e-2, 1e-3)
+    # bias-only mode with fp32 upstream gradient, no relu
+    g32 = torch.randn(M, N, generator=g)
+    dz2, _, db2, dg2 = ho.act_bwd(g32.cuda(), relu=False)
+    assert dg2 is None and close(db2, g32.sum(0), 1e-4, 1e-3) and close(dz2, g32, 1e-2, 1e-3)
+
+
+def test_losses_match_reference_golden(ho):
+    gold = np.load(os.path.join(G, 'losses.npz'))
+    li = synth.loss_inputs()
+    n = li['num_total_samples']
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in li.items()}
+    noR, sums = ho.edl_focal_l1_fwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'])
+    torch.cuda.synchronize()
+    assert np.allclose(noR.cpu().numpy(), gold['loss_noR'], rtol=2e-5, atol=1e-7)
+    s = sums.cpu().numpy()
+    assert np.allclose(s[0] / n, gold['loss_cls'], rtol=1e-5) and np.allclose(s[1] / n, gold['loss_bbox'], rtol=1e-5)
+    assert np.allclose(s[2] / 1024, gold['loss_noR'].mean(), rtol=1e-5)
+    one = torch.full((1,), 1.0 / n, device='cuda')
+    gc, gb = ho.edl_focal_l1_bwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'],
+                                 one, one, None, 1.0 / 1024)
+    assert np.allclose(gc.cpu().numpy(), gold['grad_logits'], rtol=5e-4, atol=2e-7)
+    assert np.array_equal(gb.cpu().numpy(), gold['grad_bbox'])
+    # padded bf16 dZ layout: A = 4 anchors per pixel, pitch 88 (>= 4*20), bbox pitch 16
+    gc2, gb2 = ho.edl_focal_l1_bwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'],
+                                   one, one, None, 1.0 / 1024, out_bf16=True, A=4, pitch_cls=88, pitch_box=16)
+    ref = torch.from_numpy(gold['grad_logits']).view(256, 80)
+    assert close(gc2[:, :80], ref, 1e-2, 1e-6) and (gc2[:, 80:] == 0).all()
+    # MEH
+    lam = dev['lam']
+    out = ho.meh_loss_fwd(lam, noR, dev['bbox_weights'])
+    assert np.allclose(out.item() / 1024 * 5, gold['loss_L'], rtol=1e-5)
+    gl = ho.meh_loss_bwd(lam, noR, dev['bbox_weights'], torch.full((1,), 5.0 / 1024, device='cuda'))
+    assert np.allclose(gl.cpu().numpy().reshape(-1), gold['grad_lam'], rtol=1e-4, atol=1e-9)
+
+
+def test_losses_edge_cases(ho):
+    """All-background rows, extreme logits (softmax saturation -> clamps), zero rows."""
+    x = torch.tensor([[50., -50.] + [0.] * 18, [-80.] * 19 + [80.], [0.] * 20], device='cuda')
+    lab = torch.tensor([0, 20, 19], device='cuda')
+    lw = torch.ones(3, device='cuda')
+    noR, _ = ho.edl_focal_l1_fwd(x, lab, lw)
+    ref = olosses.edl_softmax_focal_none(x.cpu(), lab.cpu()).sum(-1)
+    assert torch.isfinite(noR).all() and close(noR, ref, 1e-4, 1e-6)
+    e, s = ho.edl_focal_l1_fwd(torch.zeros(0, 20, device='cuda'), torch.zeros(0, dtype=torch.long, device='cuda'), torch.zeros(0, device='cuda'))
+    assert e.numel() == 0 and float(s.sum()) == 0
+
+
+def test_cpu_tensor_is_refused(ho):
+    from aod_meh_hua_amd._C import AodHipError
+    with pytest.raises(AodHipError):
+        ho.add_relu(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
