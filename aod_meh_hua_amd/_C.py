@@ -47,12 +47,15 @@ _SIGS = {
     'aod_upsample2x_add_bwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
     'aod_act_bwd': (C.c_int, [P, P, P, P, P, P, P, P, P, P, I64, I32, I32, I32, P]),
     'aod_add_relu': (C.c_int, [P, P, P, I64, P]),
+    'aod_pad_cast_colsum': (C.c_int, [P, P, P, P, I64, I32, I32, I32, P]),
+    'aod_assign_ws_bytes': (SZ, [I32, I32]),
+    'aod_max_iou_assign': (C.c_int, [P, P, I64, I32, P, P, P, I32, F32, F32, F32, I32, I32, P, P, P, P, P, P, P, P, P, I32, P, P]),
     'aod_loss_partials_len': (SZ, [I64]),
     'aod_edl_focal_l1_fwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, P]),
     'aod_edl_focal_l1_bwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, F32, P, P, I32, I32, I32, I32, P]),
     'aod_meh_loss_fwd': (C.c_int, [P, P, P, I64, P, P, P]),
     'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
-    'aod_sgd_multi': (C.c_int, [P, P, I32, I64, F32, F32, F32, I32, F32, P]),
+    'aod_sgd_multi': (C.c_int, [P, P, P, P, I32, F32, F32, F32, I32, F32, P]),
 }
 for _n, (_r, _a) in _SIGS.items():
     if hasattr(lib, _n):

@@ -229,14 +229,22 @@ extern "C" int aod_act_bwd(const void* g, const void* a, const void* z, const fl
 }
 
 // ---------------------------------------------------------------- multi-tensor SGD (torch.optim.SGD semantics)
-__global__ void sgd_multi_kernel(void* const* __restrict__ ptrs, const long long* __restrict__ sizes, int blocks_per_tensor,
-                                 float lr, float momentum, float wd, int first_step, float grad_scale) {
+// Pointers travel as kernel arguments (<= 48 tensors per launch): no device-side table, no H2D copy, no sync.
+struct SgdChunk {
+  float* p[48];
+  const float* g[48];
+  float* m[48];
+  long long n[48];
+  int count;
+};
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int blocks_per_tensor, float lr, float momentum, float wd,
+                                                        int first_step, float grad_scale) {
   const int ti = blockIdx.x / blocks_per_tensor, bi = blockIdx.x % blocks_per_tensor;
-  float* p = (float*)ptrs[3 * ti];
-  const float* g = (const float*)ptrs[3 * ti + 1];
-  float* mbuf = (float*)ptrs[3 * ti + 2];
-  const long long n = sizes[ti];
-  for (long long i = (long long)bi * blockDim.x + threadIdx.x; i < n; i += (long long)blocks_per_tensor * blockDim.x) {
+  float* p = c.p[ti];
+  const float* g = c.g[ti];
+  float* mbuf = c.m[ti];
+  const long long n = c.n[ti];
+  for (long long i = (long long)bi * 256 + threadIdx.x; i < n; i += (long long)blocks_per_tensor * 256) {
     const float pv = p[i];
     const float d = g[i] * grad_scale + wd * pv;
     const float b = first_step ? d : momentum * mbuf[i] + d;
@@ -244,14 +252,56 @@ __global__ void sgd_multi_kernel(void* const* __restrict__ ptrs, const long long
     p[i] = pv - lr * b;
   }
 }
-extern "C" int aod_sgd_multi(void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+extern "C" int aod_sgd_multi(void* const* params, void* const* grads, void* const* moms, const int64_t* sizes, int ntensors,
                              float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream) {
-  AOD_CHECK_ARG(ptrs_dev && sizes_dev && ntensors > 0, "sgd_multi: bad args");
-  int bpt = (int)((max_size + 256 * 8 - 1) / (256 * 8));
-  if (bpt < 1) bpt = 1;
-  if (bpt > 64) bpt = 64;
-  hipLaunchKernelGGL(sgd_multi_kernel, dim3(ntensors * bpt), dim3(256), 0, (hipStream_t)stream, ptrs_dev, (const long long*)sizes_dev, bpt,
-                     lr, momentum, weight_decay, first_step, grad_scale);
+  AOD_CHECK_ARG(params && grads && moms && sizes && ntensors >= 0, "sgd_multi: bad args");
+  for (int s0 = 0; s0 < ntensors; s0 += 48) {
+    SgdChunk c;
+    c.count = ntensors - s0 < 48 ? ntensors - s0 : 48;
+    long long mx = 0;
+    for (int i = 0; i < c.count; ++i) {
+      c.p[i] = (float*)params[s0 + i]; c.g[i] = (const float*)grads[s0 + i]; c.m[i] = (float*)moms[s0 + i]; c.n[i] = sizes[s0 + i];
+      AOD_CHECK_ARG(c.p[i] && c.g[i] && c.m[i], "sgd_multi: null tensor pointer");
+      if (c.n[i] > mx) mx = c.n[i];
+    }
+    int bpt = (int)((mx + 256 * 16 - 1) / (256 * 16));
+    if (bpt < 1) bpt = 1;
+    if (bpt > 96) bpt = 96;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(c.count * bpt), dim3(256), 0, (hipStream_t)stream, c, bpt, lr, momentum, weight_decay, first_step, grad_scale);
+  }
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- pad + cast + column sums (prediction-conv gradients, N = 180 / 36 / 9)
+// dz[m][c] = g[m][c] * (a[m][c] > 0 if a given -- fused ReLU of retina_L, Lambda_L2.py:101), zero in the pad columns.
+template <bool G_F32>
+__global__ __launch_bounds__(256) void pad_cast_colsum_kernel(const void* __restrict__ g_, const float* __restrict__ a, bf16_t* __restrict__ dz,
+                                                              float* __restrict__ colsum, long long M, int N, int Npad, int rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < Npad; c += 256) {
+    float s = 0.f;
+    for (long long m = r0; m < r1; ++m) {
+      float v = 0.f;
+      if (c < N) {
+        v = G_F32 ? ((const float*)g_)[m * N + c] : (float)((const bf16_t*)g_)[m * N + c];
+        if (a && !(a[m * N + c] > 0.f)) v = 0.f;
+      }
+      dz[m * Npad + c] = (bf16_t)v;
+      s += v;
+    }
+    if (c < N) atomicAdd(colsum + c, s);
+  }
+}
+extern "C" int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, int Npad, int g_is_f32,
+                                   aod_stream_t stream) {
+  if (M == 0) return 0;
+  AOD_CHECK_ARG(g && dz && colsum && Npad >= N && Npad % 8 == 0, "pad_cast_colsum: bad args");
+  int rpb = (int)((M + 1023) / 1024);
+  if (rpb < 16) rpb = 16;
+  const int nb = (int)((M + rpb - 1) / rpb);
+  if (g_is_f32) hipLaunchKernelGGL((pad_cast_colsum_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb);
+  else hipLaunchKernelGGL((pad_cast_colsum_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,291 @@
+"""Autograd wrappers around the HIP kernels (C ABI via hipops).  No torch compute ops on the hot
+path: every forward/backward below enqueues hand-written gfx950 kernels; torch supplies device
+memory, the autograd tape and streams.
+
+Tensor convention between modules: logical shape [B, C, H, W] (what the reference's host code
+indexes), memory = NHWC bf16 (torch.channels_last), i.e. a [B*H*W, C] row tensor for the kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import hipops as ho
+from .hipops import Seg
+
+
+# --------------------------------------------------------------------------- layout helpers
+def as_rows(x):
+    """[B,C,H,W] channels_last -> [B*H*W, C] view (copies only if the caller handed NCHW-contiguous data)."""
+    B, C, H, W = x.shape
+    xr = x.permute(0, 2, 3, 1)
+    if not xr.is_contiguous():
+        xr = xr.contiguous()
+    return xr.view(B * H * W, C)
+
+
+def as_nchw(rows, B, H, W):
+    return rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2)
+
+
+def multi_rows(tensors):
+    """Several [B,C,H,W] tensors (pyramid levels) -> (base row tensor, segs) without copying when
+    every level starts a whole number of rows after the lowest-addressed one; else one torch.cat."""
+    rows = [as_rows(t) for t in tensors]
+    if len(rows) == 1:
+        t = tensors[0]
+        return rows[0], [Seg(t.shape[0], t.shape[2], t.shape[3], 0)]
+    rb = rows[0].shape[1] * rows[0].element_size()
+    base = min(rows, key=lambda r: r.data_ptr())
+    offs = [r.data_ptr() - base.data_ptr() for r in rows]
+    if all(o % rb == 0 for o in offs):
+        return base, [Seg(t.shape[0], t.shape[2], t.shape[3], o // rb) for t, o in zip(tensors, offs)]
+    cat = torch.cat(rows)
+    segs, r0 = [], 0
+    for t in tensors:
+        segs.append(Seg(t.shape[0], t.shape[2], t.shape[3], r0))
+        r0 += t.shape[0] * t.shape[2] * t.shape[3]
+    return cat, segs
+
+
+def dense_segs(segs):
+    out, r = [], 0
+    for s in segs:
+        out.append(Seg(s.B, s.H, s.W, r))
+        r += s.rows
+    return out
+
+
+class _VersionCache:
+    """Derived tensors (packed weights, folded BN) keyed by the source tensors' (id, _version)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, tag, srcs, make):
+        key = (tag,) + tuple(id(s) for s in srcs)
+        ver = tuple(s._version for s in srcs)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver and all(r() is s for r, s in zip(hit[2], srcs)):
+            return hit[1]
+        import weakref
+        val = make()
+        self.store[key] = (ver, val, [weakref.ref(s) for s in srcs])
+        return val
+
+
+CACHE = _VersionCache()
+
+
+def fold_bn(gamma, beta, mean, var, eps):
+    """Eval-mode BN as y = z*scale + shift (resnet.py:647-656 norm_eval): scale = gamma*rsqrt(var+eps)."""
+    def make():
+        with torch.no_grad():
+            invstd = torch.rsqrt(var.float() + eps)
+            scale = gamma.float() * invstd
+            shift = beta.float() - mean.float() * scale
+        return scale, shift, invstd
+    return CACHE.get('bn', (gamma, beta, mean, var), make)
+
+
+# --------------------------------------------------------------------------- conv (+BN/bias, +res, +ReLU)
+class ConvFn(Function):
+    """y = act(conv(x, w) * scale + shift + res) over one or several pyramid levels sharing `w`.
+
+    forward(ctx, meta, w, gamma, beta, mean, var, bias, res, *xs) -> tuple(len(xs)) of [B,N,OH,OW]
+    meta: dict(stride, pad, dil, relu, out_f32, eps)."""
+
+    @staticmethod
+    def forward(ctx, meta, w, gamma, beta, mean, var, bias, res, *xs):
+        O, I, R, S = w.shape
+        cin = xs[0].shape[1]
+        x_rows, x_segs = multi_rows(xs)
+        wp = CACHE.get('wf%d' % cin, (w,), lambda: ho.pack_weight_fwd(w.detach(), cin))
+        scale = shift = invstd = None
+        if gamma is not None:
+            scale, shift, invstd = fold_bn(gamma, beta, mean, var, meta['eps'])
+        elif bias is not None:
+            shift = bias.detach()
+        need_z = gamma is not None and ctx.needs_input_grad[2]
+        res_rows = as_rows(res) if res is not None else None
+        r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
+                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], save_z=need_z)
+        y_rows, y_segs = r[0], r[1]
+        z_rows = r[2] if need_z else None
+        ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
+        ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
+        ctx.nx = len(xs)
+        ctx.save_for_backward(w, gamma, mean, scale, invstd, x_rows, y_rows if meta['relu'] else None, z_rows)
+        outs = tuple(as_nchw(y_rows[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for s in y_segs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        w, gamma, mean, scale, invstd, x_rows, a_rows, z_rows = ctx.saved_tensors
+        meta = ctx.meta
+        O, I, R, S = w.shape
+        cin = x_rows.shape[1]
+        y_segs = ctx.y_segs
+        # gather the upstream gradient as one dense row tensor [M, O]
+        if len(gouts) == 1 and gouts[0] is not None:
+            g_rows = as_rows(gouts[0])
+        else:
+            parts = []
+            for g, s in zip(gouts, y_segs):
+                parts.append(as_rows(g) if g is not None else torch.zeros(s.rows, O, device=w.device, dtype=torch.bfloat16))
+            dt = torch.float32 if any(p.dtype == torch.float32 for p in parts) else torch.bfloat16
+            g_rows = torch.cat([p.to(dt) for p in parts])
+        dsegs = dense_segs(y_segs)
+        Opad = (O + 7) // 8 * 8
+        need_w = ctx.needs_input_grad[1]
+        need_x = any(ctx.needs_input_grad[8:])
+        need_res = ctx.has_res and ctx.needs_input_grad[7]
+        gw = ggamma = gbeta = gbias = gres = None
+        if Opad != O:
+            # prediction convs (N = 180 / 36 / 9): pad + cast + column sums in one pass
+            dz, gbias_v = ho.pad_cast_colsum(g_rows, Opad, a_rows if meta['relu'] else None)
+            gm = None
+        else:
+            relu = meta['relu']
+            if ctx.has_bn:
+                need_bn = ctx.needs_input_grad[2]
+                dz, gm, dbeta, dgamma = ho.act_bwd(g_rows, a_rows, z_rows if need_bn else None, scale, mean.float() if need_bn else None,
+                                                  invstd if need_bn else None, relu=relu, want_gm=need_res)
+                if need_bn:
+                    ggamma, gbeta = dgamma.to(gamma.dtype), dbeta
+                gbias_v = None
+            else:
+                plain = (not relu) and g_rows.dtype == torch.bfloat16 and not need_res
+                dz, gm, dbeta, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=need_res, want_dz=not plain)
+                if plain:
+                    dz = g_rows
+                gbias_v = dbeta
+        if ctx.has_bias and ctx.needs_input_grad[6]:
+            gbias = gbias_v[:O]
+        if need_res:
+            s = y_segs[0]
+            gres = as_nchw(gm, s.B, s.H, s.W)
+        x_segs = ctx.x_segs
+        if need_w:
+            dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'])
+            gw = ho.unpack_wgrad(dw, O, I)
+        gxs = [None] * ctx.nx
+        if need_x:
+            wd = CACHE.get('wd%d' % Opad, (w,), lambda: ho.pack_weight_dgrad(w.detach(), Opad))
+            if I != cin:   # stem: channel-padded input; dX only for the real channels is never needed (image)
+                raise RuntimeError('dgrad through a channel-padded input is not supported')
+            xd = dense_segs(x_segs)
+            dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'])
+            gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
+                   for i, s in enumerate(xd)]
+        return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
+
+
+def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False):
+    """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps."""
+    single = torch.is_tensor(xs)
+    xl = [xs] if single else list(xs)
+    meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0)
+    if bn is not None:
+        outs = ConvFn.apply(meta, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, res, *xl)
+    else:
+        outs = ConvFn.apply(meta, w, None, None, None, None, bias, res, *xl)
+    return outs[0] if single else list(outs)
+
+
+# --------------------------------------------------------------------------- stem helpers
+def image_to_nhwc(img, cpad=8):
+    """fp32 NCHW image batch -> bf16 NHWC rows viewed as [B, cpad, H, W] (no grad: images are leaves)."""
+    B, C, H, W = img.shape
+    rows, _ = ho.nchw_to_rows(img.detach().float(), cpad)
+    return as_nchw(rows, B, H, W)
+
+
+def max_pool_3x3_s2(x):
+    """resnet.py:610 -- only used inside the frozen stem (no backward needed)."""
+    assert not x.requires_grad, 'maxpool backward is not implemented (stem is frozen, resnet.py:612-628)'
+    B, C, H, W = x.shape
+    rows, s = ho.maxpool3x3s2(as_rows(x), Seg(B, H, W))
+    return as_nchw(rows, s.B, s.H, s.W)
+
+
+class UpsampleAddFn(Function):
+    """FPN top-down step: out = lateral + nearest_upsample(top)  (fpn.py:163-172)."""
+
+    @staticmethod
+    def forward(ctx, lateral, top):
+        B, C, H, W = lateral.shape
+        h, w = top.shape[2:]
+        out = as_rows(lateral).clone()
+        ho.upsample_add_(out, Seg(B, H, W), as_rows(top), Seg(B, h, w))
+        ctx.dims = (B, C, H, W, h, w)
+        return as_nchw(out, B, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, h, w = ctx.dims
+        g_rows = as_rows(g)
+        gt = None
+        if ctx.needs_input_grad[1]:
+            gt_rows = torch.zeros(B * h * w, C, device=g.device, dtype=torch.bfloat16)
+            ho.upsample_add_bwd_(gt_rows, Seg(B, h, w), g_rows, Seg(B, H, W))
+            gt = as_nchw(gt_rows, B, h, w)
+        return (g if ctx.needs_input_grad[0] else None), gt
+
+
+def upsample_add(lateral, top):
+    return UpsampleAddFn.apply(lateral, top)
+
+
+# --------------------------------------------------------------------------- losses
+class RetinaLossFn(Function):
+    """Per level: (loss_cls_sum, loss_bbox_sum, loss_noR[N]) = fused EDL softmax-focal + L1
+    (Lambda_L2.py:112-121).  Sums are NOT yet divided by avg_factor (done by the caller with a
+    device scalar so that no host sync is needed)."""
+
+    @staticmethod
+    def forward(ctx, cls_score, bbox_pred, labels, label_w, bbox_t, bbox_w, gamma, alpha, num_classes):
+        B, AC, H, W = cls_score.shape
+        A = AC // num_classes
+        cls_rows = as_rows(cls_score).view(-1, num_classes)
+        box_rows = as_rows(bbox_pred).view(-1, 4)
+        labels = labels.reshape(-1).contiguous()
+        label_w = label_w.reshape(-1).contiguous()
+        bbox_t = bbox_t.reshape(-1, 4).contiguous()
+        bbox_w = bbox_w.reshape(-1, 4).contiguous()
+        noR, sums = ho.edl_focal_l1_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, gamma, alpha)
+        ctx.save_for_backward(cls_rows, box_rows, labels, label_w, bbox_t, bbox_w)
+        ctx.cfg = (gamma, alpha, cls_score.shape, bbox_pred.shape)
+        return sums[0], sums[1], noR
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, g_noR):
+        cls_rows, box_rows, labels, label_w, bbox_t, bbox_w = ctx.saved_tensors
+        gamma, alpha, cshape, bshape = ctx.cfg
+        dev = cls_rows.device
+        g_cls = torch.zeros(1, device=dev) if g_cls is None else g_cls.reshape(1).float().contiguous()
+        g_box = torch.zeros(1, device=dev) if g_box is None else g_box.reshape(1).float().contiguous()
+        g_noR_t = None if g_noR is None else g_noR.float().contiguous()
+        gc, gb = ho.edl_focal_l1_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, g_cls, g_box, g_noR_t, 0.0, gamma, alpha)
+        B, AC, H, W = cshape
+        return (as_nchw(gc.view(B * H * W, AC), B, H, W), as_nchw(gb.view(B * H * W, bshape[1]), B, H, W),
+                None, None, None, None, None, None, None)
+
+
+class MEHLossFn(Function):
+    """sum(((|lambda + 1e-9 - loss_noR|) * w)^2) for one level (Lambda_L2.py:235-241)."""
+
+    @staticmethod
+    def forward(ctx, L_score, loss_noR, bbox_w):
+        lam = as_rows(L_score).view(-1)
+        bw = bbox_w.reshape(-1, 4).contiguous()
+        loss_noR = loss_noR.contiguous()
+        out = ho.meh_loss_fwd(lam, loss_noR, bw)
+        ctx.save_for_backward(lam, loss_noR, bw)
+        ctx.shape = L_score.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lam, loss_noR, bw = ctx.saved_tensors
+        B, A, H, W = ctx.shape
+        gl = ho.meh_loss_bwd(lam, loss_noR, bw, g.reshape(1).float().contiguous())
+        return as_nchw(gl.view(B * H * W, A), B, H, W), None, None

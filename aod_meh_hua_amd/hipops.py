@@ -207,3 +207,37 @@ def meh_loss_bwd(lam, loss_noR, bbox_w4, g, out_bf16=False, A=1, pitch=None, gra
         grad = torch.zeros(n // A, pitch, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=lam.device)
     call('aod_meh_loss_bwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), n, ptr(g), ptr(grad), int(out_bf16), A, pitch, stream())
     return grad
+
+
+def pad_cast_colsum(g, npad, relu_out=None):
+    M, N = g.shape
+    assert relu_out is None or relu_out.dtype == torch.float32
+    dz = torch.empty(M, npad, dtype=torch.bfloat16, device=g.device)
+    cs = torch.zeros(npad, dtype=torch.float32, device=g.device)
+    call('aod_pad_cast_colsum', ptr(g), ptr(relu_out), ptr(dz), ptr(cs), M, N, npad, int(g.dtype == torch.float32), stream())
+    return dz, cs
+
+
+_F4 = C.c_float * 4
+
+
+def max_iou_assign(anchors, valid, gts, gt_count, gt_labels, pos_thr=0.5, neg_thr=0.4, min_pos_iou=0.0, assign_all=True,
+                   num_classes=20, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), level_start=None):
+    """anchors [A,4] f32, valid [B,A] uint8/bool or None, gts [B,Gmax,4], gt_count [B] int32, gt_labels [B,Gmax] int64."""
+    A = anchors.shape[0]
+    B, Gmax = gts.shape[:2]
+    dev = anchors.device
+    assigned = torch.empty(B, A, dtype=torch.int64, device=dev)
+    labels = torch.empty(B, A, dtype=torch.int64, device=dev)
+    label_w = torch.empty(B, A, dtype=torch.float32, device=dev)
+    bbox_t = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
+    bbox_w = torch.empty(B, A, 4, dtype=torch.float32, device=dev)
+    num_pos = torch.empty(B, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(int(_C.lib.aod_assign_ws_bytes(B, Gmax)), 8), dtype=torch.uint8, device=dev)
+    if valid is not None:
+        valid = valid.view(torch.uint8) if valid.dtype == torch.bool else valid
+    call('aod_max_iou_assign', ptr(anchors), ptr(valid), A, B, ptr(gts), ptr(gt_count), ptr(gt_labels), Gmax, pos_thr, neg_thr,
+         min_pos_iou, int(assign_all), num_classes, _F4(*means), _F4(*stds), ptr(assigned), ptr(labels), ptr(label_w), ptr(bbox_t),
+         ptr(bbox_w), ptr(num_pos), ptr(ws), 0 if level_start is None else len(level_start) - 1,
+         None if level_start is None else (C.c_int64 * len(level_start))(*level_start), stream())
+    return assigned, labels, label_w, bbox_t, bbox_w, num_pos

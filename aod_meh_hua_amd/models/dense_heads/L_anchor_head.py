@@ -1,0 +1,168 @@
+"""L_AnchorHead: anchor-based dense-head base with the reference's interface
+(mmdet/models/dense_heads/L_anchor_head.py:36-356): builds coder / assigner / sampler / anchor generator /
+losses from config, `get_anchors`, `get_targets`, `loss` (returns (dict, head_out)), `loss_L`, `get_bboxes`.
+
+MI355X re-design of the target pipeline: anchors and valid flags are cached per shape; assignment +
+pseudo-sampling + delta encoding + unmap + images_to_levels for ALL images of the batch is one call into
+the HIP kernels (3 launches) that writes level-major outputs, instead of the reference's per-image Python
+loop of small torch ops (`_get_targets_single`, :155-202)."""
+import torch
+
+from ...core.anchor import build_anchor_generator
+from ...core.bbox import build_assigner, build_bbox_coder, build_sampler
+from ...core.utils import multi_apply
+from ...mmcv_lite import BaseModule, Conv2d, force_fp32
+from ..builder import HEADS, build_loss
+
+_NO_SAMPLING = ['EDL_Loss', 'EDL_Loss_2', 'EDL_Loss_3', 'EDL_Loss_BCE', 'FocalLoss', 'GHMC', 'QualityFocalLoss', 'EDL_FocalLoss',
+                'EDL_BetaFocalLoss', 'EDL_FocalLoss_Dummy', 'EDL_Softmax_FocalLoss', 'EDL_Softmax_FocalLoss_Dummy',
+                'EDL_Softmax_SL_FocalLoss', 'SSL_EDL_Softmax_FocalLoss']
+
+
+def pack_gts(gt_bboxes, gt_labels, device):
+    """list of [G_i,4] / [G_i] -> ([B,Gmax,4] f32, [B] int32 counts, [B,Gmax] int64); sizes are host-known."""
+    B = len(gt_bboxes)
+    counts = [int(g.shape[0]) for g in gt_bboxes]
+    gmax = max(max(counts), 1)
+    gts = torch.zeros(B, gmax, 4, device=device)
+    labs = torch.zeros(B, gmax, dtype=torch.long, device=device)
+    if sum(counts) > 0:
+        bi = torch.tensor([b for b, c in enumerate(counts) for _ in range(c)], dtype=torch.long)
+        gi = torch.tensor([i for c in counts for i in range(c)], dtype=torch.long)
+        bi, gi = bi.to(device, non_blocking=True), gi.to(device, non_blocking=True)
+        gts[bi, gi] = torch.cat([g.to(device).float().reshape(-1, 4) for g in gt_bboxes])
+        if gt_labels is not None:
+            labs[bi, gi] = torch.cat([l.to(device).long().reshape(-1) for l in gt_labels])
+    return gts, torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True), labs
+
+
+@HEADS.register_module()
+class L_AnchorHead(BaseModule):
+    def __init__(self, num_classes, in_channels, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator', scales=[8, 16, 32], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True, target_means=(.0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False, loss_cls=dict(type='CrossEntropyLoss', last_activation='sigmoid', loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0), train_cfg=None, test_cfg=None,
+                 init_cfg=dict(type='Normal', layer='Conv2d', std=0.01)):
+        super().__init__(init_cfg)
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, num_classes, feat_channels
+        self.last_activation = loss_cls.get('last_activation')
+        self.sampling = loss_cls['type'] not in _NO_SAMPLING
+        if self.last_activation in ('sigmoid', 'relu'):
+            self.cls_out_channels = num_classes
+        elif self.last_activation in ('softmax', 'EDL_BG'):
+            self.cls_out_channels = num_classes + 1
+        if self.cls_out_channels <= 0:
+            raise ValueError(f'num_classes={num_classes} is too small')
+        self.reg_decoded_bbox = reg_decoded_bbox
+        assert not reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            sampler_cfg = self.train_cfg.sampler if (self.sampling and hasattr(self.train_cfg, 'sampler')) else dict(type='PseudoSampler')
+            self.sampler = build_sampler(sampler_cfg, context=self)
+        self.fp16_enabled = False
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+
+    def _init_layers(self):
+        self.conv_cls = Conv2d(self.in_channels, self.num_anchors * self.cls_out_channels, 1)
+        self.conv_reg = Conv2d(self.in_channels, self.num_anchors * 4, 1)
+
+    def forward_single(self, x):
+        return self.conv_cls(x, out_f32=True), self.conv_reg(x, out_f32=True)
+
+    def forward(self, feats):
+        return multi_apply(self.forward_single, feats)
+
+    # ------------------------------------------------------------------ anchors / targets
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        """L_anchor_head.py:129-153 (cached; the per-image lists alias the same tensors)."""
+        mlvl = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchor_list = [mlvl for _ in range(len(img_metas))]
+        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, m['pad_shape'], device) for m in img_metas]
+        return anchor_list, valid_flag_list
+
+    def get_targets_batch(self, featmap_sizes, img_metas, gt_bboxes, gt_labels, device):
+        """get_targets + _get_targets_single (L_anchor_head.py:155-257) for the whole batch on the GPU.
+        Returns per-level lists (labels [B,A_l], label_weights, bbox_targets [B,A_l,4], bbox_weights),
+        num_total_pos (0-d device tensor = sum_b max(#pos_b, 1)), num_level_anchors."""
+        assert self.train_cfg.allowed_border < 0, 'allowed_border >= 0 is not used by the AL configs'
+        assert self.train_cfg.get('pos_weight', -1) <= 0
+        ag = self.anchor_generator
+        flat = ag.flat_grid_anchors(featmap_sizes, device)
+        nla = [a.shape[0] for a in ag.grid_anchors(featmap_sizes, device)]
+        B = len(img_metas)
+        pad_shapes = [tuple(int(v) for v in m['pad_shape'][:2]) for m in img_metas]
+        flags = [ag.flat_valid_flags(featmap_sizes, ps, device) for ps in pad_shapes]
+        key = ('allv', tuple(pad_shapes), tuple(map(tuple, featmap_sizes)))
+        cache = ag._cache
+        if key not in cache:
+            cache[key] = all(bool(f.all()) for f in flags)          # one-time host check per shape
+        valid = None if cache[key] else torch.stack(flags).to(torch.uint8)
+        gts, counts, labs = pack_gts(gt_bboxes, gt_labels, device)
+        starts = [0]
+        for n in nla:
+            starts.append(starts[-1] + n)
+        assigned, labels, lw, bt, bw, num_pos = self._assign(flat, valid, gts, counts, labs, starts)
+        labels_l, lw_l, bt_l, bw_l = [], [], [], []
+        lab_f, lw_f, bt_f, bw_f = labels.view(-1), lw.view(-1), bt.view(-1, 4), bw.view(-1, 4)
+        for l, n in enumerate(nla):
+            s, e = starts[l] * B, starts[l + 1] * B
+            labels_l.append(lab_f[s:e].view(B, n)), lw_l.append(lw_f[s:e].view(B, n))
+            bt_l.append(bt_f[s:e].view(B, n, 4)), bw_l.append(bw_f[s:e].view(B, n, 4))
+        num_total_pos = num_pos.clamp(min=1).sum().float()
+        return labels_l, lw_l, bt_l, bw_l, num_total_pos, nla
+
+    def _assign(self, flat, valid, gts, counts, labs, starts):
+        from ... import hipops as ho
+        a = self.assigner
+        return ho.max_iou_assign(flat, valid, gts, counts, labs, float(a.pos_iou_thr), float(a.neg_iou_thr), float(a.min_pos_iou),
+                                 bool(a.gt_max_assign_all), self.num_classes, tuple(self.bbox_coder.means), tuple(self.bbox_coder.stds),
+                                 level_start=starts)
+
+    # ------------------------------------------------------------------ losses
+    @force_fp32(apply_to=('cls_scores', 'bbox_preds', 'd_scores'))
+    def loss(self, cls_scores, bbox_preds, D_scores, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None, **kwargs):
+        """L_anchor_head.py:290-320: returns (dict(loss_cls, loss_bbox, loss_noR), head_out)."""
+        featmap_sizes = [tuple(f.shape[-2:]) for f in cls_scores]
+        assert len(featmap_sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        labels_list, lw_list, bt_list, bw_list, num_total_pos, nla = self.get_targets_batch(featmap_sizes, img_metas, gt_bboxes, gt_labels, device)
+        assert not self.sampling
+        num_total_samples = num_total_pos
+        B = cls_scores[0].shape[0]
+        mlvl = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        all_anchor_list = [a[None].expand(B, a.shape[0], 4) for a in mlvl]
+        head_info = ['cls_scores', 'bbox_preds', 'all_anchor_list', 'labels_list', 'label_weights_list', 'bbox_targets_list',
+                     'bbox_weights_list', 'num_total_samples']
+        head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
+        losses_cls, losses_bbox, losses_noR = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list,
+                                                          bt_list, bw_list, list(range(len(cls_scores))),
+                                                          num_total_samples=num_total_samples, featmap_sizes=featmap_sizes, **kwargs)
+        return dict(loss_cls=losses_cls, loss_bbox=losses_bbox, loss_noR=losses_noR), head_out
+
+    @force_fp32(apply_to=('L_scores'))
+    def loss_L(self, L_scores, head_out, losses, **kwargs):
+        """L_anchor_head.py:322-327."""
+        losses_L, _ = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], **kwargs)
+        return dict(loss_L=losses_L)
+
+    # ------------------------------------------------------------------ scoring
+    @force_fp32(apply_to=('cls_scores', 'bbox_preds'))
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True, **kwargs):
+        """L_anchor_head.py:329-356."""
+        assert len(cls_scores) == len(bbox_preds)
+        device = cls_scores[0].device
+        featmap_sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        mlvl_cls_scores = [c.detach() for c in cls_scores]
+        mlvl_bbox_preds = [b.detach() for b in bbox_preds]
+        B = cls_scores[0].shape[0]
+        img_shapes = [img_metas[i]['img_shape'] for i in range(B)]
+        scale_factors = [img_metas[i]['scale_factor'] for i in range(B)]
+        return self._get_bboxes(mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes, scale_factors, cfg, rescale, with_nms, **kwargs)

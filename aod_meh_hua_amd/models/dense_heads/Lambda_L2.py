@@ -1,0 +1,127 @@
+"""Lambda_L2Net: RetinaNet head + Model Evidence Head (MEH) + HUA scoring, with the reference's
+interface (mmdet/models/dense_heads/Lambda_L2.py:19-749).
+
+MI355X re-design:
+  * the three towers (cls / reg / L: 4 x [3x3 conv 256->256 + ReLU], weights shared across the five
+    pyramid levels) run LEVEL-BATCHED: one implicit-GEMM launch per conv covers all five levels
+    (M = B*5456 rows at 512^2) instead of the reference's 5 x multi_apply launches per conv
+    (forward_single, :85-103); bias + ReLU are fused in the epilogue;
+  * prediction convs write fp32 NHWC, which IS the [B, H*W*A, C] layout the losses / scoring want,
+    so `permute(0,2,3,1).reshape` (:114,120,266) costs nothing;
+  * loss_single (:112-121) is one fused kernel per level (EDL softmax-focal + L1 + row sums);
+  * scoring (:254-384, 489-619) = softmax/row-max, stable top-k, gather+decode, class-aware greedy NMS
+    and the fused HUA kernel (Dirichlet sampling -> entropies -> (object, level, class) bins -> aggregate)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import functional as AF
+from ...core.utils import multi_apply
+from ...mmcv_lite import Conv2d, ConvModule, force_fp32
+from ..builder import HEADS
+from .L_anchor_head import L_AnchorHead
+
+
+@HEADS.register_module()
+class Lambda_L2Net(L_AnchorHead):
+    def __init__(self, num_classes, in_channels, stacked_convs=4, conv_cfg=None, norm_cfg=None,
+                 anchor_generator=dict(type='AnchorGenerator', octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0],
+                                       strides=[8, 16, 32, 64, 128]),
+                 init_cfg=dict(type='Normal', layer='Conv2d', std=0.01,
+                               override=dict(type='Normal', name='retina_cls', std=0.01, bias_prob=0.01)), **kwargs):
+        self.stacked_convs, self.conv_cfg, self.norm_cfg = stacked_convs, conv_cfg, norm_cfg
+        self.isTrainD = False
+        super().__init__(num_classes, in_channels, anchor_generator=anchor_generator, init_cfg=init_cfg, **kwargs)
+        self.L_names = ['retina_L', 'L_convs']
+
+    def _init_layers(self):
+        """Lambda_L2.py:38-54 (same attribute names -> same state_dict keys)."""
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs, self.reg_convs, self.L_convs = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            for tower in (self.cls_convs, self.reg_convs, self.L_convs):
+                tower.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1, conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        self.retina_cls = Conv2d(self.feat_channels, self.num_anchors * self.cls_out_channels, 3, padding=1)
+        self.retina_reg = Conv2d(self.feat_channels, self.num_anchors * 4, 3, padding=1)
+        self.retina_L = Conv2d(self.feat_channels, self.num_anchors, 3, padding=1)
+
+    # ------------------------------------------------------------------ forward
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        outs = self.forward(x, **kwargs)
+        loss_inputs = outs + (None, gt_bboxes, gt_labels, img_metas)
+        return self.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore, **kwargs)
+
+    def forward_train_L(self, prev_loss, head_out, x, **kwargs):
+        L_scores = self.forward_L(x, head_out, **kwargs)
+        return self.loss_L(L_scores, head_out, prev_loss, **kwargs)
+
+    def forward(self, feats, **kwargs):
+        """Lambda_L2.py:79-94, all levels per launch.  Returns (cls_scores[L], bbox_preds[L]) fp32 [B, A*C, h, w]."""
+        feats = list(feats)
+        cls_feat, reg_feat = feats, feats
+        for conv in self.cls_convs:
+            cls_feat = conv(cls_feat)
+        for conv in self.reg_convs:
+            reg_feat = conv(reg_feat)
+        return self.retina_cls(cls_feat, out_f32=True), self.retina_reg(reg_feat, out_f32=True)
+
+    def forward_L(self, feats, head_out=None, **kwargs):
+        """Lambda_L2.py:82-83,96-103: MEH tower + retina_L + ReLU (fused)."""
+        L_feat = list(feats)
+        for conv in self.L_convs:
+            L_feat = conv(L_feat)
+        return self.retina_L(L_feat, relu=True, out_f32=True)
+
+    def forward_single(self, x):
+        c, r = self.forward([x])
+        return c[0], r[0]
+
+    def forward_single_L(self, x):
+        return self.forward_L([x])[0], 0
+
+    # ------------------------------------------------------------------ losses
+    @force_fp32(apply_to=('cls_score', 'bbox_pred'))
+    def loss_single(self, cls_score, bbox_pred, anchors, labels, label_weights, bbox_targets, bbox_weights, sIdx, num_total_samples, **kwargs):
+        """Live branch of Lambda_L2.py:112-121 (Labeled and not Pseudo).  The Pseudo branch (:122-232) is never
+        entered by the AL driver (SURVEY 3.2 iv) and is not built."""
+        if not (kwargs.get('Labeled', True) and not kwargs.get('Pseudo', False)):
+            raise NotImplementedError('pseudo-label branch (Lambda_L2.py:122-232) is dead code in the reference driver')
+        assert type(self.loss_bbox).__name__ == 'L1Loss' and type(self.loss_cls).__name__ == 'EDL_Softmax_FocalLoss'
+        sum_cls, sum_box, loss_noR = AF.RetinaLossFn.apply(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
+                                                           float(self.loss_cls.gamma), float(self.loss_cls.alpha), self.cls_out_channels)
+        loss_cls = self.loss_cls.loss_weight * sum_cls / num_total_samples
+        loss_bbox = self.loss_bbox.loss_weight * sum_box / num_total_samples
+        return loss_cls, loss_bbox, self.loss_cls.loss_weight * loss_noR
+
+    @force_fp32(apply_to=('L_score'))
+    def loss_single_L(self, L_score, loss, label_weights, bbox_weights, **kwargs):
+        """Lambda_L2.py:235-241: mean(((|lambda + 1e-9 - loss|) * bbox_weights[...,0])^2) * 5."""
+        s = AF.MEHLossFn.apply(L_score, loss, bbox_weights)
+        return s * (5.0 / loss.numel()), 0
+
+    # ------------------------------------------------------------------ scoring
+    def simple_test(self, feats, img_metas, rescale=False, **kwargs):
+        """Lambda_L2.py:398-420."""
+        outs = self.forward(feats)
+        L_scores = self.forward_L(feats, head_out=None)
+        if not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_NoNMS':
+            results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, with_nms=False, **kwargs)
+        elif not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_ALL':
+            results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, with_nms=bool(kwargs.get('showNMS')), L_scores=L_scores, **kwargs)
+        elif not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_NMS':
+            results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, with_nms=True, L_scores=L_scores, **kwargs)
+        else:
+            results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, **kwargs)
+        if not kwargs['isEval']:
+            if kwargs.get('scaleUnc'):
+                return results_list
+            return (results_list[0], *results_list[1:])
+        return results_list
+
+    @force_fp32(apply_to=('mlvl_cls_scores', 'mlvl_bbox_preds', 'mlvl_anchors'))
+    def _get_bboxes(self, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes, scale_factors, cfg, rescale=False, with_nms=True, **kwargs):
+        """Lambda_L2.py:254-384 on the HIP scoring kernels (see ..scoring.ScoringPipeline)."""
+        from ...scoring import score_batch
+        cfg = self.test_cfg if cfg is None else cfg
+        return score_batch(self, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes, scale_factors, cfg, rescale, with_nms, **kwargs)

@@ -1,0 +1,57 @@
+"""Optimizer plumbing: FusedSGD (torch.optim.SGD semantics on the multi-tensor HIP kernel) and the mmcv-style
+`build_optimizer` used by apis/train_Lambda.py:54."""
+import ctypes as C
+
+import torch
+
+from ._C import call, stream
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """SGD with momentum / weight decay; one kernel launch per <= 48 tensors instead of ~5 small launches per
+    parameter.  The parameter list is re-read from param_groups every step (the reference edits it in place:
+    RemoveParamFromOptim, apis/train_Lambda.py:97-109)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
+        assert dampening == 0 and not nesterov, 'the AL configs use plain momentum SGD'
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            ps, gs, ms, ns, first = [], [], [], [], None
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                assert p.dtype == torch.float32 and p.is_contiguous()
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                is_first = 'momentum_buffer' not in st
+                if is_first:
+                    st['momentum_buffer'] = torch.empty_like(p)
+                if first is None:
+                    first = is_first
+                if is_first != first:      # mixed fresh/old buffers: flush what we have, start a new batch
+                    self._launch(ps, gs, ms, ns, group, first)
+                    ps, gs, ms, ns, first = [], [], [], [], is_first
+                ps.append(p.data_ptr()), gs.append(g.data_ptr()), ms.append(st['momentum_buffer'].data_ptr()), ns.append(p.numel())
+            self._launch(ps, gs, ms, ns, group, first)
+
+    def _launch(self, ps, gs, ms, ns, group, first):
+        n = len(ps)
+        if n == 0:
+            return
+        arr = C.c_void_p * n
+        call('aod_sgd_multi', arr(*ps), arr(*gs), arr(*ms), (C.c_int64 * n)(*ns), n, float(group['lr']), float(group['momentum']),
+             float(group['weight_decay']), int(bool(first)), float(self.grad_scale), stream())
+
+
+def build_optimizer(model, cfg):
+    """mmcv.runner.build_optimizer subset: dict(type='SGD', lr, momentum, weight_decay) over all trainable params."""
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    assert t == 'SGD', 'the AL configs use SGD'
+    cfg.pop('paramwise_cfg', None)
+    module = model.module if hasattr(model, 'module') else model
+    return FusedSGD([p for p in module.parameters() if p.requires_grad], **cfg)

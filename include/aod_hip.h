@@ -91,6 +91,10 @@ int aod_upsample2x_add_bwd(const void* g_dst, void* g_src_accum, int B, int h, i
 int aod_act_bwd(const void* g, const void* a, const void* z, const float* scale, const float* mean, const float* invstd,
                 void* dz, void* gmask_out, float* dbeta, float* dgamma, int64_t M, int N, int relu, int g_is_f32,
                 aod_stream_t stream);
+/* dz[M,Npad] (bf16) = pad(g[M,N] * (relu_out > 0 if given));  colsum[n] += sum_m of the same
+ * (gradients of the N = 180/36/9 prediction convs; relu_out_f32 = retina_L's fp32 output, Lambda_L2.py:101) */
+int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, int Npad,
+                        int g_is_f32, aod_stream_t stream);
 /* out = relu(a + b) bf16 and backward mask (bottleneck join, resnet.py:292-299) */
 int aod_add_relu(const void* a, const void* b, void* out, int64_t n, aod_stream_t stream);
 
@@ -131,15 +135,16 @@ int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const float* bbox_
  *   + unmap, as driven by L_anchor_head.py:155-257.  Bit-exact integer outputs.
  * anchors [A,4] fp32; valid [B,A] uint8; gts packed [B, Gmax, 4] fp32 with gt_count[B], gt_labels [B,Gmax] int64.
  * outputs: assigned [B,A] int64, labels [B,A] int64, label_w [B,A] f32, bbox_t [B,A,4], bbox_w [B,A,4],
- * num_pos [B] int32.  ws: workspace of aod_assign_ws_bytes(B, Gmax). */
-int aod_grid_anchors(const float* base_anchors, int nbase, int fh, int fw, int stride, float* out, aod_stream_t stream);
+ * num_pos [B] int32.  ws: workspace of aod_assign_ws_bytes(B, Gmax).  nlev > 0 with level_start_host[nlev+1]
+ * (anchor offsets of the pyramid levels, HOST array) writes the outputs level-major [L][B][A_l] so that every
+ * level's targets are one contiguous block (images_to_levels, anchor/utils.py:4-17, without a copy). */
 size_t aod_assign_ws_bytes(int B, int Gmax);
 int aod_max_iou_assign(const float* anchors, const uint8_t* valid, int64_t A, int B,
                        const float* gts, const int32_t* gt_count, const int64_t* gt_labels, int Gmax,
                        float pos_thr, float neg_thr, float min_pos_iou, int gt_max_assign_all, int num_classes,
                        const float* means4, const float* stds4,
                        int64_t* assigned, int64_t* labels, float* label_w, float* bbox_t, float* bbox_w,
-                       int32_t* num_pos, void* ws, aod_stream_t stream);
+                       int32_t* num_pos, void* ws, int nlev, const int64_t* level_start_host, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ scoring (K11-K13)
  * replaces Lambda_L2.py:264-304 (softmax, normalise, row max, per-level top-k, gather, decode) */
@@ -176,9 +181,9 @@ int aod_hua_score(const float* boxes, const float* scores, const float* lam, con
                   float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer (K16)
- * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61) over a table of tensors:
- * ptrs[3*i+{0,1,2}] = param, grad, momentum buffer (device pointers stored in device memory), sizes[i]. */
-int aod_sgd_multi(void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+ * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61): d = g*grad_scale + wd*p; buf = first ? d : mom*buf + d;
+ * p -= lr*buf, over HOST arrays of device pointers (params/grads/momentum buffers, fp32) and element counts. */
+int aod_sgd_multi(void* const* params, void* const* grads, void* const* moms, const int64_t* sizes, int ntensors,
                   float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream);
 
 #ifdef __cplusplus
