@@ -1,0 +1,385 @@
+// Scoring pass kernels (gfx950): softmax/row-max scan, stable per-level top-k, gather + delta decode,
+// class-aware greedy multiclass NMS.  Replaces Lambda_L2.py:264-332 + core/post_processing/bbox_nms.py:7-93
+// (+ mmcv batched_nms / nms_cpu semantics).  Index outputs are exact functions of the fp32 scores:
+//   top-k   : descending score, ties -> lower anchor index (torch.topk's tie order is unspecified; pinned here)
+//   NMS     : descending score, ties -> lower flat (candidate*C + class) index; suppress iff
+//             inter / (area_i + area_j - inter) > thr on the class-offset boxes (mmcv nms_cpu form).
+// HBM-bound row scans read the fp32 logits once with one thread per anchor row; selection / NMS work is
+// per (image[, level]) blocks with LDS histograms and an in-LDS bitonic sort.
+#include "common.h"
+
+#define MAXC 96
+
+// ---------------------------------------------------------------- shared row math (bit-identical wherever used)
+// alphas = softmax(x); S = sum(alphas) + 1e-20; scores = alphas / (S + 1e-9)   (Lambda_L2.py:269-273, gamma = 1)
+__device__ __forceinline__ void row_scores(const float* __restrict__ x, int C, float* s, float& max_alpha, float& max_score) {
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
+  float S = 0.f;
+  max_alpha = 0.f;
+  for (int c = 0; c < C; ++c) { s[c] = s[c] / sum; S += s[c]; max_alpha = fmaxf(max_alpha, s[c]); }
+  const float den = (S + 1e-20f) + 1e-9f;
+  max_score = 0.f;
+  for (int c = 0; c < C; ++c) { s[c] = s[c] / den; max_score = fmaxf(max_score, s[c]); }
+}
+
+// ---------------------------------------------------------------- S1: row max of normalised scores + level gate
+__global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __restrict__ cls, long long rows_per_img, int B, int C,
+                                                             float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  const int P = C | 1;
+  const int b = blockIdx.y;
+  const long long r0 = (long long)blockIdx.x * 256;
+  const int nr = (int)min((long long)256, rows_per_img - r0);
+  const float* src = cls + ((long long)b * rows_per_img + r0) * C;
+  for (int i = threadIdx.x; i < nr * C; i += 256) srow[(i / C) * P + (i % C)] = src[i];
+  __syncthreads();
+  bool fg = false;
+  if ((int)threadIdx.x < nr) {
+    float x[MAXC], s[MAXC], ma, ms;
+    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
+    row_scores(x, C, s, ma, ms);
+    rowmax[(long long)b * rows_per_img + r0 + threadIdx.x] = ms;
+    fg = ma > fg_thr;
+  }
+  if (__ballot(fg) && (threadIdx.x & 63) == 0) atomicOr(any_fg + b, 1);
+}
+
+extern "C" int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img, int C, float fg_thr, float* rowmax, int32_t* any_fg,
+                                  aod_stream_t stream) {
+  if (B == 0 || rows_per_img == 0) return 0;
+  AOD_CHECK_ARG(cls && rowmax && any_fg && C >= 1 && C <= MAXC, "softmax_rowmax: bad args");
+  dim3 grid((unsigned)((rows_per_img + 255) / 256), B);
+  hipLaunchKernelGGL(softmax_rowmax_kernel, grid, dim3(256), (size_t)256 * (C | 1) * 4, (hipStream_t)stream, cls, (long long)rows_per_img, B, C,
+                     fg_thr, rowmax, any_fg);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- block-wide helpers (1024 threads)
+constexpr int TB = 1024;
+
+__device__ __forceinline__ int block_excl_scan(int v, int* s_warp, int& total) {
+  // exclusive prefix sum over 1024 threads; s_warp: 16 ints of LDS
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  __syncthreads();
+  if (lane == 63) s_warp[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < TB / 64; ++i) { const int x = s_warp[i]; if (i < w) base += x; tot += x; }
+  total = tot;
+  return base + inc - v;
+}
+
+// in-LDS bitonic sort of n (power of two, <= 4096) u64 keys, DESCENDING
+__device__ void bitonic_desc(unsigned long long* k, int n) {
+  for (int size = 2; size <= n; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < n / 2; i += TB) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = k[lo], b = k[hi];
+        if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
+      }
+    }
+  __syncthreads();
+}
+
+// Radix-select over u64 keys produced on the fly by `key(i)` for i in [0, n): finds the value of the k-th
+// largest key among those < upper (k >= 1, at least k such keys must exist).  8 passes x 8 bits.
+template <typename KeyFn>
+__device__ unsigned long long radix_select_kth(KeyFn key, long long n, unsigned long long upper, int k, int* hist /*256 LDS ints*/) {
+  unsigned long long prefix = 0ull, mask = 0ull;
+  int remaining = k;
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += TB) hist[i] = 0;
+    __syncthreads();
+    const int shift = pass * 8;
+    for (long long i = threadIdx.x; i < n; i += TB) {
+      const unsigned long long v = key(i);
+      if (v < upper && (v & mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xffull)], 1);
+    }
+    __syncthreads();
+    // every thread walks the histogram from the top (256 LDS reads, uniform)
+    int d = 255, acc = 0;
+    for (; d >= 0; --d) {
+      const int h = hist[d];
+      if (acc + h >= remaining) break;
+      acc += h;
+    }
+    remaining -= acc;
+    prefix |= ((unsigned long long)d) << shift;
+    mask |= 0xffull << shift;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// ---------------------------------------------------------------- S2: stable top-k per (image, level)
+// key = (score bits << 32) | (0xffffffff - index): larger key = higher score, then lower index; keys are unique.
+__global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ score, long long A, int k, int* __restrict__ idx_out, long long out_pitch) {
+  __shared__ int hist[256];
+  __shared__ int s_warp[TB / 64];
+  __shared__ unsigned long long keys[1024];
+  const int b = blockIdx.x;
+  const float* s = score + (long long)b * A;
+  auto key = [&](long long i) { return ((unsigned long long)__float_as_uint(s[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i); };
+  const unsigned long long kth = radix_select_kth(key, A, ~0ull, k, hist);
+  // compaction of keys >= kth (exactly k of them)
+  for (int i = threadIdx.x; i < 1024; i += TB) keys[i] = 0ull;
+  __syncthreads();
+  int base = 0;
+  for (long long c0 = 0; c0 < A; c0 += TB) {
+    const long long i = c0 + threadIdx.x;
+    const bool take = i < A && key(i) >= kth;
+    int tot;
+    const int pos = block_excl_scan(take ? 1 : 0, s_warp, tot);
+    if (take) keys[base + pos] = key(i);
+    base += tot;
+    __syncthreads();
+  }
+  bitonic_desc(keys, 1024);
+  for (int i = threadIdx.x; i < k; i += TB) idx_out[(long long)b * out_pitch + i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+}
+
+extern "C" int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, int64_t out_pitch, aod_stream_t stream) {
+  if (B == 0 || k == 0) return 0;
+  AOD_CHECK_ARG(score && idx && k >= 1 && k <= 1024 && k <= A && out_pitch >= k, "topk: need 1 <= k <= min(1024, A)");
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, score, (long long)A, k, idx, (long long)out_pitch);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- S3: gather + decode one level
+struct GatherArgs {
+  const float* cls; const float* reg; const float* lam_map; const float* anchors; const int* idx;
+  int B; long long A; int k; int C; long long idx_pitch;
+  const float* img_hw; const float* scale4;
+  float means[4], stds[4]; float max_ratio;
+  float* boxes; float* scores; float* lam; int* cand_anchor;
+  long long n_total; long long cand0; long long anchor0;
+};
+__global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.k) return;
+  const long long a = p.idx ? p.idx[(long long)b * p.idx_pitch + j] : j;
+  const long long row = (long long)b * p.A + a;
+  float x[MAXC], s[MAXC], ma, ms;
+  for (int c = 0; c < p.C; ++c) x[c] = p.cls[row * p.C + c];
+  row_scores(x, p.C, s, ma, ms);
+  const long long o = (long long)b * p.n_total + p.cand0 + j;
+  for (int c = 0; c < p.C; ++c) p.scores[o * (p.C + 1) + c] = s[c];
+  p.scores[o * (p.C + 1) + p.C] = 0.f;
+  p.lam[o] = p.lam_map[row];
+  p.cand_anchor[o] = (int)(p.anchor0 + a);
+  // delta2bbox (delta_xywh_bbox_coder.py:144-262)
+  const f32x4 an = *reinterpret_cast<const f32x4*>(p.anchors + a * 4);
+  const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.reg + row * 4);
+  float d[4];
+  for (int i = 0; i < 4; ++i) d[i] = d0[i] * p.stds[i] + p.means[i];
+  const float px = (an[0] + an[2]) * 0.5f, py = (an[1] + an[3]) * 0.5f, pw = an[2] - an[0], ph = an[3] - an[1];
+  const float dxw = pw * d[0], dyh = ph * d[1];
+  const float dw = fminf(fmaxf(d[2], -p.max_ratio), p.max_ratio), dh = fminf(fmaxf(d[3], -p.max_ratio), p.max_ratio);
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  const float gx = px + dxw, gy = py + dyh;
+  float bx[4] = {gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f};
+  const float Hh = p.img_hw[b * 2], Ww = p.img_hw[b * 2 + 1];
+  const float mx[4] = {Ww, Hh, Ww, Hh};
+  for (int i = 0; i < 4; ++i) {
+    float v = bx[i];
+    v = v < 0.f ? 0.f : v;
+    v = v > mx[i] ? mx[i] : v;
+    if (p.scale4) v = v / p.scale4[b * 4 + i];
+    p.boxes[o * 4 + i] = v;
+  }
+}
+
+extern "C" int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
+                                 int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
+                                 const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
+                                 int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, aod_stream_t stream) {
+  if (B == 0 || k == 0) return 0;
+  AOD_CHECK_ARG(cls && reg && lam_map && anchors && img_hw && boxes && scores && lam && cand_anchor && C <= MAXC, "gather_decode: bad args");
+  GatherArgs p;
+  p.cls = cls; p.reg = reg; p.lam_map = lam_map; p.anchors = anchors; p.idx = idx; p.B = B; p.A = A; p.k = k; p.C = C; p.idx_pitch = idx_pitch;
+  p.img_hw = img_hw; p.scale4 = scale4;
+  for (int i = 0; i < 4; ++i) { p.means[i] = means4 ? means4[i] : 0.f; p.stds[i] = stds4 ? stds4[i] : 1.f; }
+  p.max_ratio = fabsf(logf(wh_ratio_clip));
+  p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.n_total = n_total; p.cand0 = cand0; p.anchor0 = anchor0;
+  hipLaunchKernelGGL(gather_decode_kernel, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- S4: multiclass NMS, one block per image
+// workspace per image: vflat[n*C] ints (flat index of the p-th valid entry)
+constexpr int TR = 4096;  // tranche of candidates sorted at a time
+__global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
+                                                 float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
+                                                 long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat) {
+  __shared__ int hist[256];
+  __shared__ int s_warp[TB / 64];
+  __shared__ unsigned long long keys[TR];
+  __shared__ float kbox[128][4];
+  __shared__ float karea[128];
+  __shared__ int kcls[128];
+  __shared__ int s_nkept, s_nvalid;
+  __shared__ float s_maxc;
+  const int b = blockIdx.x;
+  const float* bx = boxes + (long long)b * n * 4;
+  const float* sc = scores + (long long)b * n * (C + 1);
+  int* vflat = ws_vflat + (long long)b * n * C;
+  const long long NC = (long long)n * C;
+  // 1. compaction of valid (score > thr) entries in flat order + max coordinate of their boxes
+  if (threadIdx.x == 0) { s_nkept = 0; s_maxc = -INFINITY; }
+  __syncthreads();
+  int base = 0;
+  float mymax = -INFINITY;
+  for (long long c0 = 0; c0 < NC; c0 += TB) {
+    const long long f = c0 + threadIdx.x;
+    bool v = false;
+    if (f < NC) {
+      const int cand = (int)(f / C), cl = (int)(f - (long long)cand * C);
+      v = sc[(long long)cand * (C + 1) + cl] > score_thr;
+      if (v) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+        mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
+      }
+    }
+    int tot;
+    const int pos = block_excl_scan(v ? 1 : 0, s_warp, tot);
+    if (v) vflat[base + pos] = (int)f;
+    base += tot;
+    __syncthreads();
+  }
+  const int nvalid = base;
+  mymax = wave_max(mymax);
+  if ((threadIdx.x & 63) == 0 && mymax > -INFINITY) atomicMax((int*)&s_maxc, __float_as_int(mymax));  // coords >= 0 after clipping
+  __syncthreads();
+  // boxes are clipped to >= 0 so the int ordering of the float bits is valid; guard the (never expected) negative case
+  const float off_unit = s_maxc + 1.f;
+  auto key = [&](long long pidx) {
+    const int f = vflat[pidx];
+    const int cand = f / C, cl = f - cand * C;
+    return ((unsigned long long)__float_as_uint(sc[(long long)cand * (C + 1) + cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pidx);
+  };
+  unsigned long long upper = ~0ull;
+  int done = 0;
+  while (done < nvalid) {
+    if (s_nkept >= max_num) break;
+    const int take = min(TR, nvalid - done);
+    const unsigned long long kth = radix_select_kth(key, nvalid, upper, take, hist);
+    int np2 = 64;
+    while (np2 < take) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += TB) keys[i] = 0ull;
+    __syncthreads();
+    int kb = 0;
+    for (int c0 = 0; c0 < nvalid; c0 += TB) {
+      const int i = c0 + threadIdx.x;
+      unsigned long long kv = 0ull;
+      bool t = false;
+      if (i < nvalid) { kv = key(i); t = kv < upper && kv >= kth; }
+      int tot;
+      const int pos = block_excl_scan(t ? 1 : 0, s_warp, tot);
+      if (t) keys[kb + pos] = kv;
+      kb += tot;
+      __syncthreads();
+    }
+    bitonic_desc(keys, np2);
+    // greedy scan by wave 0, 64 candidates per round
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      int nk = s_nkept;      // wave-uniform register copy; LDS is only written back after the scan
+      for (int c0 = 0; c0 < take; c0 += 64) {
+        if (nk >= max_num) break;
+        const int i = c0 + lane;
+        const bool act = i < take;
+        float q[4] = {0, 0, 0, 0}, area = 0.f, scv = 0.f;
+        int cl = -1, pidx = 0;
+        if (act) {
+          const unsigned long long kv = keys[i];
+          pidx = (int)(0xffffffffu - (unsigned)(kv & 0xffffffffull));
+          scv = __uint_as_float((unsigned)(kv >> 32));
+          const int f = vflat[pidx];
+          const int cand = f / C;
+          cl = f - cand * C;
+          const float off = (float)cl * off_unit;
+          const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+          for (int u = 0; u < 4; ++u) q[u] = r[u] + off;
+          area = (q[2] - q[0]) * (q[3] - q[1]);
+        }
+        bool sup = !act;
+        for (int j = 0; j < nk && !sup; ++j) {
+          if (kcls[j] != cl) continue;
+          const float w = fmaxf(0.f, fminf(q[2], kbox[j][2]) - fmaxf(q[0], kbox[j][0]));
+          const float h = fmaxf(0.f, fminf(q[3], kbox[j][3]) - fmaxf(q[1], kbox[j][1]));
+          const float inter = w * h;
+          const float ovr = inter / (karea[j] + area - inter);
+          if (ovr > iou_thr) sup = true;
+        }
+        // intra-round resolution in order
+        for (int s = 0; s < 64; ++s) {
+          const bool s_keep = __shfl((int)(!sup), s, 64) != 0;
+          if (!s_keep) continue;                    // uniform
+          if (nk >= max_num) break;                 // uniform
+          const float b0 = __shfl(q[0], s, 64), b1 = __shfl(q[1], s, 64), b2 = __shfl(q[2], s, 64), b3 = __shfl(q[3], s, 64);
+          const float ar = __shfl(area, s, 64);
+          const int cs = __shfl(cl, s, 64);
+          if (lane == s) {
+            kbox[nk][0] = q[0]; kbox[nk][1] = q[1]; kbox[nk][2] = q[2]; kbox[nk][3] = q[3]; karea[nk] = area; kcls[nk] = cl;
+            const int f = vflat[pidx];
+            const int cand = f / C;
+            const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+            float* o = dets + ((long long)b * max_num + nk) * 5;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = scv;
+            det_labels[(long long)b * max_num + nk] = cl;
+            keep[(long long)b * max_num + nk] = pidx;
+          }
+          ++nk;
+          if (lane > s && !sup && cl == cs) {
+            const float w = fmaxf(0.f, fminf(q[2], b2) - fmaxf(q[0], b0));
+            const float h = fmaxf(0.f, fminf(q[3], b3) - fmaxf(q[1], b1));
+            const float inter = w * h;
+            const float ovr = inter / (ar + area - inter);
+            if (ovr > iou_thr) sup = true;
+          }
+        }
+      }
+      if (lane == 0) s_nkept = nk;
+    }
+    __syncthreads();
+    upper = kth;
+    done += take;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { num_det[b] = s_nkept; }
+  // zero the unused tail so that consumers can read fixed-size tensors
+  const int nk = s_nkept;
+  for (int i = nk * 5 + threadIdx.x; i < max_num * 5; i += TB) dets[(long long)b * max_num * 5 + i] = 0.f;
+  for (int i = nk + threadIdx.x; i < max_num; i += TB) { det_labels[(long long)b * max_num + i] = -1; keep[(long long)b * max_num + i] = -1; }
+  if (threadIdx.x == 0) s_nvalid = nvalid;
+}
+
+extern "C" size_t aod_nms_ws_bytes(int B, int n, int C) { return (size_t)B * n * C * 4; }
+
+extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, int C, float score_thr, float iou_thr, int max_num,
+                                  float* dets, int64_t* det_labels, int64_t* keep, int32_t* num_det, void* ws, aod_stream_t stream) {
+  if (B == 0) return 0;
+  AOD_CHECK_ARG(boxes && scores && dets && det_labels && keep && num_det && ws, "nms: null pointer");
+  AOD_CHECK_ARG(max_num >= 1 && max_num <= 128 && C >= 1, "nms: max_num must be in 1..128");
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
+                     (long long*)det_labels, (long long*)keep, num_det, (int*)ws);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

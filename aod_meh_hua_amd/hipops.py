@@ -13,6 +13,27 @@ from . import _C
 from ._C import ConvDesc, ConvSeg, call, ptr, stream
 
 
+# ---- optional per-launch profiling (bench.py): (kind, tile, flops, start_event, end_event) on the CURRENT stream
+PROFILE = None
+
+
+def _prof(kind, desc, fn):
+    if PROFILE is None:
+        return fn()
+    # algorithmic FLOPs = 2 * (forward output pixels) * Cout * R*S*Cin, for dgrad too (dZ pixels = seg.H*seg.W)
+    if desc.transposed:
+        m = sum(desc.seg[i].B * desc.seg[i].H * desc.seg[i].W for i in range(desc.nseg))
+    else:
+        m = sum(desc.seg[i].B * desc.seg[i].OH * desc.seg[i].OW for i in range(desc.nseg))
+    flops = 2.0 * m * desc.N * desc.R * desc.S * desc.C
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((kind, (m, desc.N, desc.R * desc.S * desc.C), flops, e0, e1))
+    return r
+
+
 @dataclass(frozen=True)
 class Seg:
     B: int
@@ -76,8 +97,8 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
         out = torch.empty(rows, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
     z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
-    call('aod_conv2d', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift), ptr(res),
-         ptr(mask), ptr(post_scale), ptr(z), stream())
+    _prof('fwd', d, lambda: call('aod_conv2d', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
+                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), stream()))
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
@@ -89,8 +110,8 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     if out is None:
         out = torch.empty(rows, Cin, dtype=torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
-    call('aod_conv2d', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
-         ptr(post_scale), None, stream())
+    _prof('dgrad', d, lambda: call('aod_conv2d', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
+                                   ptr(post_scale), None, stream()))
     return out
 
 
@@ -100,7 +121,7 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     if dw is None:
         dw = torch.zeros(Npad, R, S, Cin, dtype=torch.float32, device=x_rows.device)
     d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
-    call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), stream())
+    _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), stream()))
     return dw
 
 

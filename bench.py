@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Benchmark of the MEH/HUA hot path on MI355X (contract: prompt section 'bench.py').
+
+Workload (BASELINE.json configs[1]): RetinaNet-R50-FPN + MEH/HUA, synthetic VOC 512x512,
+20 classes, 16 images per GPU.  One "step" = one AL work unit over one batch of synthetic images resident
+in HBM: the full training iteration of MyEpochBasedRunnerLambda.run_iter (main forward + backward + SGD,
+then MEH forward + backward + SGD) PLUS the HUA scoring pass over a batch of the same size
+(forward + MEH forward + top-k + NMS + Dirichlet sampling + aggregation -> one score per image), i.e. the
+metric "images/sec train + HUA-score".  value = images through both phases / time.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live (HIP events on the launch stream around every
+conv launch of one extra instrumented step); `cpu_baseline` times the CPU oracle (a faithful port of the
+reference's CPU path, oracle/model.py) on a bounded sample on rank 0 at N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--mode', default='train+score', choices=['train', 'score', 'train+score'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def synth_batch(B, H, W, device, seed):
+    """img ~ N(0,1); G ~ U{1..5}; w,h ~ U(32,384) clipped inside; labels ~ U{0..19}."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, H, W, generator=g)
+    boxes, labels = [], []
+    for _ in range(B):
+        G = int(torch.randint(1, 6, (1,), generator=g))
+        wh = torch.rand(G, 2, generator=g) * (384 - 32) * (H / 512.0) + 32 * (H / 512.0)
+        xy = torch.rand(G, 2, generator=g) * (torch.tensor([float(W), float(H)]) - wh).clamp(min=0)
+        boxes.append(torch.cat([xy, (xy + wh).clamp(max=float(H))], 1).to(device))
+        labels.append(torch.randint(0, 20, (G,), generator=g).to(device))
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3), scale_factor=np.ones(4, np.float32), flip=False)
+             for _ in range(B)]
+    return dict(img=img.to(device), img_metas=metas, gt_bboxes=boxes, gt_labels=labels)
+
+
+def build_model(device, seed=20):
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    cfg.model.backbone.pop('init_cfg')        # no network: random-init weights of the named architecture
+    torch.manual_seed(seed)
+    model = build_detector(cfg.model)
+    model.init_weights()
+    with torch.no_grad():                     # "trained-like" head so that HUA is non-degenerate
+        model.bbox_head.retina_cls.weight.mul_(30.0)
+        model.bbox_head.retina_L.bias.fill_(0.1)
+    return model.to(device), cfg
+
+
+def make_optimizers(model, cfg):
+    """apis/train_Lambda.py:54-61: main SGD without the MEH parameters + optimizer_L over the MEH parameters."""
+    from aod_meh_hua_amd.optim import FusedSGD
+    o = cfg.optimizer
+    meh = [p for n, p in model.named_parameters() if ('retina_L' in n or 'L_convs' in n)]
+    ids = {id(p) for p in meh}
+    main = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
+    return (FusedSGD(main, lr=o.lr, momentum=o.momentum, weight_decay=o.weight_decay),
+            FusedSGD(meh, lr=o.lr, momentum=o.momentum, weight_decay=o.weight_decay))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
+    model, cfg = build_model(dev)
+    broadcast_model(model)
+    opt, opt_L = make_optimizers(model, cfg)
+    gsync = GradSync()
+    B, H = args.batch, args.size
+    data = synth_batch(B, H, H, dev, seed=20 + rank)
+    pool = synth_batch(B, H, H, dev, seed=1020 + rank)
+    score_kw = dict(return_loss=False, rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS',
+                    uPool2='objectSum_scaleMax_classSum', scaleUnc=False, showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
+    do_train, do_score = 'train' in args.mode, 'score' in args.mode
+    have_scoring = True
+    try:
+        import aod_meh_hua_amd.scoring  # noqa: F401
+    except ImportError:
+        have_scoring = False
+        do_score = False
+
+    def step(it=0):
+        if do_train:
+            model.train()
+            out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+            opt.zero_grad()
+            out['loss'].backward()
+            gsync.all_reduce_grads(opt.param_groups[0]['params'])
+            opt.step()
+            lossL = model.train_step_L(prev, head_out, feat_out)
+            opt_L.zero_grad()
+            lossL['loss'].backward()
+            gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
+            opt_L.step()
+        if do_score:
+            model.eval()
+            with torch.no_grad():
+                ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                _, unc = model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **score_kw)
+                unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
+                if world > 1:
+                    gather_scores(unc, B * world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    phases = int(do_train) + int(do_score)
+    imgs_per_step = B * world * phases
+    value = imgs_per_step * args.steps / dt
+
+    # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv launch
+    roof = None
+    if rank == 0:
+        ho.PROFILE = []
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, shape, flops, e0, e1 in ho.PROFILE:
+            a = agg.setdefault(kind, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += flops
+        ho.PROFILE = None
+        kind = max(agg, key=lambda k: agg[k][1])
+        n, tsec, fl = agg[kind]
+        roof = dict(bound='mfma', kernel={'fwd': 'conv_igemm_kernel (forward)', 'dgrad': 'conv_igemm_kernel (dgrad)', 'wgrad': 'conv_wgrad_kernel'}[kind],
+                    achieved=round(fl / tsec / 1e12, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    traffic=None, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
+                    all={k: dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in agg.items()})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, do_train, do_score and have_scoring)
+
+    if rank == 0:
+        line = dict(metric='images/sec train+HUA-score, RetinaNet-R50 VOC 512^2', value=round(value, 2), unit='images/sec',
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                    config=dict(workload=f'RetinaNet-R50-FPN + MEH/HUA, synthetic VOC {H}x{H}, bs={B}/GPU: '
+                                         + ' + '.join((['train iteration (main fwd/bwd/SGD + MEH fwd/bwd/SGD)'] if do_train else [])
+                                                      + (['HUA scoring pass'] if do_score else [])),
+                                global_batch=B * world, image_size=H, num_classes=20, anchors_per_image=49104 if H == 512 else None,
+                                parallelism=f'dp{world}', phases=args.mode if (do_score or not have_scoring) else 'train'),
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, do_train, do_score):
+    """CPU oracle (port of the reference's CPU path) on a bounded sample: B=2 (the reference's samples_per_gpu,
+    Config_RetinaNet.py:127) at the bench resolution, all host cores."""
+    from oracle import model as om
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    H = args.size
+    sd = om.seeded_state_dict()
+    train_keys = [k for k, v in sd.items() if v.is_floating_point() and not any(s in k for s in ('running', 'backbone.conv1.', 'backbone.bn1.', 'layer1.'))]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(20)
+    B = 2
+    img = torch.randn(B, 3, H, H, generator=g)
+    gtb = [torch.tensor([[H * .1, H * .2, H * .6, H * .7]]), torch.tensor([[H * .3, H * .3, H * .8, H * .9], [H * .05, H * .05, H * .3, H * .4]])]
+    gtl = [torch.tensor([3]), torch.tensor([7, 1])]
+    bufs, bufs_L = {}, {}
+    meh = [k for k in train_keys if 'retina_L' in k or 'L_convs' in k]
+    main = [k for k in train_keys if k not in meh]
+
+    def it():
+        n = 0
+        if do_train:
+            o = om.train_step(sd, img, gtb, gtl)
+            for k in train_keys:
+                sd[k].grad = None
+            o['loss'].backward()
+            with torch.no_grad():
+                om.sgd_step({k: sd[k] for k in main}, {k: sd[k].grad for k in main}, bufs)
+            oL = om.train_step_L(sd, o['feats'], o['loss_noR'], o['targets'])
+            for k in train_keys:
+                sd[k].grad = None
+            oL['loss'].backward()
+            with torch.no_grad():
+                om.sgd_step({k: sd[k] for k in meh}, {k: sd[k].grad for k in meh}, bufs_L)
+            n += B
+        if do_score:
+            with torch.no_grad():
+                om.score_images(sd, img, sampler='torch')
+            n += B
+        return n
+    it()
+    t0, n, iters = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        n += it()
+        iters += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 3), unit='images/sec', cores=cores, kind='port',
+                sample=f'{iters} iterations of the same step at B={B}, {H}x{H}, fp32 torch CPU ops, {cores} threads (oracle/model.py)')
+
+
+if __name__ == '__main__':
+    main()

@@ -147,20 +147,26 @@ int aod_max_iou_assign(const float* anchors, const uint8_t* valid, int64_t A, in
                        int32_t* num_pos, void* ws, int nlev, const int64_t* level_start_host, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ scoring (K11-K13)
- * replaces Lambda_L2.py:264-304 (softmax, normalise, row max, per-level top-k, gather, decode) */
-int aod_softmax_rowmax(const float* cls, int64_t nrows, int C, float* alphas_or_null, float* rowmax, aod_stream_t stream);
-/* per (image) stable top-k (ties -> lower index) of score[B, A] -> idx[B, k] int32 (descending) */
-size_t aod_topk_ws_bytes(int B, int64_t A);
-int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, void* ws, aod_stream_t stream);
-/* gather + decode one level: out boxes [B,k,4] (clipped to img_hw[b], divided by scale[b][4]), scores [B,k,C+1]
- * (normalised softmax + zero bg column), lam [B,k] */
-int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors,
-                      const int32_t* idx, int B, int64_t A, int k, int C, const float* img_hw, const float* scale4,
-                      const float* means4, const float* stds4, float wh_ratio_clip,
-                      float* boxes, float* scores, float* lam, aod_stream_t stream);
-/* multiclass_nms (core/post_processing/bbox_nms.py:7-93 -> mmcv batched_nms/nms_cpu semantics).
- * boxes [B,n,4], scores [B,n,C+1]; outputs dets [B,max_num,5], det_labels [B,max_num] int64,
- * keep [B,max_num] int64 (index into the score>thr list), num_det [B] int32. */
+ * replaces Lambda_L2.py:264-304: alphas = softmax; scores = alphas / (sum(alphas) + 1e-20 + 1e-9); row max; level gate
+ * (any anchor of the level with max alpha > fg_thr, Lambda_L2.py:497-502).  cls [B, rows_per_img, C] fp32 (one level);
+ * rowmax [B, rows_per_img]; any_fg [B] int32 (OR-ed into; caller zeroes). */
+int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img, int C, float fg_thr, float* rowmax, int32_t* any_fg,
+                       aod_stream_t stream);
+/* per image stable top-k (k <= 1024; descending score, ties -> lower index) of score [B, A] -> idx [B, out_pitch] int32
+ * (torch.topk at Lambda_L2.py:290; its tie order is unspecified, pinned here) */
+int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, int64_t out_pitch, aod_stream_t stream);
+/* gather + decode ONE level into the concatenated candidate arrays (Lambda_L2.py:292-308,325-326; delta2bbox
+ * delta_xywh_bbox_coder.py:144-262): for candidate j (anchor idx[b][j], or j itself when idx == NULL):
+ * boxes [B, n_total, 4] (clipped to img_hw[b] = (H, W), divided by scale4[b] when given), scores [B, n_total, C+1]
+ * (normalised softmax + zero background column), lam [B, n_total], cand_anchor [B, n_total] = anchor0 + anchor index,
+ * written at candidate offset cand0. */
+int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
+                      int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
+                      const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
+                      int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, aod_stream_t stream);
+/* multiclass_nms (core/post_processing/bbox_nms.py:7-93 -> mmcv batched_nms / nms_cpu semantics, both its <10000 and
+ * per-class paths reduce to this class-aware greedy scan).  boxes [B,n,4], scores [B,n,C+1]; outputs dets [B,max_num,5],
+ * det_labels [B,max_num] int64, keep [B,max_num] int64 (index into the score>thr list; -1 padded), num_det [B] int32. */
 size_t aod_nms_ws_bytes(int B, int n, int C);
 int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, int C, float score_thr, float iou_thr,
                        int max_num, float* dets, int64_t* det_labels, int64_t* keep, int32_t* num_det,
@@ -168,16 +174,18 @@ int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, in
 
 /* ------------------------------------------------------------------ HUA (K13-K15)
  * replaces GetObjectIdx + ComputeObjUnc + AggregateObjScaleUnc (Lambda_L2.py:343-349,489-537,597-619;
- * torch._sample_dirichlet): per image, (candidate,object) pairs -> 500 Dirichlet samples -> epistemic ->
+ * torch._sample_dirichlet): per image, (candidate,object) pairs -> num_samples Dirichlet samples -> epistemic ->
  * (object, level, class) bins -> class/scale/object aggregation -> unc[B].
- * level_start[L+1]: candidate offsets of the concatenated levels; level_any_fg [B,L] uint8 (Lambda_L2.py:497-502);
- * cand_anchor [B,n] int32 global anchor id (RNG key); image_ids [B] int64 (RNG key); agg = 3 codes (class,scale,object)
- * each 0 Sum / 1 Avg / 2 Max.  pair_out (optional, [B, max_pairs, 4] f32: cand, obj, ale, epi) for tests. */
-size_t aod_hua_ws_bytes(int B, int n, int max_obj, int L, int C);
+ * level_start_host[L+1]: candidate offsets of the concatenated levels (HOST array); level_any_fg [L][B] int32;
+ * cand_anchor [B,n] global anchor id and image_ids [B] int64 key the counter RNG (partition invariant);
+ * agg3_host = (class, scale, object) codes 0 Sum / 1 Avg / 2 Max (HOST array; NULL = Sum/Max/Sum).
+ * pair_out (optional, [B, max_pairs, 4] f32: cand, obj, aleatoric, epistemic); pair_count [B] int32 (may exceed
+ * max_pairs: then the excess pairs were dropped and the caller must retry with a larger workspace). */
+size_t aod_hua_ws_bytes(int B, int max_pairs);
 int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor,
-                  const float* dets, const int32_t* num_det, const int32_t* level_start, const uint8_t* level_any_fg,
+                  const float* dets, const int32_t* num_det, const int32_t* level_start_host, const int32_t* level_any_fg,
                   const int64_t* image_ids, int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr,
-                  float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3, int clsW,
+                  float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3_host, int clsW,
                   float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer (K16)

@@ -91,7 +91,7 @@ def philox_dirichlet_stats(alpha, image_id, anchor_id, obj_id, seed, num_samples
     s = np.arange(num_samples, dtype=np.uint32)[:, None, None]
     k = np.arange(C, dtype=np.uint32)[None, None, :]
     obj = np.asarray(obj_id, dtype=np.uint32)[None, :, None]
-    c1 = (obj << np.uint32(16)) | (s << np.uint32(5)) | k
+    c1 = (obj << np.uint32(20)) | (s << np.uint32(7)) | k
     c2 = np.asarray(anchor_id, dtype=np.uint32)[None, :, None]
     g = philox_gamma(np.broadcast_to(alpha[None], (num_samples, P, C)), c1, c2, np.uint32(image_id), seed)
     g = np.maximum(g, FLT_MIN)
