@@ -1,0 +1,81 @@
+"""calculate_uncertainty / single_gpu_uncertainty / single_gpu_test with the reference's names and kwargs
+(mmdet/apis/test.py:19-195).
+
+Re-design for 8 x MI355X: the pool is SHARDED -- each rank scores the contiguous block
+[r*ceil(N/W), (r+1)*ceil(N/W)) of the loader's dataset and the per-image fp32 scores are all-gathered over RCCL
+(the reference's loader is dist=False, so every rank would score the whole pool).  Scores stay on the device
+inside the loop; the host syncs once per pool.  The Philox stream is keyed by the global image index, so the
+result is bit-identical for any world size."""
+import numpy as np
+import torch
+
+from ..mmcv_lite import DataContainer, ProgressBar
+from ..parallel import gather_scores, get_dist_info, shard_range
+
+
+class Uncertainty_fns:
+    @staticmethod
+    def Random(cfg, *args, **kwargs):
+        return torch.randperm(len(args[1].dataset)).numpy()
+
+    @staticmethod
+    @torch.no_grad()
+    def Entropy_NMS(cfg, *args, **kwargs):
+        model, dataloader = args
+        model.eval()
+        unc = single_gpu_uncertainty(model, dataloader, isUnc=cfg.uncertainty_type, uPool=cfg.uncertainty_pool,
+                                     uPool2=cfg.uncertainty_pool2, **kwargs)
+        return unc.cpu() if torch.is_tensor(unc) else [u.cpu() if torch.is_tensor(u) else u for u in unc]
+
+    @staticmethod
+    def Entropy_ALL(cfg, *args, **kwargs):
+        raise NotImplementedError('Entropy_ALL is a "next" row (SURVEY 8f rank 4)')
+
+    Entropy_NoNMS = Entropy_ALL
+
+
+def calculate_uncertainty(cfg, *args, **kwargs):
+    """test.py:65-70."""
+    return getattr(Uncertainty_fns, cfg.uncertainty_pool)(cfg, *args, **kwargs)
+
+
+def _unwrap(x):
+    return x.data if isinstance(x, DataContainer) else x
+
+
+def single_gpu_uncertainty(model, data_loader, **kwargs):
+    """test.py:90-135, sharded.  Returns a [N] fp32 tensor (N = len(dataset)) identical on every rank."""
+    model.eval()
+    dataset = data_loader.dataset
+    N = len(dataset)
+    rank, world = get_dist_info()
+    lo, hi, per = shard_range(N, rank, world)
+    bs = data_loader.batch_size or 1
+    collate = data_loader.collate_fn
+    prog_bar = ProgressBar(hi - lo)
+    chunks = []
+    kwargs.setdefault('scaleUnc', False)
+    for s in range(lo, hi, bs):
+        idxs = list(range(s, min(s + bs, hi)))
+        data = collate([dataset[i] for i in idxs])
+        data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
+        dev = next(model.parameters()).device
+        image_ids = torch.tensor(idxs, dtype=torch.int64).to(dev, non_blocking=True)
+        with torch.no_grad():
+            result, unc, *others = model(return_loss=False, rescale=True, isEval=False, batchIdx=s // bs, image_ids=image_ids, **data, **kwargs)
+        chunks.append(torch.as_tensor(unc, dtype=torch.float32, device=dev).reshape(-1))
+        prog_bar.update(len(idxs))
+    dev = next(model.parameters()).device
+    local = torch.cat(chunks) if chunks else torch.zeros(0, device=dev)
+    return gather_scores(local, N)
+
+
+@torch.no_grad()
+def single_gpu_test(model, data_loader, show=False, out_dir=None, show_score_thr=0.3, **kwargs):
+    """test.py:138-195 (detection results for evaluation; isEval=True)."""
+    model.eval()
+    results = []
+    for data in data_loader:
+        data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
+        results.extend(model(return_loss=False, rescale=True, isEval=True, isUnc=False, **data, **kwargs))
+    return results

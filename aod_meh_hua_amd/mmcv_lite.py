@@ -391,8 +391,8 @@ class DataContainer:
 def scatter_kwargs(inputs, device):
     def mv(x):
         if isinstance(x, DataContainer):
-            d = x.data
-            d = d[0] if isinstance(d, list) and len(d) == 1 and not x.cpu_only and not torch.is_tensor(d) else d
+            d = x.data                     # mmcv: one entry per device; this build is one process per GPU
+            d = d[0] if isinstance(d, list) and len(d) == 1 else d
             return d if x.cpu_only else mv(d)
         if torch.is_tensor(x):
             return x.to(device, non_blocking=True)

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Active-learning driver with the reference's CLI and control flow (tools/train_RetinaNet.py:49-255):
+seeds = 20, per cycle {build + init model, outer_epoch x train_detector_SSL phases, save, HUA-score the pool, select}.
+
+    python tools/train_RetinaNet.py --work-dir demo --synthetic 64            # synthetic VOC-shaped pool (no dataset needed)
+    python -m torch.distributed.run --nproc-per-node 8 tools/train_RetinaNet.py --launcher pytorch ...   # one rank per MI355X
+"""
+import argparse
+import math
+import os
+import os.path as osp
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+from aod_meh_hua_amd.apis import calculate_uncertainty, train_detector_SSL  # noqa: E402
+from aod_meh_hua_amd.datasets import build_dataloader, build_dataset  # noqa: E402
+from aod_meh_hua_amd.mmcv_lite import Config, MMDataParallel, mkdir_or_exist  # noqa: E402
+from aod_meh_hua_amd.models import build_detector  # noqa: E402
+from aod_meh_hua_amd.utils import get_root_logger  # noqa: E402
+from aod_meh_hua_amd.utils.active_datasets import create_X_L_file, get_X_L_0_prev, update_X_L  # noqa: E402
+from aod_meh_hua_amd.utils.functions import DelJunkSave, EditCfg, ResumeCycle  # noqa: E402
+
+# module-level knobs, as in the reference (:28-43)
+onlyEval = False
+load_cycle = -1
+resume_cycle = -1
+isSave = True
+editCfg = {'uncertainty_pool2': 'objectSum_scaleMax_classSum'}
+clsW = False
+zeroRate = 0.15
+saveMaxConf = False
+useMaxConf = 'False'
+score_thr = 0.3
+iou_thr = 0.9
+
+
+def parse_args():
+    base_dir = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    p = argparse.ArgumentParser(description='Train a detector (active learning, MEH + HUA)')
+    p.add_argument('--config', default=osp.join(base_dir, 'configs/_base_/Config_RetinaNet.py'))
+    p.add_argument('--work-dir', default='WORK_DIR')
+    p.add_argument('--resume-from')
+    p.add_argument('--load-from')
+    p.add_argument('--bbox-head')
+    p.add_argument('--no-validate', default=True)
+    p.add_argument('--gpu-ids', type=int, default=[0], nargs='+')
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--Unc-type', type=str)
+    p.add_argument('--synthetic', type=int, default=0, help='run on a synthetic VOC-shaped pool of this many images')
+    p.add_argument('--synthetic-size', type=int, default=512)
+    p.add_argument('--cycles', type=int, default=None, help='override the number of AL cycles')
+    p.add_argument('--samples-per-gpu', type=int, default=None)
+    args = p.parse_args()
+    os.environ.setdefault('LOCAL_RANK', str(args.local_rank))
+    return args
+
+
+def main():
+    args = parse_args()
+    cfg = Config.fromfile(args.config)
+    seed = 20
+    torch.manual_seed(seed), np.random.seed(seed), random.seed(seed)
+    cfg.seed, cfg.onlyEval = seed, onlyEval
+    if args.bbox_head:
+        cfg.model.bbox_head.type = args.bbox_head
+    str2unc = {'SACA': 'scaleAvg_classAvg', 'SSCS': 'scaleSum_classSum', 'SACS': 'scaleAvg_classSum', 'SSCA': 'scaleSum_classAvg'}
+    if args.Unc_type:
+        cfg.uncertainty_pool2 = str2unc[args.Unc_type]
+    base_dir = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    cfg.work_dir = osp.join(base_dir, 'work_dirs', args.work_dir)
+    mkdir_or_exist(cfg.work_dir)
+    cfg.save_dir = osp.join(cfg.work_dir, 'model_save')
+    mkdir_or_exist(cfg.save_dir)
+    cfg.gpu_ids = args.gpu_ids
+    distributed = args.launcher != 'none'
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(cfg.dist_params.get('backend', 'nccl'))      # 'nccl' == RCCL over xGMI on ROCm
+        cfg.gpu_ids = list(range(dist.get_world_size()))
+    rank = int(os.environ.get('RANK', 0))
+    if editCfg:
+        EditCfg(cfg, editCfg)
+    cfg.model.backbone.pop('init_cfg', None) if args.synthetic else None
+    if args.synthetic:            # the pool is N deterministic synthetic images
+        n = args.synthetic
+        ann = osp.join(cfg.work_dir, 'synthetic_all.txt')
+        if rank == 0:
+            np.savetxt(ann, np.array([f'synthetic_{i}' for i in range(n)]), fmt='%s')
+        if distributed:
+            torch.distributed.barrier()
+        ds = dict(type='SyntheticVOCDataset', size=(args.synthetic_size, args.synthetic_size), ann_file=[ann])
+        cfg.data.train = dict(type='RepeatDataset', times=cfg.X_L_repeat, dataset=dict(ds))
+        cfg.data.test = dict(ds)
+        cfg.X_L_0_size, cfg.X_S_size = max(n // 8, 1), max(n // 16, 1)
+    if args.cycles is not None:
+        cfg.cycles = list(range(args.cycles))
+    if args.samples_per_gpu:
+        cfg.data.samples_per_gpu = args.samples_per_gpu
+    cfg.dump(osp.join(cfg.work_dir, osp.basename(args.config)))
+    timestamp = time.strftime('%Y%m%d_%H%M%S', time.localtime())
+    logger = get_root_logger(log_file=osp.join(cfg.work_dir, f'{timestamp}.log'), log_level=cfg.log_level)
+    meta = dict(exp_name=osp.basename(args.config))
+    cfg.data.workers_per_gpu = 0
+
+    X_L, X_U, X_all, all_anns = get_X_L_0_prev(cfg)
+    if rank == 0:
+        np.save(cfg.work_dir + '/X_L_0.npy', X_L), np.save(cfg.work_dir + '/X_U_0.npy', X_U)
+    notResumed = True
+    for cycle in cfg.cycles:
+        if resume_cycle >= 0 and notResumed:
+            X_L, X_U = ResumeCycle(cfg, cycle, resume_cycle)
+            if not isinstance(X_L, np.ndarray):
+                continue
+            notResumed = False
+        logger.info(f'Current cycle is {cycle} cycle.  len of X_U:{len(X_U)}, X_L:{len(X_L)}')
+        cfg = create_X_L_file(cfg, X_L, all_anns, cycle)
+        model = build_detector(cfg.model)
+        model.init_weights()
+        if cfg.model.train_cfg.get('bias') == 'uniform':                     # :158-162
+            N, k = model.bbox_head.num_anchors, model.bbox_head.retina_cls.bias.numel()
+            torch.nn.init.uniform_(model.bbox_head.retina_cls.bias, -math.sqrt(1 / (N * k)), math.sqrt(1 / (N * k)))
+        if load_cycle >= 0:
+            from aod_meh_hua_amd.mmcv_lite import load_checkpoint
+            cfg_name = osp.splitext(osp.basename(args.config))[0]
+            load_checkpoint(model, f'{cfg.save_dir}/{cfg_name}_Cycle{load_cycle}_Epoch{cfg.runner.max_epochs}_mycode.pth')
+        datasets = [build_dataset(cfg.data.train)]
+        model.CLASSES = datasets[0].CLASSES
+        for epoch in range(cfg.outer_epoch):
+            cfg.lr_config.step = [1000]
+            cfg.optimizer['lr'] = 0.001
+            if epoch == 0:
+                logger.info(f'Epoch = {epoch}, First Label Set Training')
+                cfg.total_epochs = cfg.epoch_ratio[0]
+                train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=False, timestamp=timestamp, meta=meta)
+            if epoch == cfg.outer_epoch - 1:
+                cfg.lr_config.step = [2]
+            logger.info(f'Epoch = {epoch}, Fully-Supervised Learning')
+            cfg.total_epochs = cfg.epoch_ratio[0]
+            train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=False, timestamp=timestamp, meta=meta)
+        if isSave and rank == 0:
+            for f in os.listdir(cfg.save_dir):
+                if '_mycode' not in f:
+                    os.remove(osp.join(cfg.save_dir, f))
+            cfg_name = osp.splitext(osp.basename(args.config))[0]
+            torch.save(model.state_dict(), f'{cfg.save_dir}/{cfg_name}_Cycle{cycle}_Epoch{cfg.runner.max_epochs}_mycode.pth')
+        if cycle != cfg.cycles[-1]:
+            dataset_al = build_dataset(cfg.data.test)
+            data_loader = build_dataloader(dataset_al, samples_per_gpu=cfg.data.samples_per_gpu, workers_per_gpu=0, dist=False, shuffle=False)
+            poolModel = MMDataParallel(model, device_ids=cfg.gpu_ids)
+            with torch.no_grad():
+                uncertainty = calculate_uncertainty(cfg, poolModel, data_loader, return_box=False, showNMS=False, saveUnc=False,
+                                                    saveMaxConf=saveMaxConf, clsW=clsW, scaleUnc=False, score_thr=score_thr, iou_thr=iou_thr)
+            uncertainty = uncertainty.numpy() if torch.is_tensor(uncertainty) else np.asarray(uncertainty)
+            X_L, X_U = update_X_L(uncertainty, X_all, X_L, cfg.X_S_size, zeroRate=zeroRate, maxconf=None, useMaxConf=useMaxConf)
+            if rank == 0:
+                np.save(cfg.work_dir + f'/X_L_{cycle + 1}.npy', X_L), np.save(cfg.work_dir + f'/X_U_{cycle + 1}.npy', X_U)
+                np.save(cfg.work_dir + f'/Unc_{cycle + 1}.npy', uncertainty)
+            logger.info(f'cycle {cycle}: scored {len(uncertainty)} images, {int((uncertainty > 0).sum())} non-zero, selected {cfg.X_S_size}')
+        if rank == 0:
+            DelJunkSave(cfg.work_dir)
+
+
+if __name__ == '__main__':
+    main()
