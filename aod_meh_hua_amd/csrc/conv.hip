@@ -25,6 +25,7 @@ struct ConvKParams {
   int C, N, K, R, S, stride, pad, dil, transposed, relu, out_f32;
   int nseg, M;
   int tiles_m, tiles_n;
+  long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
   long long seg_src0[8], seg_dst0[8];
   int seg_mend[8];
@@ -57,16 +58,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int kc = t % CPR, rb = t / CPR;
+  // ---- operand staging: LDS-DMA (buffer_load_dwordx4 ... lds), no VGPR round trip, no ds_write.
+  // One wave-instruction fills 1 KiB = 8 tile rows x 8 chunks LINEARLY (lane l -> row l>>3, slot l&7); the
+  // XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied on the SOURCE side:
+  // slot s of row r holds k-chunk s ^ ((r>>1)&7).  Out-of-image taps / K,N tails use an out-of-range
+  // buffer offset, for which the hardware range check returns zeros (no select, no predication).
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int prow = lane >> 3;                       // row inside the wave's 8-row group
+  const int kc = (lane & 7) ^ ((4 * uw + (lane >> 4)) & 7);   // k-chunk this lane fetches (same for every pass)
   const int C8 = p.C >> 3;
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
 
-  // ---- per-row gather state (A operand)
-  const bf16_t* rptr[A_IT];
+  unsigned rbase[A_IT];                             // byte offset of pixel (b, 0, 0) of the row's source block
   int ry0[A_IT], rx0[A_IT], rH[A_IT], rW[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + rb + i * RPP;
-    rH[i] = 0; rW[i] = 0; ry0[i] = 0; rx0[i] = 0; rptr[i] = p.x;
+    const int m = m0 + 32 * i + 8 * uw + prow;
+    rH[i] = 0; rW[i] = 0; ry0[i] = 0; rx0[i] = 0; rbase[i] = 0;
     if (m < p.M) {
       int sg = 0, mstart = 0;
       while (sg < p.nseg - 1 && m >= p.seg_mend[sg]) { mstart = p.seg_mend[sg]; ++sg; }
@@ -75,28 +85,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       const int b = ml / ohw, rem = ml - b * ohw;
       const int oy = rem / p.segOW[sg], ox = rem - oy * p.segOW[sg];
       rH[i] = p.segH[sg]; rW[i] = p.segW[sg];
-      rptr[i] = p.x + (p.seg_src0[sg] + (long long)b * p.segH[sg] * p.segW[sg]) * p.C;
+      rbase[i] = (unsigned)((p.seg_src0[sg] + (long long)b * p.segH[sg] * p.segW[sg]) * p.C * 2);
       if (p.transposed) { ry0[i] = oy + p.pad; rx0[i] = ox + p.pad; }
       else { ry0[i] = oy * p.stride - p.pad; rx0[i] = ox * p.stride - p.pad; }
     }
   }
-  // tap state of this thread's chunk column
+  // tap state of this lane's k-chunk
   int c8 = kc, tr = 0, ts = 0;
   while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
 
-  const bf16_t* wptr[B_IT];
-  bool wok[B_IT];
+  unsigned wbase[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + rb + i * RPP;
-    wok[i] = n < p.N;
-    wptr[i] = p.w + (long long)(wok[i] ? n : 0) * p.K + kc * 8;
+    const int n = n0 + 32 * i + 8 * uw + prow;
+    wbase[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8) * 2) : OOB;
   }
 
-  bf16x8 areg[A_IT], breg[B_IT];
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + A_BYTES;
     const bool tapok = tr < p.R;
     const int dy = tr * p.dil, dx = ts * p.dil;
 #pragma unroll
@@ -109,29 +116,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         else { ok = ok && ((ty | tx) >= 0) && (ty % p.stride == 0) && (tx % p.stride == 0); y = ty / p.stride; x = tx / p.stride; }
       } else { y = ry0[i] + dy; x = rx0[i] + dx; }
       ok = ok && (unsigned)y < (unsigned)rH[i] && (unsigned)x < (unsigned)rW[i];
-      areg[i] = ok ? *reinterpret_cast<const bf16x8*>(rptr[i] + ((long long)y * rW[i] + x) * p.C + c8 * 8) : zero8;
+      const unsigned off = ok ? rbase[i] + (unsigned)(((y * rW[i] + x) * p.C + c8 * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
     const bool kok = (kt * BK + kc * 8) < p.K;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      breg[i] = (wok[i] && kok) ? *reinterpret_cast<const bf16x8*>(wptr[i] + (long long)kt * BK) : zero8;
+    for (int i = 0; i < B_IT; ++i) {
+      const unsigned off = (kok && wbase[i] != OOB) ? wbase[i] + (unsigned)(kt * BK * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
+    }
     // advance tap state by one K-step
     c8 += CPR;
     while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
-  };
-  auto lds_store = [&](int buf) {
-    char* sa = smem + buf * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int row = rb + i * RPP;
-      *reinterpret_cast<bf16x8*>(sa + row * ROWB + ((kc ^ ((row >> 1) & 7)) << 4)) = areg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int row = rb + i * RPP;
-      *reinterpret_cast<bf16x8*>(sb + row * ROWB + ((kc ^ ((row >> 1) & 7)) << 4)) = breg[i];
-    }
   };
 
   f32x4 acc[MI][NI];
@@ -141,13 +137,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  gload(0);
-  lds_store(0);
+  gload(0, 0);
   __syncthreads();
   const int lr = lane & 15, lq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) gload(kt + 1, cur ^ 1);
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -169,8 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lds_store(cur ^ 1);
-    __syncthreads();
+    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier: next tile is resident afterwards
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, [BM][CP]) -> row-major vector stores
@@ -331,6 +325,16 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   p.x = (const bf16_t*)src; p.w = (const bf16_t*)w_packed; p.y = dst;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw;
+  long long xrows = 0;
+  for (int i = 0; i < desc->nseg; ++i) {
+    const aod_conv_seg_t& sg = desc->seg[i];
+    AOD_CHECK_ARG(sg.src_row0 >= 0, "conv: negative src_row0");
+    const long long e = sg.src_row0 + (long long)sg.B * sg.H * sg.W;
+    if (e > xrows) xrows = e;
+  }
+  p.x_bytes = xrows * p.C * 2;
+  p.w_bytes = (long long)p.N * p.K * 2;
+  AOD_CHECK_ARG(p.x_bytes < 0xfffffff0ll && p.w_bytes < 0xfffffff0ll, "conv: operand larger than 4 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   if (p.N > 64 && t128 >= 384) launch_conv<128, 128>(p, st);
@@ -347,16 +351,61 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
 // =====================================================================================
 // wgrad
 // =====================================================================================
+// Row table: one 16-B record per GEMM row m (= destination pixel): where its receptive field starts.
+// Depends only on the segment geometry / stride / pad, so it is built once per geometry and shared by every conv
+// (and every iteration) with that geometry -- the per-step im2col decode of wgrad becomes one 16-B load.
+struct RowRec {
+  unsigned pix0;     // row index of source pixel (b, 0, 0)
+  short y0, x0;      // top-left tap coordinate (oy*stride - pad, ox*stride - pad)
+  short H, W;        // source block extent
+  unsigned zrow;     // row of this pixel in the dZ / output buffer
+};
+
+__global__ void row_table_kernel(const ConvKParams p, RowRec* __restrict__ tab) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  int sg = 0, mstart = 0;
+  while (sg < p.nseg - 1 && m >= p.seg_mend[sg]) { mstart = p.seg_mend[sg]; ++sg; }
+  const int ml = m - mstart;
+  const int ohw = p.segOH[sg] * p.segOW[sg];
+  const int b = ml / ohw, rem = ml - b * ohw;
+  const int oy = rem / p.segOW[sg], ox = rem - oy * p.segOW[sg];
+  RowRec r;
+  r.pix0 = (unsigned)(p.seg_src0[sg] + (long long)b * p.segH[sg] * p.segW[sg]);
+  r.y0 = (short)(oy * p.stride - p.pad); r.x0 = (short)(ox * p.stride - p.pad);
+  r.H = (short)p.segH[sg]; r.W = (short)p.segW[sg];
+  r.zrow = (unsigned)(p.seg_dst0[sg] + ml);
+  tab[m] = r;
+}
+
+extern "C" size_t aod_conv_row_table_bytes(const aod_conv_desc_t* d) {
+  long long m = 0;
+  for (int i = 0; i < d->nseg; ++i) m += (long long)d->seg[i].B * d->seg[i].OH * d->seg[i].OW;
+  return (size_t)m * sizeof(RowRec);
+}
+
+extern "C" int aod_conv_row_table(const aod_conv_desc_t* d, void* table, aod_stream_t stream) {
+  AOD_CHECK_ARG(d && table && !d->transposed, "row_table: bad args");
+  ConvKParams cp;
+  memset(&cp, 0, sizeof(cp));
+  int rc = fill_params(d, cp);
+  if (rc) return rc;
+  if (cp.M == 0) return 0;
+  for (int i = 0; i < d->nseg; ++i) AOD_CHECK_ARG(d->seg[i].H < 32768 && d->seg[i].W < 32768, "row_table: extent too large");
+  hipLaunchKernelGGL(row_table_kernel, dim3((cp.M + 255) / 256), dim3(256), 0, (hipStream_t)stream, cp, (RowRec*)table);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
 struct WgradParams {
   const bf16_t* x;
   const bf16_t* dz;
   float* dw;
-  int C, N, K, R, S, stride, pad, dil;
-  int nseg, M;
+  const RowRec* tab;
+  int C, N, K, R, S, dil;
+  int M;
   int tiles_n, tiles_k, splits, rows_per_split;
-  int segH[8], segW[8], segOH[8], segOW[8];
-  long long seg_src0[8], seg_dst0[8];
-  int seg_mend[8];
+  long long x_bytes, z_bytes;
 };
 
 // byte offset of (row, 16-B chunk) in a 256-B-pitch bf16 image that serves transposed reads
@@ -364,13 +413,18 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
   return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
+// dW[n][kk] += sum_m dZ[m][n] * X[pix(m, tap(kk))][c(kk)]: 128 x 128 output tile per workgroup, 64 pixels per step.
+// Both LDS images keep the global row-major form ([pixel][128 columns], 256-B rows) and are filled by LDS-DMA:
+// one wave-instruction = 4 pixel rows x 16 chunks, the conflict-avoiding XOR applied on the SOURCE chunk index,
+// which is the same for the 4 rows a lane serves -> every lane owns ONE fixed (tap, channel-chunk) column.
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  constexpr int BKM = 32;                 // contraction rows (pixels) per step
-  constexpr int IMG = BKM * 256;          // one [32][128] bf16 image
+  constexpr int BKM = 64;
+  constexpr int IMG = BKM * 256;
   constexpr int STAGE = 2 * IMG;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = uw >> 1, wn = uw & 1;
   int bid = blockIdx.x;
   const int split = bid % p.splits; bid /= p.splits;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
@@ -378,50 +432,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int ms = split * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   if (ms >= me) return;
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
 
-  const int ch = t & 15, rb = t >> 4;   // chunk column, row 0..15 (+16)
-  // dZ columns of this thread
+  const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group
+  const int ch = (lane & 15) ^ ((prow << 2) | uw);             // source chunk of this lane (fixed)
   const int zn = n0 + ch * 8;
-  const bool zok = zn < p.N;            // N % 8 == 0 is required
-  // X column (tap, channel) of this thread: fixed for the whole loop
+  const bool zok = zn < p.N;
   const int kk = k0 + ch * 8;
   const bool kok = kk < p.K;
   const int tap = kok ? kk / p.C : 0, c0 = kok ? kk - tap * p.C : 0;
   const int tr = tap / p.S, ts = tap - tr * p.S;
-  const int dy = tr * p.dil - p.pad, dx = ts * p.dil - p.pad;
+  const int dy = tr * p.dil, dx = ts * p.dil;
 
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  bf16x8 zreg[2], xreg[2];
-  auto gload = [&](int mbase) {
+  RowRec rec[4];
+  auto tload = [&](int mbase) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = mbase + rb + i * 16;
-      zreg[i] = zero8; xreg[i] = zero8;
-      if (m < me) {
-        int sg = 0, mstart = 0;
-        while (sg < p.nseg - 1 && m >= p.seg_mend[sg]) { mstart = p.seg_mend[sg]; ++sg; }
-        const int ml = m - mstart;
-        if (zok) zreg[i] = *reinterpret_cast<const bf16x8*>(p.dz + (p.seg_dst0[sg] + ml) * (long long)p.N + zn);
-        if (kok) {
-          const int ohw = p.segOH[sg] * p.segOW[sg];
-          const int b = ml / ohw, rem = ml - b * ohw;
-          const int oy = rem / p.segOW[sg], ox = rem - oy * p.segOW[sg];
-          const int y = oy * p.stride + dy, x = ox * p.stride + dx;
-          if ((unsigned)y < (unsigned)p.segH[sg] && (unsigned)x < (unsigned)p.segW[sg])
-            xreg[i] = *reinterpret_cast<const bf16x8*>(
-                p.x + (p.seg_src0[sg] + ((long long)b * p.segH[sg] + y) * p.segW[sg] + x) * p.C + c0);
-        }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + 16 * i + 4 * uw + prow;
+      rec[i] = p.tab[min(m, p.M - 1)];
     }
   };
-  auto lds_store = [&](int buf) {
+  auto gload = [&](int mbase, int buf) {
     char* sz = smem + buf * STAGE;
     char* sx = sz + IMG;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = rb + i * 16;
-      *reinterpret_cast<bf16x8*>(sz + tr_off(row, ch)) = zreg[i];
-      *reinterpret_cast<bf16x8*>(sx + tr_off(row, ch)) = xreg[i];
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + 16 * i + 4 * uw + prow;
+      const bool mok = m < me;
+      const RowRec r = rec[i];
+      const unsigned zoff = (mok && zok) ? (unsigned)(((long long)r.zrow * p.N + zn) * 2) : OOB;
+      const int y = r.y0 + dy, x = r.x0 + dx;
+      const bool xok = mok && kok && (unsigned)y < (unsigned)r.H && (unsigned)x < (unsigned)r.W;
+      const unsigned xoff = xok ? (unsigned)((((long long)r.pix0 + y * r.W + x) * p.C + c0) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + (16 * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + (16 * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
     }
   };
 
@@ -432,43 +478,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (me - ms + BKM - 1) / BKM;
-  gload(ms);
-  lds_store(0);
+  tload(ms);
+  gload(ms, 0);
+  if (nsteps > 1) tload(ms + BKM);
   __syncthreads();
-  // transposed-read lane roles: group g = lane>>4 covers k rows 8g..8g+7; lane 4q+p -> row q, cols 4p..4p+3
+  // transposed-read lane roles: group g = lane>>4 covers k rows 8g..8g+7 of a 32-row sub-step; lane 4q+pp -> row q, cols 4pp..4pp+3
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   for (int stp = 0; stp < nsteps; ++stp) {
     const int cur = stp & 1;
-    if (stp + 1 < nsteps) gload(ms + (stp + 1) * BKM);
+    if (stp + 1 < nsteps) {
+      gload(ms + (stp + 1) * BKM, cur ^ 1);                 // uses rec[] fetched one step ago
+      if (stp + 2 < nsteps) tload(ms + (stp + 2) * BKM);
+    }
     const char* sz = smem + cur * STAGE;
     const char* sx = sz + IMG;
-    bf16x8 af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = wm * 64 + i * 16 + pp * 4;          // n column of the block this lane addresses
-      const int r0 = 8 * g + q;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0, col >> 3) + (col & 7) * 2));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-      af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int r0 = ks * 32 + 8 * g + q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = wm * 64 + i * 16 + pp * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0, col >> 3) + (col & 7) * 2));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
+        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + pp * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
+        bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = wn * 64 + j * 16 + pp * 4;
-      const int r0 = 8 * g + q;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-      bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if (stp + 1 < nsteps) lds_store(cur ^ 1);
     __syncthreads();
   }
   // accumulate into dW[n][kk] (fp32 atomics; one dword per lane, 16 consecutive columns per row group)
@@ -485,8 +536,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       }
 }
 
-extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, aod_stream_t stream) {
-  AOD_CHECK_ARG(d && x && dz && dw, "wgrad: null pointer");
+extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, const void* row_table,
+                                aod_stream_t stream) {
+  AOD_CHECK_ARG(d && x && dz && dw && row_table, "wgrad: null pointer");
   AOD_CHECK_ARG(!d->transposed, "wgrad: descriptor must be the forward descriptor");
   AOD_CHECK_ARG(d->N % 8 == 0, "wgrad: N %d must be a multiple of 8 (pad dZ)", d->N);
   ConvKParams cp;
@@ -496,25 +548,36 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   if (cp.M == 0) return 0;
   WgradParams p;
   memset(&p, 0, sizeof(p));
-  p.x = (const bf16_t*)x; p.dz = (const bf16_t*)dz; p.dw = dw;
-  p.C = cp.C; p.N = cp.N; p.K = cp.K; p.R = cp.R; p.S = cp.S; p.stride = cp.stride; p.pad = cp.pad; p.dil = cp.dil;
-  p.nseg = cp.nseg; p.M = cp.M;
-  for (int i = 0; i < 8; ++i) {
-    p.segH[i] = cp.segH[i]; p.segW[i] = cp.segW[i]; p.segOH[i] = cp.segOH[i]; p.segOW[i] = cp.segOW[i];
-    p.seg_src0[i] = cp.seg_src0[i]; p.seg_dst0[i] = cp.seg_dst0[i]; p.seg_mend[i] = cp.seg_mend[i];
+  p.x = (const bf16_t*)x; p.dz = (const bf16_t*)dz; p.dw = dw; p.tab = (const RowRec*)row_table;
+  p.C = cp.C; p.N = cp.N; p.K = cp.K; p.R = cp.R; p.S = cp.S; p.dil = cp.dil; p.M = cp.M;
+  long long xrows = 0, zrows = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    const aod_conv_seg_t& sg = d->seg[i];
+    AOD_CHECK_ARG(sg.src_row0 >= 0 && sg.dst_row0 >= 0, "wgrad: negative row offset");
+    const long long e = sg.src_row0 + (long long)sg.B * sg.H * sg.W, ez = sg.dst_row0 + (long long)sg.B * sg.OH * sg.OW;
+    if (e > xrows) xrows = e;
+    if (ez > zrows) zrows = ez;
   }
+  p.x_bytes = xrows * p.C * 2;
+  p.z_bytes = zrows * p.N * 2;
+  AOD_CHECK_ARG(p.x_bytes < 0xfffffff0ll && p.z_bytes < 0xfffffff0ll, "wgrad: operand larger than 4 GiB (32-bit buffer offsets)");
   p.tiles_n = (p.N + 127) / 128;
   p.tiles_k = (p.K + 127) / 128;
   const int tiles = p.tiles_n * p.tiles_k;
-  int splits = (1024 + tiles - 1) / tiles;               // aim at >= 4 workgroups per CU
-  const int max_splits = (p.M + 255) / 256;              // at least 8 steps per workgroup
+  int splits = (512 + tiles - 1) / tiles;                // ~2 workgroups per CU
+  const int max_splits = (p.M + 511) / 512;              // at least 8 steps per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int rps = (p.M + splits - 1) / splits;
-  rps = (rps + 31) / 32 * 32;
+  rps = (rps + 63) / 64 * 64;
   splits = (p.M + rps - 1) / rps;
   p.splits = splits; p.rows_per_split = rps;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, p);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 65536, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -36,7 +36,8 @@ def multi_rows(tensors):
     rb = rows[0].shape[1] * rows[0].element_size()
     base = min(rows, key=lambda r: r.data_ptr())
     offs = [r.data_ptr() - base.data_ptr() for r in rows]
-    if all(o % rb == 0 for o in offs):
+    span = max(o + r.numel() * r.element_size() for o, r in zip(offs, rows))
+    if all(o % rb == 0 for o in offs) and span < (1 << 31):       # kernels address operands with 32-bit buffer offsets
         return base, [Seg(t.shape[0], t.shape[2], t.shape[3], o // rb) for t, o in zip(tensors, offs)]
     cat = torch.cat(rows)
     segs, r0 = [], 0
@@ -106,8 +107,9 @@ class ConvFn(Function):
             shift = bias.detach()
         need_z = gamma is not None and ctx.needs_input_grad[2]
         res_rows = as_rows(res) if res is not None else None
+        out_rows = as_rows(meta['out']) if meta.get('out') is not None else None      # caller-provided destination (pyramid slice)
         r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
-                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], save_z=need_z)
+                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], save_z=need_z, out=out_rows)
         y_rows, y_segs = r[0], r[1]
         z_rows = r[2] if need_z else None
         ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
@@ -179,11 +181,11 @@ class ConvFn(Function):
         return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
 
 
-def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False):
+def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None):
     """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps."""
     single = torch.is_tensor(xs)
     xl = [xs] if single else list(xs)
-    meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0)
+    meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out)
     if bn is not None:
         outs = ConvFn.apply(meta, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, res, *xl)
     else:
@@ -229,6 +231,18 @@ class UpsampleAddFn(Function):
             ho.upsample_add_bwd_(gt_rows, Seg(B, h, w), g_rows, Seg(B, H, W))
             gt = as_nchw(gt_rows, B, h, w)
         return (g if ctx.needs_input_grad[0] else None), gt
+
+
+def pyramid_buffer(shapes, channels, device, dtype=torch.bfloat16):
+    """One flat [sum(B*H*W), C] allocation + per-level [B,C,H,W] channels_last views (adjacent levels: a
+    level-batched conv reads them as segments of ONE buffer, no copy, 32-bit offsets)."""
+    rows = sum(b * h * w for b, h, w in shapes)
+    flat = torch.empty(rows, channels, device=device, dtype=dtype)
+    views, r = [], 0
+    for b, h, w in shapes:
+        views.append(as_nchw(flat[r:r + b * h * w], b, h, w))
+        r += b * h * w
+    return flat, views
 
 
 def upsample_add(lateral, top):

@@ -13,6 +13,9 @@ from . import _C
 from ._C import ConvDesc, ConvSeg, call, ptr, stream
 
 
+_ROW_TABLES = {}     # wgrad row tables, one per conv geometry (shared by every layer / iteration with that geometry)
+
+
 # ---- optional per-launch profiling (bench.py): (kind, tile, flops, start_event, end_event) on the CURRENT stream
 PROFILE = None
 
@@ -121,7 +124,13 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     if dw is None:
         dw = torch.zeros(Npad, R, S, Cin, dtype=torch.float32, device=x_rows.device)
     d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
-    _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), stream()))
+    key = (tuple(x_segs), tuple(dz_segs), R, S, stride, pad, dil, x_rows.device.index)
+    tab = _ROW_TABLES.get(key)
+    if tab is None:
+        tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=x_rows.device)
+        call('aod_conv_row_table', C.byref(d), ptr(tab), stream())
+        _ROW_TABLES[key] = tab
+    _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), ptr(tab), stream()))
     return dw
 
 

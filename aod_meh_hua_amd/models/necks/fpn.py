@@ -50,7 +50,17 @@ class FPN(BaseModule):
         n = len(laterals)
         for i in range(n - 1, 0, -1):
             laterals[i - 1] = AF.upsample_add(laterals[i - 1], laterals[i])
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        # all output levels live in ONE pyramid buffer so that the head's level-batched convs read them in place
+        from ...hipops import out_hw
+        shapes = [(l.shape[0], l.shape[2], l.shape[3]) for l in laterals]
+        if self.num_outs > n and self.add_extra_convs:
+            src0 = inputs[self.backbone_end_level - 1] if self.add_extra_convs == 'on_input' else laterals[-1]
+            hw = (src0.shape[2], src0.shape[3]) if self.add_extra_convs != 'on_output' else shapes[-1][1:]
+            for _ in range(n, self.num_outs):
+                hw = out_hw(hw[0], hw[1], 3, 3, 2, 1, 1)
+                shapes.append((laterals[0].shape[0], hw[0], hw[1]))
+        _, slots = AF.pyramid_buffer(shapes, self.out_channels, laterals[0].device)
+        outs = [self.fpn_convs[i](laterals[i], out=slots[i]) for i in range(n)]
         if self.num_outs > len(outs):
             assert self.add_extra_convs, 'max-pool extra levels (Faster R-CNN style) are not on the MEH/HUA path'
             if self.add_extra_convs == 'on_input':
@@ -59,7 +69,7 @@ class FPN(BaseModule):
                 src = laterals[-1]
             else:
                 src = outs[-1]
-            outs.append(self.fpn_convs[n](src))
+            outs.append(self.fpn_convs[n](src, out=slots[n]))
             for i in range(n + 1, self.num_outs):
-                outs.append(self.fpn_convs[i](outs[-1]))
+                outs.append(self.fpn_convs[i](outs[-1], out=slots[i]))
         return tuple(outs)

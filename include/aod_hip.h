@@ -67,7 +67,12 @@ int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packe
  * call sites.  dw_f32 is [N][R][S][C] fp32 and is ACCUMULATED into (caller zeroes it);
  * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */
 int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz, float* dw_f32,
-                     aod_stream_t stream);
+                     const void* row_table, aod_stream_t stream);
+/* Row table of a forward descriptor (16 B per destination pixel: source block origin, top-left tap, extents,
+ * dZ row).  Depends only on segment geometry / stride / pad / filter size: build once, reuse for every wgrad
+ * launch with that geometry. */
+size_t aod_conv_row_table_bytes(const aod_conv_desc_t* desc);
+int aod_conv_row_table(const aod_conv_desc_t* desc, void* table, aod_stream_t stream);
 
 /* OIHW fp32 -> [O][R][S][Ipad] bf16 (forward) / [I][R][S][Opad] bf16 (dgrad); pads zero-filled, multiples of 8 */
 int aod_pack_weight_fwd(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Ipad, aod_stream_t stream);
