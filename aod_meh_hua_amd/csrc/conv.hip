@@ -336,14 +336,14 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   p.w_bytes = (long long)p.N * p.K * 2;
   AOD_CHECK_ARG(p.x_bytes < 0xfffffff0ll && p.w_bytes < 0xfffffff0ll, "conv: operand larger than 4 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (p.N > 64 && t128 >= 384) launch_conv<128, 128>(p, st);
-  else if (p.N > 64) {
-    const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (t64 >= 2048 || p.M >= 16384) launch_conv<128, 128>(p, st); else launch_conv<64, 128>(p, st);
-  } else {
-    if ((p.M + 127) / 128 >= 512) launch_conv<128, 64>(p, st); else launch_conv<64, 64>(p, st);
-  }
+  // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups
+  auto ntiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const long long want = 512;
+  if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
+  else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
+  else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
+  else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) launch_conv<128, 64>(p, st);
+  else launch_conv<64, 64>(p, st);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,172 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/aod_hip.h declares, the product
+refuses CPU tensors, and the host-side mirror of the reference interface (registry / config / plugins / AL logic)
+behaves like the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from aod_meh_hua_amd.build import build
+    return ctypes.CDLL(build(verbose=False))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'aod_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(aod_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.aod_last_error.restype = ctypes.c_char_p
+    assert lib.aod_version() >= 1 and lib.aod_last_error() is not None
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(lib):
+    """Argument validation happens before any launch: error code -1 + message, no crash."""
+    from aod_meh_hua_amd._C import ConvDesc
+    d = ConvDesc()
+    d.C, d.N, d.R, d.S, d.stride, d.pad, d.dil, d.nseg = 12, 64, 3, 3, 1, 1, 1, 1      # C not a multiple of 8
+    one = ctypes.c_void_p(16)
+    lib.aod_conv2d.restype = ctypes.c_int
+    rc = lib.aod_conv2d(ctypes.byref(d), one, one, one, None, None, None, None, None, None, None)
+    assert rc == -1
+    lib.aod_last_error.restype = ctypes.c_char_p
+    assert b'multiple of 8' in lib.aod_last_error()
+    lib.aod_loss_partials_len.restype = ctypes.c_size_t
+    assert lib.aod_loss_partials_len(ctypes.c_int64(1000)) == 12
+
+
+def test_product_refuses_cpu_tensors():
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import AodHipError
+    with pytest.raises(AodHipError):
+        ho.add_relu(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
+    with pytest.raises(AodHipError):
+        ho.edl_focal_l1_fwd(torch.zeros(4, 20), torch.zeros(4, dtype=torch.long), torch.ones(4))
+
+
+def test_product_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import aod_meh_hua_amd.models, aod_meh_hua_amd.scoring, aod_meh_hua_amd.apis; "
+            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]") % ROOT
+    subprocess.check_call([sys.executable, '-c', code])
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'aod_meh_hua_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_registry_and_config_build_the_reference_types():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    assert cfg.X_L_0_size == 16551 // 20 and cfg.model.bbox_head.loss_cls.last_activation == 'relu'
+    cfg.model.backbone.pop('init_cfg')
+    model = build_detector(cfg.model)
+    assert type(model).__name__ == 'SSL_L_RetinaNet' and type(model.bbox_head).__name__ == 'Lambda_L2Net'
+    g = np.load(os.path.join(G, 'state_dict_spec.npz'))
+    assert list(model.state_dict().keys()) == list(g['keys'])
+    assert sum(p.numel() for p in model.parameters()) == int(g['n_params'])
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == int(g['n_trainable'])
+    # frozen stem + layer1, BN kept in eval mode by train() (resnet.py:612-656)
+    model.train()
+    assert not model.backbone.conv1.weight.requires_grad and not model.backbone.layer1[0].conv1.weight.requires_grad
+    assert model.backbone.layer2[0].bn1.weight.requires_grad and not model.backbone.layer2[0].bn1.training
+    # init_cfg semantics: head Normal(0.01) + retina_cls bias_prob=0.01; FPN Xavier uniform
+    model.init_weights()
+    h = model.bbox_head
+    assert abs(float(h.retina_cls.bias[0]) + np.log(99)) < 1e-5 and float(h.retina_reg.bias.abs().max()) == 0
+    assert 0.008 < float(h.cls_convs[0].conv.weight.std()) < 0.012
+    w = model.neck.lateral_convs[0].conv.weight
+    assert float(w.abs().max()) <= np.sqrt(6.0 / (512 + 256)) + 1e-6
+    # the driver touches these attributes (train_RetinaNet.py:157-176, train_Lambda.py:55-61)
+    assert h.num_anchors == 9 and h.L_names == ['retina_L', 'L_convs'] and len(h.cls_convs) == 4
+    with pytest.raises(KeyError):
+        build_detector(dict(type='NoSuchDetector'))
+
+
+def test_anchor_generator_matches_reference_golden():
+    from aod_meh_hua_amd.core.anchor import AnchorGenerator, SSDAnchorGenerator
+    g = np.load(os.path.join(G, 'anchors.npz'))
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    assert np.array_equal(np.stack([b.numpy() for b in ag.base_anchors]), g['base'])
+    small = ag.grid_anchors([(16, 12), (8, 6), (4, 3), (2, 2), (1, 1)], 'cpu')
+    assert np.array_equal(torch.cat(small).numpy(), g['grid_small'])
+    f = ag.valid_flags([(16, 12), (8, 6), (4, 3), (2, 2), (1, 1)], (120, 96, 3), 'cpu')
+    assert np.array_equal(torch.cat(f).numpy(), g['flags_small'])
+    assert ag.grid_anchors([(16, 12), (8, 6), (4, 3), (2, 2), (1, 1)], 'cpu')[0] is small[0]      # cached
+    ssd = SSDAnchorGenerator(strides=[8, 16, 32, 64, 100, 300], ratios=[[2], [2, 3], [2, 3], [2, 3], [2], [2]], basesize_ratio_range=(0.2, 0.9),
+                             input_size=300, scale_major=False)
+    assert ssd.base_sizes == [30, 60, 111, 162, 213, 264] and ssd.num_base_anchors == [4, 6, 6, 6, 4, 4]
+    assert sum(a.shape[0] for a in ssd.grid_anchors([(38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1)], 'cpu')) == 8732
+
+
+def test_coder_and_iou_api_match_golden():
+    from aod_meh_hua_amd.core.bbox import BboxOverlaps2D, DeltaXYWHBBoxCoder
+    g = np.load(os.path.join(G, 'coder.npz'))
+    c = DeltaXYWHBBoxCoder()
+    rois, gts, d = (torch.from_numpy(g[k]) for k in ('rois', 'gts', 'deltas'))
+    assert np.array_equal(c.encode(rois, gts).numpy(), g['enc'])
+    assert np.array_equal(c.decode(rois, d, max_shape=(128, 160, 3)).numpy(), g['dec'])
+    iou = BboxOverlaps2D()(torch.tensor([[0., 0., 10., 10., 0.9]]), torch.tensor([[0., 0., 10., 5.]]))
+    assert float(iou) == 0.5
+
+
+def test_selection_rule_matches_reference():
+    from aod_meh_hua_amd.utils.active_datasets import update_X_L
+    g = np.load(os.path.join(G, 'selection.npz'))
+    np.random.seed(20)
+    a, b = update_X_L(g['unc'].copy(), np.arange(400), g['X_L'].copy(), 20, zeroRate=0.15)
+    assert np.array_equal(a, g['XL_zero']) and np.array_equal(b, g['XU_zero'])
+    np.random.seed(20)
+    a, b = update_X_L(torch.from_numpy(g['unc'].copy()), np.arange(400), g['X_L'].copy(), 20)
+    assert np.array_equal(a, g['XL_plain']) and np.array_equal(b, g['XU_plain'])
+
+
+def test_parse_losses_sums_every_loss_key():
+    from aod_meh_hua_amd.models.detectors.SSL_Lambda import SSLBase_L_Detector
+
+    class D(SSLBase_L_Detector):
+        def extract_feat(self, x): ...
+        def simple_test(self, *a, **k): ...
+    losses = dict(loss_cls=[torch.tensor(1.0), torch.tensor(2.0)], loss_bbox=[torch.tensor(0.5)], loss_noR=[torch.tensor([1.0, 3.0])],
+                  acc=torch.tensor(9.0))
+    loss, lv = D()._parse_losses(losses, device='cpu')
+    assert float(loss) == 1 + 2 + 0.5 + 2.0 and float(lv['acc']) == 9.0 and float(lv['loss_noR']) == 2.0
+
+
+def test_agg_codes_and_functions():
+    from aod_meh_hua_amd.scoring import extract_agg_codes
+    from aod_meh_hua_amd.utils.functions import ExtractAggFunc, StartEnd
+    assert extract_agg_codes('objectSum_scaleMax_classSum') == (0, 2, 0)
+    assert extract_agg_codes('objectAvg_scaleSum_classMax') == (2, 0, 1)
+    f = ExtractAggFunc('objectSum_scaleMax_classAvg')
+    assert f['object'] is torch.sum and f['scale'] is torch.max and f['class'] is torch.mean
+    assert StartEnd([torch.zeros(2, 1000, 20), torch.zeros(2, 576, 20), torch.zeros(2, 144, 20)], 1) == (1000, 1576)
+
+
+def test_synthetic_dataset_and_loader_contract():
+    from aod_meh_hua_amd.datasets import build_dataloader, build_dataset
+    from aod_meh_hua_amd.mmcv_lite import scatter_kwargs
+    ds = build_dataset(dict(type='RepeatDataset', times=2, dataset=dict(type='SyntheticVOCDataset', num_images=5, size=(64, 64))))
+    assert len(ds) == 10 and len(ds.CLASSES) == 20
+    a, b = ds[3], ds[8]
+    assert torch.equal(a['img'], b['img'])                       # deterministic per index
+    dl = build_dataloader(ds.dataset, 2, 0, dist=False, shuffle=False)
+    batch = next(iter(dl))
+    data = scatter_kwargs(batch, 'cpu')
+    assert data['img'].shape == (2, 3, 64, 64) and len(data['img_metas']) == 2 and data['img_metas'][0]['pad_shape'] == (64, 64, 3)
+    assert len(data['gt_bboxes']) == 2 and data['gt_bboxes'][0].shape[1] == 4 and data['gt_labels'][0].dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        build_dataset(dict(type='VOCDataset', ann_file='x'))

@@ -1,0 +1,65 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: pool sharding + score all-gather (partition invariant,
+padding trimmed) and gradient averaging through flat buckets."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores, shard_range
+    lo, hi, per = shard_range(n_total)
+    # each rank "scores" its block with a function of the GLOBAL image index only
+    local = torch.tensor([float(i * i % 17) + 0.25 for i in range(lo, hi)])
+    full = gather_scores(local, n_total)
+    # gradient averaging: rank r holds grads r+1 on two tensors spanning two buckets
+    p1, p2 = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))
+    p1.grad, p2.grad = torch.full((5,), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))
+    gs = GradSync(bucket_mb=1)
+    gs.bucket_elems = 6
+    gs.all_reduce_grads([p1, p2])
+    m = torch.nn.Linear(2, 2)
+    with torch.no_grad():
+        m.weight.fill_(float(rank))
+    broadcast_model(m)
+    q.put((rank, lo, hi, full.tolist(), p1.grad.tolist(), p2.grad.flatten().tolist(), m.weight.flatten().tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_total', [7, 8, 1])
+def test_shard_gather_and_grad_sync_world2(n_total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_total) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [float(i * i % 17) + 0.25 for i in range(n_total)]
+    covered = []
+    for rank, lo, hi, full, g1, g2, w in res:
+        assert full == expect                               # identical on every rank, padding trimmed
+        covered += list(range(lo, hi))
+        assert g1 == [1.5] * 5 and g2 == [15.0] * 6         # mean of per-rank gradients
+        assert w == [0.0] * 4                               # rank-0 weights everywhere
+    assert covered == list(range(n_total))                  # blocks tile the pool exactly once
+
+
+def test_single_process_paths_are_noops():
+    sys.path.insert(0, ROOT)
+    from aod_meh_hua_amd.parallel import GradSync, gather_scores, get_dist_info, shard_range
+    assert get_dist_info() == (0, 1) and shard_range(10) == (0, 10, 10)
+    x = torch.arange(5.0)
+    assert torch.equal(gather_scores(x, 5), x)
+    GradSync().all_reduce_grads([torch.nn.Parameter(torch.zeros(2))])
