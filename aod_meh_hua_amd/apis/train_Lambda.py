@@ -9,6 +9,7 @@ from ..mmcv_lite import MMDataParallel, build_runner
 from ..optim import FusedSGD, build_optimizer
 from ..parallel import broadcast_model
 from ..utils import get_root_logger
+from ..utils import Epoch_Based_Runner_Lambda  # noqa: F401  (registers MyEpochBasedRunnerLambda)
 
 
 def RemoveParamFromOptim(optimizer, model, param_name):
