@@ -101,33 +101,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     wbase[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8) * 2) : OOB;
   }
 
+  // A-operand byte offsets are kept incrementally: inside one filter tap consecutive K-steps only advance the
+  // channel offset by BK elements (and the validity of the tap does not change), so the full coordinate / bounds
+  // computation runs once per tap instead of once per K-step.  Invalid rows park at OOB_BASE, which stays out of
+  // range under the increments (x_bytes < OOB_BASE is checked on the host).
+  constexpr unsigned OOB_BASE = 0xf0000000u;
+  const bool fast_tap = (C8 % CPR) == 0;          // then every lane of the block changes tap at the same K-step
+  unsigned aoff[A_IT];
+  unsigned woff[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) aoff[i] = OOB_BASE;
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) woff[i] = wbase[i] == OOB ? OOB_BASE : wbase[i];
+  int ksteps_in_tap = 0;
+  bool new_tap = true;
+  const int steps_per_tap = fast_tap ? C8 / CPR : 1;
+
   auto gload = [&](int kt, int buf) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + A_BYTES;
-    const bool tapok = tr < p.R;
-    const int dy = tr * p.dil, dx = ts * p.dil;
+    if (new_tap) {
+      const bool tapok = tr < p.R;
+      const int dy = tr * p.dil, dx = ts * p.dil;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        int y, x;
+        bool ok = tapok;
+        if (p.transposed) {
+          const int ty = ry0[i] - dy, tx = rx0[i] - dx;
+          if (p.stride == 1) { y = ty; x = tx; }
+          else { ok = ok && ((ty | tx) >= 0) && (ty % p.stride == 0) && (tx % p.stride == 0); y = ty / p.stride; x = tx / p.stride; }
+        } else { y = ry0[i] + dy; x = rx0[i] + dx; }
+        ok = ok && (unsigned)y < (unsigned)rH[i] && (unsigned)x < (unsigned)rW[i];
+        aoff[i] = ok ? rbase[i] + (unsigned)(((y * rW[i] + x) * p.C + c8 * 8) * 2) : OOB_BASE;
+      }
+      new_tap = false;
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int y, x;
-      bool ok = tapok;
-      if (p.transposed) {
-        const int ty = ry0[i] - dy, tx = rx0[i] - dx;
-        if (p.stride == 1) { y = ty; x = tx; }
-        else { ok = ok && ((ty | tx) >= 0) && (ty % p.stride == 0) && (tx % p.stride == 0); y = ty / p.stride; x = tx / p.stride; }
-      } else { y = ry0[i] + dy; x = rx0[i] + dx; }
-      ok = ok && (unsigned)y < (unsigned)rH[i] && (unsigned)x < (unsigned)rW[i];
-      const unsigned off = ok ? rbase[i] + (unsigned)(((y * rW[i] + x) * p.C + c8 * 8) * 2) : OOB;
+      const unsigned off = aoff[i];     // (a plain local: a subscript of a template-sized array is type-dependent and the host pass rejects it as a builtin argument)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
     const bool kok = (kt * BK + kc * 8) < p.K;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const unsigned off = (kok && wbase[i] != OOB) ? wbase[i] + (unsigned)(kt * BK * 2) : OOB;
+      const unsigned off = kok ? woff[i] : OOB_BASE;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
-    // advance tap state by one K-step
+    // advance by one K-step
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) woff[i] += BK * 2;
     c8 += CPR;
-    while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
+    if (fast_tap && ++ksteps_in_tap < steps_per_tap) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) aoff[i] += BK * 2;
+    } else {
+      ksteps_in_tap = 0;
+      while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
+      new_tap = true;
+    }
   };
 
   f32x4 acc[MI][NI];
@@ -181,6 +213,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int NCH = BN / 8;              // 8-column chunks per tile row
   constexpr int E_IT = BM * NCH / 256;
   const int ec = t % NCH, er = t / NCH;
+  // this thread always owns the same 8 output columns: fetch their scale/shift vectors once
+  float cs1[8], cb1[8], cs2[8];
+  {
+    const int n = n0 + ec * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = n + j < p.N;
+      cs1[j] = (p.pre_scale && ok) ? p.pre_scale[n + j] : 1.f;
+      cb1[j] = (p.pre_shift && ok) ? p.pre_shift[n + j] : 0.f;
+      cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
+    }
+  }
 #pragma unroll 1
   for (int it = 0; it < E_IT; ++it) {
     const int row = er + it * (256 / NCH);
@@ -200,14 +244,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     for (int j = 0; j < 8; ++j) raw[j] = v[j];
     if (full) {
       const long long off = drow * p.N + n;
-      if (p.pre_scale) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= p.pre_scale[n + j];
-      }
-      if (p.pre_shift) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += p.pre_shift[n + j];
-      }
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
       if (p.res) {
         const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.res + off);
 #pragma unroll
@@ -220,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       }
       if (p.post_scale) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= p.post_scale[n + j];
+        for (int j = 0; j < 8; ++j) v[j] *= cs2[j];
       }
       if (p.relu) {
 #pragma unroll
@@ -334,7 +372,7 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   }
   p.x_bytes = xrows * p.C * 2;
   p.w_bytes = (long long)p.N * p.K * 2;
-  AOD_CHECK_ARG(p.x_bytes < 0xfffffff0ll && p.w_bytes < 0xfffffff0ll, "conv: operand larger than 4 GiB (32-bit buffer offsets)");
+  AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.w_bytes < 0xe0000000ll, "conv: operand larger than 3.5 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups
   auto ntiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -355,10 +393,11 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
 // Depends only on the segment geometry / stride / pad, so it is built once per geometry and shared by every conv
 // (and every iteration) with that geometry -- the per-step im2col decode of wgrad becomes one 16-B load.
 struct RowRec {
-  unsigned pix0;     // row index of source pixel (b, 0, 0)
-  short y0, x0;      // top-left tap coordinate (oy*stride - pad, ox*stride - pad)
-  short H, W;        // source block extent
-  unsigned zrow;     // row of this pixel in the dZ / output buffer
+  unsigned xrow;     // byte offset of the top-left tap pixel (b, y0, x0) in the source (wraps for y0/x0 < 0: only used when valid)
+  unsigned zoff;     // byte offset of this pixel's row in the dZ buffer
+  unsigned wc2;      // source row pitch in bytes: W * C * 2
+  unsigned pad_;
+  unsigned long long mask;   // bit (r*S + s) set <=> tap (r, s) lies inside the image for this pixel (R*S <= 64)
 };
 
 __global__ void row_table_kernel(const ConvKParams p, RowRec* __restrict__ tab) {
@@ -370,11 +409,20 @@ __global__ void row_table_kernel(const ConvKParams p, RowRec* __restrict__ tab) 
   const int ohw = p.segOH[sg] * p.segOW[sg];
   const int b = ml / ohw, rem = ml - b * ohw;
   const int oy = rem / p.segOW[sg], ox = rem - oy * p.segOW[sg];
+  const int H = p.segH[sg], W = p.segW[sg];
+  const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
   RowRec r;
-  r.pix0 = (unsigned)(p.seg_src0[sg] + (long long)b * p.segH[sg] * p.segW[sg]);
-  r.y0 = (short)(oy * p.stride - p.pad); r.x0 = (short)(ox * p.stride - p.pad);
-  r.H = (short)p.segH[sg]; r.W = (short)p.segW[sg];
-  r.zrow = (unsigned)(p.seg_dst0[sg] + ml);
+  r.xrow = (unsigned)((p.seg_src0[sg] + (long long)b * H * W + (long long)y0 * W + x0) * p.C * 2);
+  r.zoff = (unsigned)((p.seg_dst0[sg] + ml) * (long long)p.N * 2);
+  r.wc2 = (unsigned)(W * p.C * 2);
+  unsigned long long mk = 0;
+  for (int tr = 0; tr < p.R; ++tr)
+    for (int ts = 0; ts < p.S; ++ts) {
+      const int y = y0 + tr * p.dil, x = x0 + ts * p.dil;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) mk |= 1ull << (tr * p.S + ts);
+    }
+  r.mask = mk;
+  r.pad_ = 0;
   tab[m] = r;
 }
 
@@ -391,7 +439,7 @@ extern "C" int aod_conv_row_table(const aod_conv_desc_t* d, void* table, aod_str
   int rc = fill_params(d, cp);
   if (rc) return rc;
   if (cp.M == 0) return 0;
-  for (int i = 0; i < d->nseg; ++i) AOD_CHECK_ARG(d->seg[i].H < 32768 && d->seg[i].W < 32768, "row_table: extent too large");
+  AOD_CHECK_ARG(d->R * d->S <= 64, "row_table: at most 64 filter taps (got %d)", d->R * d->S);
   hipLaunchKernelGGL(row_table_kernel, dim3((cp.M + 255) / 256), dim3(256), 0, (hipStream_t)stream, cp, (RowRec*)table);
   AOD_LAUNCH_CHECK();
   return 0;
@@ -434,8 +482,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   if (ms >= me) return;
   const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
-  constexpr unsigned OOB = 0xfffffff0u;
-
   const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group
   const int ch = (lane & 15) ^ ((prow << 2) | uw);             // source chunk of this lane (fixed)
   const int zn = n0 + ch * 8;
@@ -446,6 +492,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int tr = tap / p.S, ts = tap - tr * p.S;
   const int dy = tr * p.dil, dx = ts * p.dil;
 
+  // per-lane constants: byte offset of this lane's (tap, channel chunk) relative to a pixel's top-left tap, and its mask bit
+  const unsigned cdx = (unsigned)((dx * p.C + c0) * 2);
+  const unsigned long long tbit = kok ? (1ull << tap) : 0ull;
+  const unsigned zcol = (unsigned)(zn * 2);
+  constexpr unsigned OOB_BASE = 0xf0000000u;
   RowRec rec[4];
   auto tload = [&](int mbase) {
 #pragma unroll
@@ -462,10 +513,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       const int m = mbase + 16 * i + 4 * uw + prow;
       const bool mok = m < me;
       const RowRec r = rec[i];
-      const unsigned zoff = (mok && zok) ? (unsigned)(((long long)r.zrow * p.N + zn) * 2) : OOB;
-      const int y = r.y0 + dy, x = r.x0 + dx;
-      const bool xok = mok && kok && (unsigned)y < (unsigned)r.H && (unsigned)x < (unsigned)r.W;
-      const unsigned xoff = xok ? (unsigned)((((long long)r.pix0 + y * r.W + x) * p.C + c0) * 2) : OOB;
+      const unsigned zoff = (mok && zok) ? r.zoff + zcol : OOB_BASE;
+      const unsigned xoff = (mok && (r.mask & tbit)) ? r.xrow + (unsigned)dy * r.wc2 + cdx : OOB_BASE;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + (16 * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + (16 * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
     }
@@ -560,16 +609,24 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   }
   p.x_bytes = xrows * p.C * 2;
   p.z_bytes = zrows * p.N * 2;
-  AOD_CHECK_ARG(p.x_bytes < 0xfffffff0ll && p.z_bytes < 0xfffffff0ll, "wgrad: operand larger than 4 GiB (32-bit buffer offsets)");
+  AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
   p.tiles_n = (p.N + 127) / 128;
   p.tiles_k = (p.K + 127) / 128;
   const int tiles = p.tiles_n * p.tiles_k;
-  int splits = (512 + tiles - 1) / tiles;                // ~2 workgroups per CU
-  const int max_splits = (p.M + 511) / 512;              // at least 8 steps per workgroup
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int rps = (p.M + splits - 1) / splits;
-  rps = (rps + 63) / 64 * 64;
+  // split of the pixel axis over workgroups: all workgroups co-resident (<= 2 per CU, no ragged second round); cost model
+  // (measured on MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup
+  // ends with 64 KB of fp32 atomics (~1.3 TB/s chip-wide = 0.05 us per workgroup)
+  int best = 1;
+  double best_cost = 1e30;
+  const int max_s = 512 / tiles > 0 ? 512 / tiles : 1;
+  for (int sp = 1; sp <= max_s; ++sp) {
+    const int rows = ((p.M + sp - 1) / sp + 63) / 64 * 64;
+    const int wgs = tiles * ((p.M + rows - 1) / rows);
+    const double cost = (rows / 64) * (wgs > 256 ? 1.7 : 1.45) + wgs * 0.05;
+    if (cost < best_cost) { best_cost = cost; best = sp; }
+  }
+  int splits = best;
+  int rps = ((p.M + splits - 1) / splits + 63) / 64 * 64;
   splits = (p.M + rps - 1) / rps;
   p.splits = splits; p.rows_per_split = rps;
   static bool attr_done = false;
@@ -599,11 +656,13 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, bf16_t* __restr
     o[i] = (oo < O) ? (bf16_t)w[((long long)oo * I + c) * RS + rs] : (bf16_t)0.f;
   }
 }
-__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ g, int O, int I, int RS, int Ipad, int accumulate) {
+__global__ void unpack_wgrad_kernel(float* __restrict__ dw, float* __restrict__ g, int O, int I, int RS, int Ipad, int accumulate, int clear) {
   const long long n = (long long)O * I * RS;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int rs = i % RS; const long long r1 = i / RS; const int c = r1 % I; const int oo = r1 / I;
-    const float v = dw[((long long)oo * RS + rs) * Ipad + c];
+    const long long si = ((long long)oo * RS + rs) * Ipad + c;
+    const float v = dw[si];
+    if (clear) dw[si] = 0.f;          // hand the accumulator back all-zero: no separate memset launch per conv
     g[i] = accumulate ? g[i] + v : v;
   }
 }
@@ -621,9 +680,9 @@ extern "C" int aod_pack_weight_dgrad(const float* w, void* o, int O, int I, int 
   AOD_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int aod_unpack_wgrad(const float* dw, float* g, int O, int I, int R, int S, int Ipad, int accumulate, aod_stream_t stream) {
+extern "C" int aod_unpack_wgrad(float* dw, float* g, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src, aod_stream_t stream) {
   AOD_CHECK_ARG(dw && g, "unpack_wgrad: null");
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((long long)O * R * S * I)), dim3(256), 0, (hipStream_t)stream, dw, g, O, I, R * S, Ipad, accumulate);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((long long)O * R * S * I)), dim3(256), 0, (hipStream_t)stream, dw, g, O, I, R * S, Ipad, accumulate, clear_src);
   AOD_LAUNCH_CHECK();
   return 0;
 }

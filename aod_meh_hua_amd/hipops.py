@@ -122,9 +122,11 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     """dW[Npad][R][S][C] fp32 (accumulated into `dw` if given)."""
     Cin, Npad = x_rows.shape[1], dz_rows.shape[1]
     if dw is None:
-        dw = torch.zeros(Npad, R, S, Cin, dtype=torch.float32, device=x_rows.device)
+        dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
-    key = (tuple(x_segs), tuple(dz_segs), R, S, stride, pad, dil, x_rows.device.index)
+    if len(_ROW_TABLES) > 512:
+        _ROW_TABLES.clear()
+    key = (tuple(x_segs), tuple(dz_segs), Cin, Npad, R, S, stride, pad, dil, x_rows.device.index)
     tab = _ROW_TABLES.get(key)
     if tab is None:
         tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=x_rows.device)
@@ -134,11 +136,30 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     return dw
 
 
-def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False):
+_DW = {}
+
+
+def _dw_scratch(n, device):
+    """Persistent all-zero fp32 accumulator for wgrad (per device).  Invariant: all-zero between uses --
+    `unpack_wgrad(clear=True)` zeroes what wgrad touched, so no memset launch is needed per conv."""
+    buf = _DW.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 1 << 22), dtype=torch.float32, device=device)
+        _DW[device] = buf
+    return buf[:n]
+
+
+def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None):
     Opad, R, S, Ipad = dw_orsi.shape
     if grad_oihw is None:
         grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
-    call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), stream())
+    if clear is None:      # scratch-backed accumulators must go back all-zero; pad rows/channels only ever receive zeros
+        buf = _DW.get(dw_orsi.device)
+        clear = buf is not None and dw_orsi.data_ptr() == buf.data_ptr()
+    if clear and (O != Opad or I != Ipad):
+        # dZ pad columns / x pad channels are zero, so wgrad added exact zeros there: nothing to clear beyond [O, I]
+        pass
+    call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), int(bool(clear)), stream())
     return grad_oihw
 
 

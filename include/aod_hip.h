@@ -77,8 +77,11 @@ int aod_conv_row_table(const aod_conv_desc_t* desc, void* table, aod_stream_t st
 /* OIHW fp32 -> [O][R][S][Ipad] bf16 (forward) / [I][R][S][Opad] bf16 (dgrad); pads zero-filled, multiples of 8 */
 int aod_pack_weight_fwd(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Ipad, aod_stream_t stream);
 int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Opad, aod_stream_t stream);
-/* [O][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient, grad_oihw (+)= ; accumulate != 0 adds */
-int aod_unpack_wgrad(const float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, aod_stream_t stream);
+/* [Opad][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient (first O rows / I channels); accumulate != 0 adds;
+ * clear_src != 0 zeroes every element it reads, so a persistent accumulator is all-zero again (needs O == Opad, I == Ipad
+ * or a caller that tolerates the untouched pad rows staying zero -- wgrad only ever adds zeros there). */
+int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src,
+                     aod_stream_t stream);
 
 /* ------------------------------------------------------------------ layout / elementwise
  * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the
