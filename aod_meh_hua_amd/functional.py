@@ -134,7 +134,14 @@ class ConvFn(Function):
             for g, s in zip(gouts, y_segs):
                 parts.append(as_rows(g) if g is not None else torch.zeros(s.rows, O, device=w.device, dtype=torch.bfloat16))
             dt = torch.float32 if any(p.dtype == torch.float32 for p in parts) else torch.bfloat16
-            g_rows = torch.cat([p.to(dt) for p in parts])
+            # the level gradients usually ARE adjacent slices of one buffer (the dX of the next tower conv): view, don't copy
+            rb = O * parts[0].element_size()
+            adjacent = all(p.dtype == dt and p.is_contiguous() for p in parts) and all(
+                parts[i + 1].data_ptr() == parts[i].data_ptr() + parts[i].shape[0] * rb for i in range(len(parts) - 1))
+            if adjacent:
+                g_rows = torch.as_strided(parts[0], (sum(p.shape[0] for p in parts), O), (O, 1))
+            else:
+                g_rows = torch.cat([p.to(dt) for p in parts])
         dsegs = dense_segs(y_segs)
         Opad = (O + 7) // 8 * 8
         need_w = ctx.needs_input_grad[1]

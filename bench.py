@@ -112,7 +112,7 @@ def main():
         have_scoring = False
         do_score = False
 
-    def step(it=0):
+    def step(it=0, do_train=do_train, do_score=do_score):
         if do_train:
             model.train()
             out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
@@ -157,6 +157,21 @@ def main():
     imgs_per_step = B * world * phases
     value = imgs_per_step * args.steps / dt
 
+    # ---- per-phase rates (outside the timed region; SURVEY 8d reports train / score separately beside the combined rate)
+    phase = {}
+    for name, tr_, sc_ in (('train', True, False), ('score', False, True)):
+        if (tr_ and not do_train) or (sc_ and not do_score):
+            continue
+        k = max(3, min(args.steps, 10))
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(k):
+            step(args.warmup + args.steps + i, tr_, sc_)
+        barrier()
+        d = time.perf_counter() - t1
+        phase[name + '_img_per_s'] = round(B * world * k / d, 1)
+        phase[name + '_ms_per_batch'] = round(d / k * 1e3, 3)
+
     # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv launch
     roof = None
     if rank == 0:
@@ -190,7 +205,7 @@ def main():
                                                       + (['HUA scoring pass'] if do_score else [])),
                                 global_batch=B * world, image_size=H, num_classes=20, anchors_per_image=49104 if H == 512 else None,
                                 parallelism=f'dp{world}', phases=args.mode if (do_score or not have_scoring) else 'train'),
-                    roofline=roof, cpu_baseline=cpu)
+                    phase_rates=phase, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
