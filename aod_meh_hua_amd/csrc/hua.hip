@@ -27,6 +27,8 @@ struct HuaArgs {
   float obj_score_thr, obj_iou_thr, fg_thr;
   int num_samples; unsigned seed_lo, seed_hi;
   int agg_class, agg_scale, agg_obj, clsW;
+  int scale_mode;   // 1: Entropy_ALL / ComputeScaleUnc (Lambda_L2.py:539-569): every foreground anchor is a pair of ONE pseudo object,
+                    //    lambda mean over ALL anchors of the (image, level); dets / num_det / boxes are not read
   float* unc; float* pair_out; int max_pairs; int* pair_count;
   // workspace
   int* pair_cand; int* pair_obj; float* pair_epi; float* pair_ale; int* lvl_pair_start; float* lam_mean; int* nobj;
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
   const float* bx = p.boxes + (long long)b * p.n * 4;
   const float* sc = p.scores + (long long)b * p.n * (p.C + 1);
   const float* dt = p.dets + (long long)b * p.max_num * 5;
-  if (t == 0) {
+  if (t == 0 && p.scale_mode) { s_no = 1; p.nobj[b] = 1; }
+  if (t == 0 && !p.scale_mode) {
     int no = 0;
     const int nd = min(p.num_det[b], p.max_num);
     for (int j = 0; j < nd; ++j)
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
         for (int c = 0; c < p.C; ++c) ms = fmaxf(ms, sc[(long long)i * (p.C + 1) + c]);
         fg = ms > p.fg_thr;
       }
-      if (fg) {
+      if (fg && p.scale_mode) { m0 = 1ull; cnt = 1; }
+      else if (fg) {
         float q[4];
         for (int u = 0; u < 4; ++u) q[u] = bx[(long long)i * 4 + u];
         const float aq = (q[2] - q[0]) * (q[3] - q[1]);
@@ -131,8 +135,14 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
     for (int l = 0; l <= t; ++l) { s = acc; acc += s_lvl[l + 1]; e = acc; }
     s = min(s, p.max_pairs); e = min(e, p.max_pairs);
     float sum = 0.f;
-    for (int k = s; k < e; ++k) sum += p.lam[(long long)b * p.n + pc[k]];
-    p.lam_mean[b * HMAXL + t] = e > s ? sum / (float)(e - s) : 0.f;
+    if (p.scale_mode) {      // l_scores.mean() over every anchor of the level (:551-553)
+      const int c0 = p.level_start[t], c1 = p.level_start[t + 1];
+      for (int k = c0; k < c1; ++k) sum += p.lam[(long long)b * p.n + k];
+      p.lam_mean[b * HMAXL + t] = c1 > c0 ? sum / (float)(c1 - c0) : 0.f;
+    } else {
+      for (int k = s; k < e; ++k) sum += p.lam[(long long)b * p.n + pc[k]];
+      p.lam_mean[b * HMAXL + t] = e > s ? sum / (float)(e - s) : 0.f;
+    }
   }
 }
 
@@ -306,11 +316,11 @@ extern "C" size_t aod_hua_ws_bytes(int B, int max_pairs) {
 extern "C" int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor, const float* dets,
                              const int32_t* num_det, const int32_t* level_start_host, const int32_t* level_any_fg, const int64_t* image_ids,
                              int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr, float fg_thr, int num_samples,
-                             uint64_t seed, const int32_t* agg3_host, int clsW, float* unc, float* pair_out, int max_pairs,
+                             uint64_t seed, const int32_t* agg3_host, int clsW, int scale_mode, float* unc, float* pair_out, int max_pairs,
                              int32_t* pair_count, void* ws, aod_stream_t stream) {
   if (B == 0) return 0;
-  AOD_CHECK_ARG(boxes && scores && lam && cand_anchor && dets && num_det && level_start_host && level_any_fg && image_ids && unc && pair_count && ws,
-                "hua: null pointer");
+  AOD_CHECK_ARG(scores && lam && cand_anchor && level_start_host && level_any_fg && image_ids && unc && pair_count && ws, "hua: null pointer");
+  AOD_CHECK_ARG(scale_mode || (boxes && dets && num_det), "hua: object mode needs boxes / dets / num_det");
   AOD_CHECK_ARG(L >= 1 && L <= HMAXL && C >= 1 && C <= HMAXC && max_num <= HMAXO && num_samples >= 1 && num_samples <= 8192 && max_pairs >= 1,
                 "hua: L<=8, C<=96, max_num<=128, samples<=8192 required");
   HuaArgs p;
@@ -320,7 +330,7 @@ extern "C" int aod_hua_score(const float* boxes, const float* scores, const floa
   AOD_CHECK_ARG(p.level_start[0] == 0 && p.level_start[L] == n, "hua: level_start must cover [0, n)");
   p.obj_score_thr = obj_score_thr; p.obj_iou_thr = obj_iou_thr; p.fg_thr = fg_thr; p.num_samples = num_samples;
   p.seed_lo = (unsigned)(seed & 0xffffffffull); p.seed_hi = (unsigned)(seed >> 32);
-  p.agg_class = agg3_host ? agg3_host[0] : 0; p.agg_scale = agg3_host ? agg3_host[1] : 2; p.agg_obj = agg3_host ? agg3_host[2] : 0; p.clsW = clsW;
+  p.agg_class = agg3_host ? agg3_host[0] : 0; p.agg_scale = agg3_host ? agg3_host[1] : 2; p.agg_obj = agg3_host ? agg3_host[2] : 0; p.clsW = clsW; p.scale_mode = scale_mode;
   p.unc = unc; p.pair_out = pair_out; p.max_pairs = max_pairs; p.pair_count = pair_count;
   char* w = (char*)ws;
   p.pair_cand = (int*)w; w += (size_t)B * max_pairs * 4;

@@ -167,7 +167,7 @@ struct GatherArgs {
   const float* img_hw; const float* scale4;
   float means[4], stds[4]; float max_ratio;
   float* boxes; float* scores; float* lam; int* cand_anchor;
-  long long n_total; long long cand0; long long anchor0;
+  long long n_total; long long cand0; long long anchor0; int normalize;
 };
 __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) {
   const int b = blockIdx.y;
@@ -178,6 +178,13 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) 
   float x[MAXC], s[MAXC], ma, ms;
   for (int c = 0; c < p.C; ++c) x[c] = p.cls[row * p.C + c];
   row_scores(x, p.C, s, ma, ms);
+  if (!p.normalize) {   // raw softmax: undo nothing, recompute without the (S + 1e-20 + 1e-9) division
+    float m = x[0];
+    for (int c = 1; c < p.C; ++c) m = fmaxf(m, x[c]);
+    float sum = 0.f;
+    for (int c = 0; c < p.C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
+    for (int c = 0; c < p.C; ++c) s[c] = s[c] / sum;
+  }
   const long long o = (long long)b * p.n_total + p.cand0 + j;
   for (int c = 0; c < p.C; ++c) p.scores[o * (p.C + 1) + c] = s[c];
   p.scores[o * (p.C + 1) + p.C] = 0.f;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) 
 extern "C" int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
                                  int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
                                  const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
-                                 int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, aod_stream_t stream) {
+                                 int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, int normalize, aod_stream_t stream) {
   if (B == 0 || k == 0) return 0;
   AOD_CHECK_ARG(cls && reg && lam_map && anchors && img_hw && boxes && scores && lam && cand_anchor && C <= MAXC, "gather_decode: bad args");
   GatherArgs p;
@@ -216,7 +223,7 @@ extern "C" int aod_gather_decode(const float* cls, const float* reg, const float
   p.img_hw = img_hw; p.scale4 = scale4;
   for (int i = 0; i < 4; ++i) { p.means[i] = means4 ? means4[i] : 0.f; p.stds[i] = stds4 ? stds4[i] : 1.f; }
   p.max_ratio = fabsf(logf(wh_ratio_clip));
-  p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.n_total = n_total; p.cand0 = cand0; p.anchor0 = anchor0;
+  p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.n_total = n_total; p.cand0 = cand0; p.anchor0 = anchor0; p.normalize = normalize;
   hipLaunchKernelGGL(gather_decode_kernel, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;

@@ -49,7 +49,7 @@ class Candidates:
 
 
 def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors, nms_pre, C_, means, stds, rescale=True,
-            fg_thr=0.3, wh_ratio_clip=16 / 1000):
+            fg_thr=0.3, wh_ratio_clip=16 / 1000, normalize=True):
     dev = mlvl_cls[0].device
     B = mlvl_cls[0].shape[0]
     L = len(mlvl_cls)
@@ -78,7 +78,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
         idxs.append(idx)
         call('aod_gather_decode', ptr(cls[l]), ptr(reg[l]), ptr(lam[l]), ptr(mlvl_anchors[l].contiguous()), ptr(idx), B, A[l], ks[l], C_,
              ks[l], ptr(img_hw), ptr(sc4), _F4(*means), _F4(*stds), float(wh_ratio_clip), ptr(boxes), ptr(scores), ptr(lam_o),
-             ptr(cand_anchor), n, c0, a0, stream())
+             ptr(cand_anchor), n, c0, a0, int(bool(normalize)), stream())
         c0 += ks[l]
         a0 += A[l]
         level_start.append(c0)
@@ -99,18 +99,19 @@ def multiclass_nms_batch(boxes, scores, score_thr, iou_thr, max_num):
 
 
 def hua_score(cand, dets, num_det, image_ids, max_num, agg=(0, 2, 0), clsW=False, num_samples=500, seed=20, obj_score_thr=0.3,
-              obj_iou_thr=0.5, fg_thr=0.3, want_pairs=False, max_pairs=None):
+              obj_iou_thr=0.5, fg_thr=0.3, want_pairs=False, max_pairs=None, scale_mode=False):
     B, n, C1 = cand.scores.shape
     dev = cand.boxes.device
     L = len(cand.level_start) - 1
-    max_pairs = max_pairs or n * max_num
+    max_pairs = max_pairs or (n if scale_mode else n * max_num)
     unc = torch.empty(B, device=dev)
     pair_count = torch.empty(B, dtype=torch.int32, device=dev)
     pair_out = torch.zeros(B, max_pairs, 4, device=dev) if want_pairs else None
     ws = torch.empty(int(_C.lib.aod_hua_ws_bytes(B, max_pairs)), dtype=torch.uint8, device=dev)
     call('aod_hua_score', ptr(cand.boxes), ptr(cand.scores), ptr(cand.lam), ptr(cand.cand_anchor), ptr(dets), ptr(num_det),
          (C.c_int32 * (L + 1))(*cand.level_start), ptr(cand.any_fg), ptr(image_ids), B, n, L, C1 - 1, int(max_num), float(obj_score_thr),
-         float(obj_iou_thr), float(fg_thr), int(num_samples), int(seed), (C.c_int32 * 3)(*agg), int(bool(clsW)), ptr(unc), ptr(pair_out),
+         float(obj_iou_thr), float(fg_thr), int(num_samples), int(seed), (C.c_int32 * 3)(*agg), int(bool(clsW)), int(bool(scale_mode)),
+         ptr(unc), ptr(pair_out),
          int(max_pairs), ptr(pair_count), ptr(ws), stream())
     return (unc, pair_count, pair_out) if want_pairs else unc
 
@@ -125,8 +126,23 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
     C_ = head.cls_out_channels
     isUnc = kwargs.get('isUnc')
     uPool = kwargs.get('uPool')
-    if isUnc and uPool in ('Entropy_ALL', 'Entropy_NoNMS'):
-        raise NotImplementedError(f'uncertainty_pool={uPool} is a "next" row (SURVEY 8f rank 4); Entropy_NMS is built')
+    if isUnc and uPool == 'Entropy_NoNMS':
+        raise NotImplementedError('uncertainty_pool=Entropy_NoNMS is a "next" row (SURVEY 8f rank 4)')
+    if isUnc and uPool == 'Entropy_ALL':
+        # Lambda_L2.py:281-283 (no top-k), :354 (no NMS), :364-365 ComputeScaleUnc + AggregateScaleUnc
+        cand = pre_nms(mlvl_cls_scores, mlvl_bbox_preds, kwargs['L_scores'], mlvl_anchors, img_shapes, scale_factors, -1, C_,
+                       head.bbox_coder.means, head.bbox_coder.stds, rescale=rescale, normalize=False)
+        B = cand.boxes.shape[0]
+        image_ids = kwargs.get('image_ids')
+        if image_ids is None:
+            image_ids = torch.arange(B, device=cand.boxes.device, dtype=torch.int64) + int(kwargs.get('batchIdx', 0)) * B
+        cls_code, scale_code, _ = extract_agg_codes(kwargs['uPool2'] if 'object' in kwargs['uPool2'] else 'objectSum_' + kwargs['uPool2'])
+        unc = hua_score(cand, None, None, image_ids.to(torch.int64).contiguous(), 1, (cls_code, scale_code, 0), False,
+                        seed=kwargs.get('hua_seed', 20), scale_mode=True)
+        det_results = [(cand.boxes[b], cand.scores[b]) for b in range(B)]
+        if kwargs.get('_return_internals'):
+            return det_results, unc, dict(cand=cand)
+        return det_results, unc
     L_scores = kwargs.get('L_scores')
     if L_scores is None:   # plain detection: lambda is not needed, reuse zeros
         L_scores = [torch.zeros(c.shape[0], head.num_anchors, c.shape[2], c.shape[3], device=c.device).contiguous(memory_format=torch.channels_last)

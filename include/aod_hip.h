@@ -167,11 +167,11 @@ int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, i
  * delta_xywh_bbox_coder.py:144-262): for candidate j (anchor idx[b][j], or j itself when idx == NULL):
  * boxes [B, n_total, 4] (clipped to img_hw[b] = (H, W), divided by scale4[b] when given), scores [B, n_total, C+1]
  * (normalised softmax + zero background column), lam [B, n_total], cand_anchor [B, n_total] = anchor0 + anchor index,
- * written at candidate offset cand0. */
+ * written at candidate offset cand0.  normalize = 0 keeps the raw softmax (Entropy_ALL). */
 int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
                       int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
                       const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
-                      int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, aod_stream_t stream);
+                      int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, int normalize, aod_stream_t stream);
 /* multiclass_nms (core/post_processing/bbox_nms.py:7-93 -> mmcv batched_nms / nms_cpu semantics, both its <10000 and
  * per-class paths reduce to this class-aware greedy scan).  boxes [B,n,4], scores [B,n,C+1]; outputs dets [B,max_num,5],
  * det_labels [B,max_num] int64, keep [B,max_num] int64 (index into the score>thr list; -1 padded), num_det [B] int32. */
@@ -187,13 +187,15 @@ int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, in
  * level_start_host[L+1]: candidate offsets of the concatenated levels (HOST array); level_any_fg [L][B] int32;
  * cand_anchor [B,n] global anchor id and image_ids [B] int64 key the counter RNG (partition invariant);
  * agg3_host = (class, scale, object) codes 0 Sum / 1 Avg / 2 Max (HOST array; NULL = Sum/Max/Sum).
+ * scale_mode = 1: Entropy_ALL / ComputeScaleUnc + AggregateScaleUnc (Lambda_L2.py:539-569,636-691): every candidate whose max
+ * score exceeds fg_thr is a pair of one pseudo object, lambda mean over ALL candidates of the level, scores = raw softmax.
  * pair_out (optional, [B, max_pairs, 4] f32: cand, obj, aleatoric, epistemic); pair_count [B] int32 (may exceed
  * max_pairs: then the excess pairs were dropped and the caller must retry with a larger workspace). */
 size_t aod_hua_ws_bytes(int B, int max_pairs);
 int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor,
                   const float* dets, const int32_t* num_det, const int32_t* level_start_host, const int32_t* level_any_fg,
                   const int64_t* image_ids, int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr,
-                  float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3_host, int clsW,
+                  float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3_host, int clsW, int scale_mode,
                   float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer (K16)

@@ -220,3 +220,48 @@ def aggregate_obj_scale_unc(bins, type_str='objectSum_scaleMax_classSum', clsW=F
             v *= len(seen)
         out.append(v)
     return out
+
+
+# --------------------------------------------------------------- ComputeScaleUnc / AggregateScaleUnc (Entropy_ALL)
+def compute_scale_unc(mlvl_alphas, mlvl_lam, sampler='torch', seed=20, image_ids=None, level_offsets=None, num_samples=NUM_SAMPLES):
+    """Lambda_L2Net.ComputeScaleUnc (Lambda_L2.py:539-569).  mlvl_alphas[l] [B, A_l, C] = softmax(cls) (NOT renormalised),
+    mlvl_lam[l] [B, A_l].  Returns bins[b][level] = {cls: epi_mean}."""
+    S, B = len(mlvl_alphas), mlvl_alphas[0].shape[0]
+    bins = [[{} for _ in range(S)] for _ in range(B)]
+    for s in range(S):
+        for b in range(B):
+            alphas = mlvl_alphas[s][b]
+            fg = alphas.max(dim=1)[0] > 0.3
+            if not bool(fg.any()):
+                continue
+            l = mlvl_lam[s][b].reshape(-1, 1)
+            lhat = l.mean() / (l + 1e-7) * 25
+            a = (alphas * lhat)[fg]
+            idx = fg.nonzero()[:, 0]
+            if sampler == 'torch':
+                smp = torch.distributions.Dirichlet(a).sample(torch.tensor([num_samples]))
+                avg = smp.mean(dim=0)
+                epi = (-avg * avg.log()).sum(dim=1) - (-smp * smp.log()).sum(dim=-1).mean(dim=0)
+            elif sampler == 'philox':
+                img = b if image_ids is None else int(image_ids[b])
+                off = 0 if level_offsets is None else int(level_offsets[s])
+                _, e = philox_dirichlet_stats(a.numpy(), img, idx.numpy() + off, np.zeros(len(idx), np.int64), seed, num_samples)
+                epi = torch.from_numpy(e)
+            else:
+                epi = torch.from_numpy(epistemic_closed_form(a.numpy()).astype(np.float32))
+            cls = a.argmax(dim=1)
+            for c in cls.unique():
+                bins[b][s][int(c)] = float(epi[cls == c].mean())
+    return bins
+
+
+def aggregate_scale_unc(bins, type_str='scaleAvg_classAvg'):
+    """Lambda_L2Net.AggregateScaleUnc (Lambda_L2.py:636-691): type in scale{Avg,Sum}_class{Avg,Sum}."""
+    f = extract_agg_func(type_str)
+    out = []
+    for img in bins:
+        per_level = [f['class'](list(lvl.values())) for lvl in img if lvl]
+        if type_str == 'scaleSum_classSum':       # the reference flattens all bins for this one (same value)
+            per_level = [v for lvl in img for v in lvl.values()]
+        out.append(f['scale'](per_level) if per_level else 0)
+    return out

@@ -187,3 +187,36 @@ def test_nms_many_candidates_path(run):
     # nothing above the threshold
     d, lab, keep, num = sc.multiclass_nms_batch(boxes.cuda(), torch.zeros_like(scores).cuda(), 0.05, 0.5, 100)
     assert int(num[0]) == 0
+
+
+def test_entropy_all_mode_vs_oracle_and_reference():
+    """uncertainty_pool='Entropy_ALL' (every foreground anchor, no top-k / NMS): kernel vs Philox oracle (values) and
+    vs the reference's 12 reseeded MC runs (statistics)."""
+    from aod_meh_hua_amd import scoring
+    from aod_meh_hua_amd.core.anchor import AnchorGenerator
+    from aod_meh_hua_amd.core.bbox import DeltaXYWHBBoxCoder
+    from oracle import model as om
+
+    class Head:
+        last_activation, cls_out_channels, num_anchors = 'relu', 20, 9
+        bbox_coder = DeltaXYWHBBoxCoder()
+    g = np.load(os.path.join(G, 'scoring_all.npz'))
+    cls_p, reg_p, L_p = synth.planted_heads(2, 128, 128)
+    mt = synth.metas(2, 128, 128, scale=1.25)
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    anchors = ag.grid_anchors([tuple(c.shape[-2:]) for c in cls_p], 'cuda')
+    cfg = Cfg(nms_pre=1000, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    alphas = [om.nhwc_flat(c, 20).softmax(dim=2) for c in cls_p]
+    lam = [om.nhwc_flat(l, 1)[..., 0] for l in L_p]
+    offs = np.concatenate([[0], np.cumsum([a.shape[1] for a in alphas])[:-1]])
+    obins = ohua.compute_scale_unc(alphas, lam, sampler='philox', seed=20, level_offsets=offs)
+    umu, usd = g['unc_runs'].mean(0), g['unc_runs'].std(0)
+    for mode in ('scaleAvg_classAvg', 'scaleSum_classSum', 'scaleSum_classAvg', 'scaleAvg_classSum'):
+        det, unc = scoring.score_batch(Head(), [c.cuda() for c in cls_p], [r.cuda() for r in reg_p], anchors, [m['img_shape'] for m in mt],
+                                       [m['scale_factor'] for m in mt], cfg, rescale=True, with_nms=False, isUnc='Epistemic',
+                                       uPool='Entropy_ALL', uPool2=mode, isEval=False, L_scores=[l.cuda() for l in L_p], batchIdx=0)
+        u = unc.cpu().numpy()
+        assert np.allclose(u, ohua.aggregate_scale_unc(obins, mode), rtol=2e-3), (mode, u)
+        if mode == 'scaleAvg_classAvg':
+            assert (np.abs(u - umu) <= 5 * usd + 0.02 * umu).all(), (u, umu, usd)
+    assert det[0][0].shape == (3069, 4) and det[0][1].shape == (3069, 21)

@@ -235,6 +235,35 @@ save('scoring', unc_runs=np.array(uncs), bin_keys=np.array(keys), bin_vals=bin_v
 head.ComputeObjUnc = orig_cou
 L2mod.multiclass_nms = orig_nms
 
+# ---------------------------------------------------------------- Entropy_ALL (ComputeScaleUnc / AggregateScaleUnc) on planted logits
+cap2 = {}
+orig_csu = head.ComputeScaleUnc
+
+
+def spy2(mlvl_cls_scores, L_scores):
+    o = orig_csu(mlvl_cls_scores, L_scores)
+    cap2['bins'] = o
+    return o
+
+
+head.ComputeScaleUnc = spy2
+kw_all = dict(kw, uPool='Entropy_ALL', uPool2='scaleAvg_classAvg', with_nms=False)
+runs, binruns = [], []
+with torch.no_grad():
+    for seed in range(12):
+        torch.manual_seed(seed)
+        _, unc_all = head.get_bboxes(cls_p, reg_p, mt, L_scores=L_p, **kw_all)
+        runs.append(unc_all)
+        binruns.append({(b, s, int(c)): float(v[1]) for b, img_b in enumerate(cap2['bins']) for s, d in enumerate(img_b) for c, v in d.items()})
+keys2 = sorted(binruns[0].keys())
+assert all(sorted(r.keys()) == keys2 for r in binruns)
+with torch.no_grad():
+    torch.manual_seed(0)
+    _, unc_ss = head.get_bboxes(cls_p, reg_p, mt, L_scores=L_p, **dict(kw_all, uPool2='scaleSum_classSum'))
+save('scoring_all', unc_runs=np.array(runs, dtype=np.float64), bin_keys=np.array(keys2), bin_vals=np.array([[r[k] for k in keys2] for r in binruns]),
+     unc_sumsum_seed0=np.array(unc_ss, dtype=np.float64))
+head.ComputeScaleUnc = orig_csu
+
 # ---------------------------------------------------------------- selection rule
 rng_unc = np.random.RandomState(5)
 unc = rng_unc.rand(400) * (rng_unc.rand(400) > 0.4)
