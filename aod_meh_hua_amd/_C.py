@@ -57,13 +57,19 @@ _SIGS = {
     'aod_edl_focal_l1_bwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, F32, P, P, I32, I32, I32, I32, P]),
     'aod_meh_loss_fwd': (C.c_int, [P, P, P, I64, P, P, P]),
     'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
-    'aod_softmax_rowmax': (C.c_int, [P, I32, I64, I32, F32, P, P, P]),
+    'aod_softmax_rowmax': (C.c_int, [P, I32, I64, I32, F32, P, P, I32, P]),
     'aod_topk_stable': (C.c_int, [P, I32, I64, I32, P, I64, P]),
     'aod_gather_decode': (C.c_int, [P, P, P, P, P, I32, I64, I32, I32, I64, P, P, P, P, F32, P, P, P, P, I64, I64, I64, I32, P]),
     'aod_nms_ws_bytes': (SZ, [I32, I32, I32]),
     'aod_multiclass_nms': (C.c_int, [P, P, I32, I32, I32, F32, F32, I32, P, P, P, P, P, P]),
     'aod_hua_ws_bytes': (SZ, [I32, I32]),
-    'aod_hua_score': (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32, I32, U64, P, I32, I32, P, P, I32, P, P, P]),
+    'aod_hua_score': (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, F32, I32, U64, P, I32, I32, I32, P, P, I32, P, P, P]),
+    'aod_maxpool_fwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    'aod_maxpool_bwd': (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    'aod_l2norm_fwd': (C.c_int, [P, P, P, I64, I32, F32, P]),
+    'aod_l2norm_bwd': (C.c_int, [P, P, P, P, P, I64, I32, F32, P]),
+    'aod_ssd_loss_fwd': (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P, P]),
+    'aod_ssd_loss_bwd': (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, P, P, P, P, P, P]),
     'aod_sgd_multi': (C.c_int, [P, P, P, P, I32, F32, F32, F32, I32, F32, P]),
 }
 for _n, (_r, _a) in _SIGS.items():

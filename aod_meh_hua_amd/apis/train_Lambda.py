@@ -28,11 +28,13 @@ def train_detector_SSL(model, dataset, cfg, distributed=False, validate=False, t
     model = MMDataParallel(model.to(dev), device_ids=cfg.gpu_ids)
     broadcast_model(model.module)
     optimizer = build_optimizer(model, cfg.optimizer)
-    RemoveParamFromOptim(optimizer, model.module, 'retina_L')
-    RemoveParamFromOptim(optimizer, model.module, 'L_convs')
-    runner = build_runner(cfg.runner, default_args=dict(model=model, optimizer=optimizer, work_dir=cfg.work_dir, logger=logger, meta=meta))
     head = model.module.bbox_head
-    runner.optimizer_L = FusedSGD(list(head.retina_L.parameters()) + list(head.L_convs.parameters()), lr=cfg.optimizer.lr,
+    meh_names = getattr(head, 'L_names', ['retina_L', 'L_convs'])      # train_Lambda.py:55-56 / train_SSD_L.py:42
+    for name in meh_names:
+        RemoveParamFromOptim(optimizer, model.module, name)
+    runner = build_runner(cfg.runner, default_args=dict(model=model, optimizer=optimizer, work_dir=cfg.work_dir, logger=logger, meta=meta))
+    meh_params = [p for n in meh_names for p in getattr(head, n).parameters()]
+    runner.optimizer_L = FusedSGD(meh_params, lr=cfg.optimizer.lr,
                                   momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay)
     runner.timestamp = timestamp
     runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.checkpoint_config, cfg.log_config, cfg.get('momentum_config', None))

@@ -17,7 +17,7 @@
 #define ONE_MINUS_EPS 0.99999988079071044921875f
 constexpr int HMAXC = 96;
 constexpr int HMAXL = 8;
-constexpr int HMAXO = 128;
+constexpr int HMAXO = 256;
 
 struct HuaArgs {
   const float* boxes; const float* scores; const float* lam; const int* cand_anchor;
@@ -27,6 +27,7 @@ struct HuaArgs {
   float obj_score_thr, obj_iou_thr, fg_thr;
   int num_samples; unsigned seed_lo, seed_hi;
   int agg_class, agg_scale, agg_obj, clsW;
+  int nd;           // Dirichlet columns: C (evidence head, zero-padded bg column) or C+1 (SSD softmax incl. background)
   int scale_mode;   // 1: Entropy_ALL / ComputeScaleUnc (Lambda_L2.py:539-569): every foreground anchor is a pair of ONE pseudo object,
                     //    lambda mean over ALL anchors of the (image, level); dets / num_det / boxes are not read
   float* unc; float* pair_out; int max_pairs; int* pair_count;
@@ -80,24 +81,24 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
   for (int c0 = 0; c0 < p.n; c0 += 1024) {
     const int i = c0 + t;
     int cnt = 0;
-    unsigned long long m0 = 0ull, m1 = 0ull;
+    unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
     int lvl = 0;
     if (i < p.n && no > 0) {
       lvl = level_of(p, i);
       bool fg = p.any_fg[lvl * p.B + b] != 0;
       if (fg) {
         float ms = 0.f;
-        for (int c = 0; c < p.C; ++c) ms = fmaxf(ms, sc[(long long)i * (p.C + 1) + c]);
+        for (int c = 0; c <= p.C; ++c) ms = fmaxf(ms, sc[(long long)i * (p.C + 1) + c]);   // SSD quirk: max incl. the bg column (0 for RetinaNet)
         fg = ms > p.fg_thr;
       }
-      if (fg && p.scale_mode) { m0 = 1ull; cnt = 1; }
+      if (fg && p.scale_mode) { mk[0] = 1ull; cnt = 1; }
       else if (fg) {
         float q[4];
         for (int u = 0; u < 4; ++u) q[u] = bx[(long long)i * 4 + u];
         const float aq = (q[2] - q[0]) * (q[3] - q[1]);
         for (int o = 0; o < no; ++o)
           if (iou_cd(q, aq, obox[o], obox[o][4]) > p.obj_iou_thr) {
-            if (o < 64) m0 |= 1ull << o; else m1 |= 1ull << (o - 64);
+            mk[o >> 6] |= 1ull << (o & 63);
             ++cnt;
           }
       }
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
     if (cnt) {
       atomicAdd(&s_lvl[lvl + 1], cnt);
       for (int o = 0; o < no; ++o) {
-        const bool hit = o < 64 ? ((m0 >> o) & 1ull) : ((m1 >> (o - 64)) & 1ull);
+        const bool hit = (mk[o >> 6] >> (o & 63)) & 1ull;
         if (hit) { if (pos < p.max_pairs) { pc[pos] = i; po[pos] = o; } ++pos; }
       }
     }
@@ -185,7 +186,7 @@ __device__ __forceinline__ float gamma_philox(float alpha, unsigned c1, unsigned
 template <int CT>
 __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
   constexpr int CA = CT ? CT : HMAXC;
-  const int C = CT ? CT : p.C;
+  const int C = CT ? CT : p.nd;
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int np = min(p.pair_count[b], p.max_pairs);
@@ -267,19 +268,19 @@ __global__ __launch_bounds__(1024) void hua_reduce_kernel(const HuaArgs p) {
     const int s = p.lvl_pair_start[b * (HMAXL + 1) + l], e = p.lvl_pair_start[b * (HMAXL + 1) + l + 1];
     float sum[HMAXC];
     int cnt[HMAXC];
-    for (int c = 0; c < p.C; ++c) { sum[c] = 0.f; cnt[c] = 0; }
+    for (int c = 0; c < p.nd; ++c) { sum[c] = 0.f; cnt[c] = 0; }
     for (int k = s; k < e; ++k)
       if (po[k] == o) {
         const float* r = sc + (long long)pc[k] * (p.C + 1);
         int am = 0;
         float mv = r[0];
-        for (int c = 1; c < p.C; ++c) if (r[c] > mv) { mv = r[c]; am = c; }   // first max (torch.argmax on CPU)
+        for (int c = 1; c < p.nd; ++c) if (r[c] > mv) { mv = r[c]; am = c; }   // first max (torch.argmax on CPU)
         sum[am] += pe[k];
         ++cnt[am];
       }
     float acc = 0.f;
     int n = 0;
-    for (int c = 0; c < p.C; ++c)
+    for (int c = 0; c < p.nd; ++c)
       if (cnt[c]) {
         acc = agg_fold(p.agg_class, acc, sum[c] / (float)cnt[c], n);
         ++n;
@@ -316,13 +317,13 @@ extern "C" size_t aod_hua_ws_bytes(int B, int max_pairs) {
 extern "C" int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor, const float* dets,
                              const int32_t* num_det, const int32_t* level_start_host, const int32_t* level_any_fg, const int64_t* image_ids,
                              int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr, float fg_thr, int num_samples,
-                             uint64_t seed, const int32_t* agg3_host, int clsW, int scale_mode, float* unc, float* pair_out, int max_pairs,
+                             uint64_t seed, const int32_t* agg3_host, int clsW, int scale_mode, int dirichlet_cols, float* unc, float* pair_out, int max_pairs,
                              int32_t* pair_count, void* ws, aod_stream_t stream) {
   if (B == 0) return 0;
   AOD_CHECK_ARG(scores && lam && cand_anchor && level_start_host && level_any_fg && image_ids && unc && pair_count && ws, "hua: null pointer");
   AOD_CHECK_ARG(scale_mode || (boxes && dets && num_det), "hua: object mode needs boxes / dets / num_det");
   AOD_CHECK_ARG(L >= 1 && L <= HMAXL && C >= 1 && C <= HMAXC && max_num <= HMAXO && num_samples >= 1 && num_samples <= 8192 && max_pairs >= 1,
-                "hua: L<=8, C<=96, max_num<=128, samples<=8192 required");
+                "hua: L<=8, C<=96, max_num<=256, samples<=8192 required");
   HuaArgs p;
   p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.dets = dets; p.num_det = num_det; p.any_fg = level_any_fg;
   p.image_ids = (const long long*)image_ids; p.B = B; p.n = n; p.L = L; p.C = C; p.max_num = max_num;
@@ -330,7 +331,8 @@ extern "C" int aod_hua_score(const float* boxes, const float* scores, const floa
   AOD_CHECK_ARG(p.level_start[0] == 0 && p.level_start[L] == n, "hua: level_start must cover [0, n)");
   p.obj_score_thr = obj_score_thr; p.obj_iou_thr = obj_iou_thr; p.fg_thr = fg_thr; p.num_samples = num_samples;
   p.seed_lo = (unsigned)(seed & 0xffffffffull); p.seed_hi = (unsigned)(seed >> 32);
-  p.agg_class = agg3_host ? agg3_host[0] : 0; p.agg_scale = agg3_host ? agg3_host[1] : 2; p.agg_obj = agg3_host ? agg3_host[2] : 0; p.clsW = clsW; p.scale_mode = scale_mode;
+  p.agg_class = agg3_host ? agg3_host[0] : 0; p.agg_scale = agg3_host ? agg3_host[1] : 2; p.agg_obj = agg3_host ? agg3_host[2] : 0; p.clsW = clsW; p.scale_mode = scale_mode; p.nd = dirichlet_cols > 0 ? dirichlet_cols : C;
+  AOD_CHECK_ARG(p.nd == C || p.nd == C + 1, "hua: dirichlet_cols must be C or C+1");
   p.unc = unc; p.pair_out = pair_out; p.max_pairs = max_pairs; p.pair_count = pair_count;
   char* w = (char*)ws;
   p.pair_cand = (int*)w; w += (size_t)B * max_pairs * 4;
@@ -343,8 +345,8 @@ extern "C" int aod_hua_score(const float* boxes, const float* scores, const floa
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(hua_pairs_kernel, dim3(B), dim3(1024), 0, st, p);
   const int gx = (max_pairs + 3) / 4 < 256 ? (max_pairs + 3) / 4 : 256;
-  if (C == 20) hipLaunchKernelGGL((hua_sample_kernel<20>), dim3(gx, B), dim3(256), 0, st, p);
-  else if (C == 21) hipLaunchKernelGGL((hua_sample_kernel<21>), dim3(gx, B), dim3(256), 0, st, p);
+  if (p.nd == 20) hipLaunchKernelGGL((hua_sample_kernel<20>), dim3(gx, B), dim3(256), 0, st, p);
+  else if (p.nd == 21) hipLaunchKernelGGL((hua_sample_kernel<21>), dim3(gx, B), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((hua_sample_kernel<0>), dim3(gx, B), dim3(256), 0, st, p);
   hipLaunchKernelGGL(hua_reduce_kernel, dim3(B), dim3(1024), 0, st, p);
   AOD_LAUNCH_CHECK();

@@ -12,6 +12,17 @@
 
 // ---------------------------------------------------------------- shared row math (bit-identical wherever used)
 // alphas = softmax(x); S = sum(alphas) + 1e-20; scores = alphas / (S + 1e-9)   (Lambda_L2.py:269-273, gamma = 1)
+// has_bg (SSD, My_L_ssd_head.py:331-345): x holds C logits whose LAST column is background; scores = plain softmax over all C,
+// the two maxima are taken over the C-1 foreground columns.
+__device__ __forceinline__ void row_scores_bg(const float* __restrict__ x, int C, float* s, float& max_alpha, float& max_score) {
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
+  max_alpha = 0.f;
+  for (int c = 0; c < C; ++c) { s[c] = s[c] / sum; if (c < C - 1) max_alpha = fmaxf(max_alpha, s[c]); }
+  max_score = max_alpha;
+}
 __device__ __forceinline__ void row_scores(const float* __restrict__ x, int C, float* s, float& max_alpha, float& max_score) {
   float m = x[0];
   for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
@@ -27,7 +38,7 @@ __device__ __forceinline__ void row_scores(const float* __restrict__ x, int C, f
 
 // ---------------------------------------------------------------- S1: row max of normalised scores + level gate
 __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __restrict__ cls, long long rows_per_img, int B, int C,
-                                                             float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg) {
+                                                             float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg, int has_bg) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   const int P = C | 1;
   const int b = blockIdx.y;
@@ -40,7 +51,7 @@ __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __rest
   if ((int)threadIdx.x < nr) {
     float x[MAXC], s[MAXC], ma, ms;
     for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
-    row_scores(x, C, s, ma, ms);
+    if (has_bg) row_scores_bg(x, C, s, ma, ms); else row_scores(x, C, s, ma, ms);
     rowmax[(long long)b * rows_per_img + r0 + threadIdx.x] = ms;
     fg = ma > fg_thr;
   }
@@ -48,12 +59,12 @@ __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __rest
 }
 
 extern "C" int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img, int C, float fg_thr, float* rowmax, int32_t* any_fg,
-                                  aod_stream_t stream) {
+                                  int has_bg, aod_stream_t stream) {
   if (B == 0 || rows_per_img == 0) return 0;
   AOD_CHECK_ARG(cls && rowmax && any_fg && C >= 1 && C <= MAXC, "softmax_rowmax: bad args");
   dim3 grid((unsigned)((rows_per_img + 255) / 256), B);
   hipLaunchKernelGGL(softmax_rowmax_kernel, grid, dim3(256), (size_t)256 * (C | 1) * 4, (hipStream_t)stream, cls, (long long)rows_per_img, B, C,
-                     fg_thr, rowmax, any_fg);
+                     fg_thr, rowmax, any_fg, has_bg);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -177,8 +188,8 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) 
   const long long row = (long long)b * p.A + a;
   float x[MAXC], s[MAXC], ma, ms;
   for (int c = 0; c < p.C; ++c) x[c] = p.cls[row * p.C + c];
-  row_scores(x, p.C, s, ma, ms);
-  if (!p.normalize) {   // raw softmax: undo nothing, recompute without the (S + 1e-20 + 1e-9) division
+  if (p.normalize == 2) row_scores_bg(x, p.C, s, ma, ms); else row_scores(x, p.C, s, ma, ms);
+  if (p.normalize == 0) {   // raw softmax: undo nothing, recompute without the (S + 1e-20 + 1e-9) division
     float m = x[0];
     for (int c = 1; c < p.C; ++c) m = fmaxf(m, x[c]);
     float sum = 0.f;
@@ -186,8 +197,12 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) 
     for (int c = 0; c < p.C; ++c) s[c] = s[c] / sum;
   }
   const long long o = (long long)b * p.n_total + p.cand0 + j;
-  for (int c = 0; c < p.C; ++c) p.scores[o * (p.C + 1) + c] = s[c];
-  p.scores[o * (p.C + 1) + p.C] = 0.f;
+  if (p.normalize == 2) {
+    for (int c = 0; c < p.C; ++c) p.scores[o * p.C + c] = s[c];          // C columns, the last one is the background probability
+  } else {
+    for (int c = 0; c < p.C; ++c) p.scores[o * (p.C + 1) + c] = s[c];
+    p.scores[o * (p.C + 1) + p.C] = 0.f;
+  }
   p.lam[o] = p.lam_map[row];
   p.cand_anchor[o] = (int)(p.anchor0 + a);
   // delta2bbox (delta_xywh_bbox_coder.py:144-262)
@@ -238,9 +253,9 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   __shared__ int hist[256];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[TR];
-  __shared__ float kbox[128][4];
-  __shared__ float karea[128];
-  __shared__ int kcls[128];
+  __shared__ float kbox[256][4];
+  __shared__ float karea[256];
+  __shared__ int kcls[256];
   __shared__ int s_nkept, s_nvalid;
   __shared__ float s_maxc;
   const int b = blockIdx.x;
@@ -384,7 +399,7 @@ extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B
                                   float* dets, int64_t* det_labels, int64_t* keep, int32_t* num_det, void* ws, aod_stream_t stream) {
   if (B == 0) return 0;
   AOD_CHECK_ARG(boxes && scores && dets && det_labels && keep && num_det && ws, "nms: null pointer");
-  AOD_CHECK_ARG(max_num >= 1 && max_num <= 128 && C >= 1, "nms: max_num must be in 1..128");
+  AOD_CHECK_ARG(max_num >= 1 && max_num <= 256 && C >= 1, "nms: max_num must be in 1..256");
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
                      (long long*)det_labels, (long long*)keep, num_det, (int*)ws);
   AOD_LAUNCH_CHECK();

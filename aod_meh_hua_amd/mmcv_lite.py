@@ -519,8 +519,10 @@ class StepLrUpdaterHook(Hook):
     """lr_config=dict(policy='step', step=[...], gamma=0.1) by epoch; touches runner.optimizer only
     (optimizer_L keeps cfg.optimizer.lr -- SURVEY 9 item 5)."""
 
-    def __init__(self, step, gamma=0.1, by_epoch=True, **kw):
+    def __init__(self, step, gamma=0.1, by_epoch=True, warmup=None, warmup_iters=0, warmup_ratio=0.1, **kw):
         self.step, self.gamma, self.base_lr = ([step] if isinstance(step, int) else list(step)), gamma, None
+        assert warmup in (None, 'linear', 'constant')
+        self.warmup, self.warmup_iters, self.warmup_ratio, self.regular_lr = warmup, warmup_iters, warmup_ratio, None
 
     def before_run(self, runner):
         for g in runner.optimizer.param_groups:
@@ -529,8 +531,23 @@ class StepLrUpdaterHook(Hook):
 
     def before_train_epoch(self, runner):
         exp = sum(1 for s in self.step if runner.epoch >= s)
-        for g, lr in zip(runner.optimizer.param_groups, self.base_lr):
-            g['lr'] = lr * self.gamma ** exp
+        self.regular_lr = [lr * self.gamma ** exp for lr in self.base_lr]
+        for g, lr in zip(runner.optimizer.param_groups, self.regular_lr):
+            g['lr'] = lr
+
+    def before_train_iter(self, runner):
+        """mmcv LrUpdaterHook warm-up (Config_SSD.py lr_config: linear, 500 iters, ratio 0.001)."""
+        if self.warmup is None or runner.iter > self.warmup_iters:
+            return
+        if runner.iter == self.warmup_iters:
+            lrs = self.regular_lr
+        elif self.warmup == 'linear':
+            k = (1 - runner.iter / self.warmup_iters) * (1 - self.warmup_ratio)
+            lrs = [lr * (1 - k) for lr in self.regular_lr]
+        else:
+            lrs = [lr * self.warmup_ratio for lr in self.regular_lr]
+        for g, lr in zip(runner.optimizer.param_groups, lrs):
+            g['lr'] = lr
 
 
 class CheckpointHook(Hook):

@@ -62,3 +62,8 @@ class SSL_L_RetinaNet(SSL_L_SingleStageDetector):
 
     def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
         super().__init__(backbone, neck, bbox_head, train_cfg, test_cfg, pretrained, init_cfg)
+
+
+@DETECTORS.register_module()
+class SSD_L_SingleStageDetector(SSL_L_SingleStageDetector):
+    """mmdet/models/detectors/SSD_L_single_stage.py:10-134 (same control flow as SSL_L_SingleStageDetector)."""

@@ -49,7 +49,7 @@ class Candidates:
 
 
 def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors, nms_pre, C_, means, stds, rescale=True,
-            fg_thr=0.3, wh_ratio_clip=16 / 1000, normalize=True):
+            fg_thr=0.3, wh_ratio_clip=16 / 1000, normalize=True, has_bg=False):
     dev = mlvl_cls[0].device
     B = mlvl_cls[0].shape[0]
     L = len(mlvl_cls)
@@ -61,7 +61,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     n = sum(ks)
     any_fg = torch.zeros(L, B, dtype=torch.int32, device=dev)
     boxes = torch.empty(B, n, 4, device=dev)
-    scores = torch.empty(B, n, C_ + 1, device=dev)
+    scores = torch.empty(B, n, C_ if has_bg else C_ + 1, device=dev)
     lam_o = torch.empty(B, n, device=dev)
     cand_anchor = torch.empty(B, n, dtype=torch.int32, device=dev)
     img_hw = torch.tensor([[float(s[0]), float(s[1])] for s in img_shapes], dtype=torch.float32).to(dev, non_blocking=True)
@@ -70,7 +70,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     level_start, idxs = [0], []
     for l in range(L):
         rowmax = torch.empty(B, A[l], device=dev)
-        call('aod_softmax_rowmax', ptr(cls[l]), B, A[l], C_, fg_thr, ptr(rowmax), ptr(any_fg[l]), stream())
+        call('aod_softmax_rowmax', ptr(cls[l]), B, A[l], C_, fg_thr, ptr(rowmax), ptr(any_fg[l]), int(has_bg), stream())
         idx = None
         if ks[l] < A[l]:
             idx = torch.empty(B, ks[l], dtype=torch.int32, device=dev)
@@ -78,7 +78,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
         idxs.append(idx)
         call('aod_gather_decode', ptr(cls[l]), ptr(reg[l]), ptr(lam[l]), ptr(mlvl_anchors[l].contiguous()), ptr(idx), B, A[l], ks[l], C_,
              ks[l], ptr(img_hw), ptr(sc4), _F4(*means), _F4(*stds), float(wh_ratio_clip), ptr(boxes), ptr(scores), ptr(lam_o),
-             ptr(cand_anchor), n, c0, a0, int(bool(normalize)), stream())
+             ptr(cand_anchor), n, c0, a0, 2 if has_bg else int(bool(normalize)), stream())
         c0 += ks[l]
         a0 += A[l]
         level_start.append(c0)
@@ -99,7 +99,7 @@ def multiclass_nms_batch(boxes, scores, score_thr, iou_thr, max_num):
 
 
 def hua_score(cand, dets, num_det, image_ids, max_num, agg=(0, 2, 0), clsW=False, num_samples=500, seed=20, obj_score_thr=0.3,
-              obj_iou_thr=0.5, fg_thr=0.3, want_pairs=False, max_pairs=None, scale_mode=False):
+              obj_iou_thr=0.5, fg_thr=0.3, want_pairs=False, max_pairs=None, scale_mode=False, dirichlet_cols=0):
     B, n, C1 = cand.scores.shape
     dev = cand.boxes.device
     L = len(cand.level_start) - 1
@@ -111,7 +111,7 @@ def hua_score(cand, dets, num_det, image_ids, max_num, agg=(0, 2, 0), clsW=False
     call('aod_hua_score', ptr(cand.boxes), ptr(cand.scores), ptr(cand.lam), ptr(cand.cand_anchor), ptr(dets), ptr(num_det),
          (C.c_int32 * (L + 1))(*cand.level_start), ptr(cand.any_fg), ptr(image_ids), B, n, L, C1 - 1, int(max_num), float(obj_score_thr),
          float(obj_iou_thr), float(fg_thr), int(num_samples), int(seed), (C.c_int32 * 3)(*agg), int(bool(clsW)), int(bool(scale_mode)),
-         ptr(unc), ptr(pair_out),
+         int(dirichlet_cols), ptr(unc), ptr(pair_out),
          int(max_pairs), ptr(pair_count), ptr(ws), stream())
     return (unc, pair_count, pair_out) if want_pairs else unc
 
@@ -122,14 +122,17 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
 
     isEval=True (detection for mAP)  -> list of (det_bboxes [k,5], det_labels [k]) per image.
     isUnc with uPool == 'Entropy_NMS' -> (det_results, unc [B] device tensor)."""
-    assert head.last_activation == 'relu', 'only the softmax-evidence head of Config_RetinaNet.py is built'
+    assert head.last_activation in ('relu', 'softmax')
+    has_bg = head.last_activation == 'softmax'         # SSD: 21 logits incl. background (My_L_ssd_head.py:331-345)
     C_ = head.cls_out_channels
+    na = head.num_anchors if isinstance(head.num_anchors, (list, tuple)) else [head.num_anchors] * len(mlvl_cls_scores)
     isUnc = kwargs.get('isUnc')
     uPool = kwargs.get('uPool')
     if isUnc and uPool == 'Entropy_NoNMS':
         raise NotImplementedError('uncertainty_pool=Entropy_NoNMS is a "next" row (SURVEY 8f rank 4)')
     if isUnc and uPool == 'Entropy_ALL':
         # Lambda_L2.py:281-283 (no top-k), :354 (no NMS), :364-365 ComputeScaleUnc + AggregateScaleUnc
+        assert not has_bg, 'Entropy_ALL is built for the RetinaNet evidence head'
         cand = pre_nms(mlvl_cls_scores, mlvl_bbox_preds, kwargs['L_scores'], mlvl_anchors, img_shapes, scale_factors, -1, C_,
                        head.bbox_coder.means, head.bbox_coder.stds, rescale=rescale, normalize=False)
         B = cand.boxes.shape[0]
@@ -145,11 +148,11 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
         return det_results, unc
     L_scores = kwargs.get('L_scores')
     if L_scores is None:   # plain detection: lambda is not needed, reuse zeros
-        L_scores = [torch.zeros(c.shape[0], head.num_anchors, c.shape[2], c.shape[3], device=c.device).contiguous(memory_format=torch.channels_last)
-                    for c in mlvl_cls_scores]
+        L_scores = [torch.zeros(c.shape[0], a, c.shape[2], c.shape[3], device=c.device).contiguous(memory_format=torch.channels_last)
+                    for c, a in zip(mlvl_cls_scores, na)]
     nms_pre = cfg.get('nms_pre', -1)
     cand = pre_nms(mlvl_cls_scores, mlvl_bbox_preds, L_scores, mlvl_anchors, img_shapes, scale_factors, nms_pre, C_,
-                   head.bbox_coder.means, head.bbox_coder.stds, rescale=rescale)
+                   head.bbox_coder.means, head.bbox_coder.stds, rescale=rescale, has_bg=has_bg)
     if not with_nms:
         return [(cand.boxes[b], cand.scores[b]) for b in range(cand.boxes.shape[0])]
     max_num = cfg.max_per_img
@@ -164,7 +167,7 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
         image_ids = torch.arange(B, device=dets.device, dtype=torch.int64) + int(bs) * B
     agg = extract_agg_codes(kwargs['uPool2'])
     unc = hua_score(cand, dets, num, image_ids.to(torch.int64).contiguous(), max_num, agg, kwargs.get('clsW', False),
-                    seed=kwargs.get('hua_seed', 20))
+                    seed=kwargs.get('hua_seed', 20), dirichlet_cols=C_ if has_bg else 0)
     det_results = [(dets[b], labels[b]) for b in range(B)]   # zero-padded to max_per_img rows (num_det rows are valid)
     if kwargs.get('_return_internals'):
         return det_results, unc, dict(cand=cand, dets=dets, labels=labels, keep=keep, num=num)

@@ -116,3 +116,8 @@ class MyEpochBasedRunnerLambda(BaseRunner):
                 os.symlink(filename, dst_file)
             else:
                 shutil.copy(filepath, dst_file)
+
+
+@RUNNERS.register_module()
+class MyEpochBasedRunnerLSSD(MyEpochBasedRunnerLambda):
+    """mmdet/utils/Epoch_Based_Runner_SSD_L.py (byte-identical to the Lambda runner apart from the class name)."""

@@ -157,9 +157,10 @@ int aod_max_iou_assign(const float* anchors, const uint8_t* valid, int64_t A, in
 /* ------------------------------------------------------------------ scoring (K11-K13)
  * replaces Lambda_L2.py:264-304: alphas = softmax; scores = alphas / (sum(alphas) + 1e-20 + 1e-9); row max; level gate
  * (any anchor of the level with max alpha > fg_thr, Lambda_L2.py:497-502).  cls [B, rows_per_img, C] fp32 (one level);
- * rowmax [B, rows_per_img]; any_fg [B] int32 (OR-ed into; caller zeroes). */
+ * rowmax [B, rows_per_img]; any_fg [B] int32 (OR-ed into; caller zeroes).  has_bg = 1 (SSD, My_L_ssd_head.py:331-345): plain softmax
+ * over C logits whose last column is background, maxima over the C-1 foreground columns. */
 int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img, int C, float fg_thr, float* rowmax, int32_t* any_fg,
-                       aod_stream_t stream);
+                       int has_bg, aod_stream_t stream);
 /* per image stable top-k (k <= 1024; descending score, ties -> lower index) of score [B, A] -> idx [B, out_pitch] int32
  * (torch.topk at Lambda_L2.py:290; its tie order is unspecified, pinned here) */
 int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, int64_t out_pitch, aod_stream_t stream);
@@ -167,7 +168,8 @@ int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, i
  * delta_xywh_bbox_coder.py:144-262): for candidate j (anchor idx[b][j], or j itself when idx == NULL):
  * boxes [B, n_total, 4] (clipped to img_hw[b] = (H, W), divided by scale4[b] when given), scores [B, n_total, C+1]
  * (normalised softmax + zero background column), lam [B, n_total], cand_anchor [B, n_total] = anchor0 + anchor index,
- * written at candidate offset cand0.  normalize = 0 keeps the raw softmax (Entropy_ALL). */
+ * written at candidate offset cand0.  normalize: 1 normalised evidence scores, 0 raw softmax (Entropy_ALL), 2 softmax incl. a
+ * background logit (SSD: C logits -> C score columns, no padding column). */
 int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
                       int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
                       const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
@@ -189,6 +191,7 @@ int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, in
  * agg3_host = (class, scale, object) codes 0 Sum / 1 Avg / 2 Max (HOST array; NULL = Sum/Max/Sum).
  * scale_mode = 1: Entropy_ALL / ComputeScaleUnc + AggregateScaleUnc (Lambda_L2.py:539-569,636-691): every candidate whose max
  * score exceeds fg_thr is a pair of one pseudo object, lambda mean over ALL candidates of the level, scores = raw softmax.
+ * dirichlet_cols: C (evidence head; 0 = default) or C+1 (SSD: the background probability is a Dirichlet component too).
  * pair_out (optional, [B, max_pairs, 4] f32: cand, obj, aleatoric, epistemic); pair_count [B] int32 (may exceed
  * max_pairs: then the excess pairs were dropped and the caller must retry with a larger workspace). */
 size_t aod_hua_ws_bytes(int B, int max_pairs);
@@ -196,7 +199,24 @@ int aod_hua_score(const float* boxes, const float* scores, const float* lam, con
                   const float* dets, const int32_t* num_det, const int32_t* level_start_host, const int32_t* level_any_fg,
                   const int64_t* image_ids, int B, int n, int L, int C, int max_num, float obj_score_thr, float obj_iou_thr,
                   float fg_thr, int num_samples, uint64_t seed, const int32_t* agg3_host, int clsW, int scale_mode,
-                  float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
+                  int dirichlet_cols, float* unc, float* pair_out, int max_pairs, int32_t* pair_count, void* ws, aod_stream_t stream);
+
+/* ------------------------------------------------------------------ SSD300-VGG16 variant (BASELINE config 0)
+ * generic NHWC bf16 max-pool fwd/bwd (mmcv VGG pools, ceil_mode, + the 3x3 s1 p1 pool5 of backbones/ssd_vgg.py:66-68) */
+int aod_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int k, int s, int p, aod_stream_t stream);
+int aod_maxpool_bwd(const void* x, const void* g, void* gx, int B, int H, int W, int C, int OH, int OW, int k, int s, int p,
+                    aod_stream_t stream);
+/* L2Norm (necks/ssd_neck.py:105-128): y = w[c] * x / (||x||_2 + eps) per pixel; bwd accumulates gw (fp32) */
+int aod_l2norm_fwd(const void* x, const float* w, void* y, int64_t rows, int C, float eps, aod_stream_t stream);
+int aod_l2norm_bwd(const void* x, const float* w, const void* g, void* gx, float* gw, int64_t rows, int C, float eps, aod_stream_t stream);
+/* SSD loss per image (My_L_ssd_head.py:182-215): ce[b][a] = CE(logits, label) * w (== loss_noR); sums3[b] = (sum_pos ce + sum of the
+ * min(ratio * #pos, #neg) largest negative ce, sum smooth_l1 * w, mean ce); sel4[b] = selection record consumed by the backward. */
+int aod_ssd_loss_fwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred, const float* bbox_tgt,
+                     const float* bbox_w, int B, int A, int C1, int num_classes, int neg_pos_ratio, float beta, float* ce, float* sums3,
+                     uint32_t* sel4, aod_stream_t stream);
+int aod_ssd_loss_bwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred, const float* bbox_tgt,
+                     const float* bbox_w, const float* ce, const uint32_t* sel4, int B, int A, int C1, int num_classes, float beta,
+                     const float* g_cls, const float* g_box, const float* g_noR, float* grad_cls, float* grad_box, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer (K16)
  * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61): d = g*grad_scale + wd*p; buf = first ? d : mom*buf + d;

@@ -79,3 +79,28 @@ def planted_heads(B=2, H=128, W=128, C=20, A=9, seed=22, n_plant=6):
         reg.append(0.1 * torch.randn(B, A * 4, h, w, generator=g))
         Ls.append(torch.rand(B, A, h, w, generator=g) * 0.3 + 0.01)
     return cls, reg, Ls
+
+
+SSD_SIZES = (38, 19, 10, 5, 3, 1)
+SSD_ANCHORS = (4, 6, 6, 6, 4, 4)
+
+
+def planted_heads_ssd(B=2, C1=21, seed=23, n_plant=5):
+    """SSD300 head outputs with planted foreground logits: cls = 0.5*N(0,1) over C1 = 21 logits (background last, +2.0 so most
+    anchors are background) with +9.0 on a few (anchor, class) 3x3 patches; reg = 0.3*N(0,1); L = U(.01,.31)."""
+    g = gen(seed)
+    cls, reg, Ls = [], [], []
+    for h, A in zip(SSD_SIZES, SSD_ANCHORS):
+        c = 0.5 * torch.randn(B, A * C1, h, h, generator=g)
+        c.view(B, A, C1, h, h)[:, :, C1 - 1] += 2.0
+        for b in range(B):
+            for _ in range(n_plant if h >= 5 else 1):
+                a = int(torch.randint(0, A, (1,), generator=g))
+                k = int(torch.randint(0, C1 - 1, (1,), generator=g))
+                y = int(torch.randint(0, h, (1,), generator=g))
+                x = int(torch.randint(0, h, (1,), generator=g))
+                c[b, a * C1 + k, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] += 9.0
+        cls.append(c)
+        reg.append(0.3 * torch.randn(B, A * 4, h, h, generator=g))
+        Ls.append(torch.rand(B, A, h, h, generator=g) * 0.3 + 0.01)
+    return cls, reg, Ls

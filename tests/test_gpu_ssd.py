@@ -1,0 +1,272 @@
+"""GPU parity of the SSD300-VGG16 + MEH/HUA path (BASELINE config 0): SSD-only kernels against torch / the
+oracle, the product model against the golden values the REFERENCE produced (tests/golden/ssd_*.npz), and the scoring pass in
+softmax-with-background mode (21 Dirichlet columns) against the golden integer artifacts and the Philox oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detect as odetect
+from oracle import model_ssd as ossd
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize('k,s,p,ceil,H,W', [(2, 2, 0, True, 75, 75), (2, 2, 0, True, 38, 38), (3, 1, 1, False, 19, 19), (2, 2, 0, False, 10, 7)])
+def test_maxpool_fwd_bwd_exact(k, s, p, ceil, H, W):
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.functional_ssd import max_pool
+    g = synth.gen(5)
+    x = torch.randn(2, 64, H, W, generator=g).bfloat16()
+    xr = x.float().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p, ceil_mode=ceil)
+    go = torch.randn(yr.shape, generator=g).bfloat16()
+    yr.backward(go.float())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = max_pool(xd, k, s, p, ceil)
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(go.cuda().contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu(), yr.detach())                 # bf16 max is exact
+    # ties (equal bf16 values in one window) route to the first max in both implementations
+    assert torch.equal(xd.grad.float().cpu(), xr.grad.bfloat16().float())
+
+
+def test_l2norm_fwd_bwd():
+    from aod_meh_hua_amd.functional_ssd import l2norm
+    g = synth.gen(6)
+    x = (torch.randn(2, 512, 38, 38, generator=g) * 3).bfloat16()
+    w = (torch.rand(512, generator=g) * 10 + 15)
+    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = ossd.l2norm(xr, wr)
+    go = torch.randn(yr.shape, generator=g).bfloat16()
+    yr.backward(go.float())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    y = l2norm(xd, wd, 1e-10)
+    y.backward(go.cuda().contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    assert rel(y.detach().float().cpu().numpy(), yr.detach().numpy()) < 8e-3          # bf16 output rounding
+    assert rel(xd.grad.float().cpu().numpy(), xr.grad.numpy()) < 1e-2
+    assert np.allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('A,npos', [(8732, 23), (8732, 0), (500, 200)])
+def test_ssd_loss_fwd_bwd(A, npos):
+    """CE + 3:1 hard-negative mining + SmoothL1 (My_L_ssd_head.py:182-215) vs the oracle, incl. n_pos = 0 and neg-limited cases."""
+    from aod_meh_hua_amd.functional_ssd import SSDLossFn
+    g = synth.gen(7 + npos)
+    B, C1 = 3, 21
+    cls = torch.randn(B, A, C1, generator=g) * 2
+    box = torch.randn(B, A, 4, generator=g)
+    labels = torch.full((B, A), 20, dtype=torch.int64)
+    lw = torch.ones(B, A)
+    bt, bw = torch.randn(B, A, 4, generator=g) * 1.5, torch.zeros(B, A, 4)
+    for b in range(B):
+        pos = torch.randperm(A, generator=g)[:npos + b * (npos > 0)]
+        labels[b, pos] = torch.randint(0, 20, (len(pos),), generator=g)
+        bw[b, pos] = 1.0
+        ign = torch.randperm(A, generator=g)[:7]
+        ign = ign[labels[b, ign] == 20]
+        lw[b, ign] = 0.0                                   # invalid (unmapped) anchors: label = bg, weight 0
+    cr, br = cls.clone().requires_grad_(True), box.clone().requires_grad_(True)
+    ntot = 37.0
+    tot = 0
+    ref = []
+    for b in range(B):
+        lc, lb, ce = ossd.ssd_loss_single(cr[b], br[b], labels[b], lw[b], bt[b], bw[b], ntot)
+        ref.append((float(lc), float(lb), ce.detach()))
+        tot = tot + lc.sum() + lb + ce.mean()
+    tot.backward()
+    cd, bd = cls.cuda().requires_grad_(True), box.cuda().requires_grad_(True)
+    cs, bs, ce = SSDLossFn.apply(cd, bd, labels.cuda(), lw.cuda(), bt.cuda(), bw.cuda(), 20, 3, 1.0)
+    (cs.sum() / ntot + bs.sum() / ntot + ce.mean(1).sum()).backward()
+    torch.cuda.synchronize()
+    for b in range(B):
+        assert np.allclose(float(cs[b]) / ntot, ref[b][0], rtol=1e-5, atol=1e-6), (b, float(cs[b]) / ntot, ref[b][0])
+        assert np.allclose(float(bs[b]) / ntot, ref[b][1], rtol=1e-5, atol=1e-6)
+        assert np.allclose(ce[b].detach().cpu().numpy(), ref[b][2].numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(cd.grad.cpu().numpy(), cr.grad.numpy(), rtol=1e-4, atol=1e-7)
+    assert np.allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ model
+@pytest.fixture(scope='module')
+def built():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_SSD.py'))
+    cfg.model.backbone.pop('init_cfg')
+    model = build_detector(cfg.model)
+    sd = ossd.seeded_state_dict()
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().train(), sd
+
+
+def test_ssd_state_dict_and_anchors_match_reference(built):
+    model, _ = built
+    g = np.load(os.path.join(G, 'ssd_spec.npz'))
+    assert list(model.state_dict().keys()) == list(g['keys'])
+    assert [str(tuple(v.shape)) for v in model.state_dict().values()] == list(g['shapes'])
+    ag = model.bbox_head.anchor_generator
+    assert np.array_equal(np.concatenate([b.cpu().numpy() for b in ag.base_anchors]), g['base_anchors'])
+    mlvl = ag.grid_anchors([(s, s) for s in synth.SSD_SIZES], 'cuda')
+    assert np.array_equal(mlvl[3].cpu().numpy(), g['anchors_l3']) and np.array_equal(mlvl[5].cpu().numpy(), g['anchors_l5'])
+
+
+def test_ssd_train_step_vs_reference_golden(built):
+    model, sd = built
+    g = np.load(os.path.join(G, 'ssd_train_step.npz'))
+    img = synth.images(8, 300, 300, seed=41).cuda()
+    gtb, gtl = synth.random_gts(8, 300, 300, seed=42, gmin=1, gmax=3)
+    data = dict(img=img, img_metas=synth.metas(8, 300, 300), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    torch.cuda.synchronize()
+    lab = torch.cat(head_out[4], 1).cpu()
+    assert [int(((l >= 0) & (l < 20)).sum()) for l in lab] == list(g['n_pos'])           # integer-exact assignment
+    assert [int(l.sum()) for l in lab] == list(g['labels_sum'])
+    fam = [float(f.float().abs().mean()) for f in feat_out]
+    assert np.allclose(fam, g['feat_absmean'], rtol=2e-2), (fam, g['feat_absmean'])
+    assert rel(feat_out[0][0, :8, :6, :6].float().cpu().numpy(), g['feat_l0_sample']) < 3e-2
+    assert rel(feat_out[3][:2].float().cpu().numpy(), g['feat_l3']) < 3e-2
+    assert rel(feat_out[5].float().cpu().numpy(), g['feat_l5']) < 3e-2
+    assert rel(head_out[1][2][:2].detach().float().cpu().numpy(), g['cls_l2']) < 3e-2
+    lv = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
+    assert np.allclose(lv, g['log_vars'], rtol=2e-2), (lv, g['log_vars'])
+    assert np.allclose(float(out['loss']), g['loss'], rtol=2e-2)
+    assert rel(prev[0].cpu().numpy(), g['loss_noR_img0']) < 3e-2
+    model.zero_grad()
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    pd = dict(model.named_parameters())
+    gn = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names']])
+    assert np.allclose(gn, g['grad_norms'], rtol=6e-2), (gn, g['grad_norms'])
+    assert pd['bbox_head.L_convs.0.0.weight'].grad is None
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    model.zero_grad()
+    lossL['loss'].backward()
+    torch.cuda.synchronize()
+    assert np.allclose(float(lossL['loss']), g['loss_L'], rtol=2e-2)
+    gnL = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names_L']])
+    assert np.allclose(gnL, g['grad_norms_L'], rtol=6e-2), (gnL, g['grad_norms_L'])
+    assert pd['bbox_head.cls_convs.0.0.weight'].grad is None and pd['backbone.features.33.weight'].grad is None
+
+
+def test_ssd_gradients_vs_oracle_directionally(built):
+    model, sd0 = built
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    img = synth.images(8, 300, 300, seed=41)
+    gtb, gtl = synth.random_gts(8, 300, 300, seed=42, gmin=1, gmax=3)
+    torch.set_num_threads(8)
+    o = ossd.train_step(sd, img, gtb, gtl)
+    o['loss'].backward()
+    data = dict(img=img.cuda(), img_metas=synth.metas(8, 300, 300), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    out, *_ = model.train_step(data, Labeled=True, Pseudo=False)
+    model.zero_grad()
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    pd = dict(model.named_parameters())
+    for k in ['backbone.features.0.weight', 'backbone.features.0.bias', 'backbone.features.12.weight', 'backbone.features.21.weight',
+              'backbone.features.31.weight', 'backbone.features.33.bias', 'neck.l2_norm.weight', 'neck.extra_layers.0.1.conv.weight',
+              'neck.extra_layers.2.0.conv.bias', 'neck.extra_layers.3.1.conv.weight', 'bbox_head.cls_convs.0.0.weight',
+              'bbox_head.cls_convs.4.0.bias', 'bbox_head.reg_convs.1.0.weight', 'bbox_head.reg_convs.5.0.weight']:
+        a, b = pd[k].grad.float().cpu().flatten(), sd[k].grad.flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        print(k, 'cos', cos, 'norm ratio', float(a.norm() / b.norm()))
+        # the first conv sits under 15 bf16 layers and 4 max-pools (arg-max routing flips on bf16 near-ties): looser bound
+        assert cos > (0.98 if k.startswith('backbone.features.0.') else 0.99), (k, cos)
+        assert abs(float(a.norm() / b.norm()) - 1) < 6e-2, (k, float(a.norm()), float(b.norm()))
+
+
+# ------------------------------------------------------------------------------------------------ scoring
+@pytest.fixture(scope='module')
+def run(built):
+    from aod_meh_hua_amd import scoring
+    model, _ = built
+    head = model.bbox_head
+    cls_p, reg_p, L_p = synth.planted_heads_ssd(2)
+    mt = synth.metas(2, 300, 300, scale=1.25)
+    anchors = head.anchor_generator.grid_anchors([(s, s) for s in synth.SSD_SIZES], 'cuda')
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    det, unc, internals = scoring.score_batch(head, [cl(c) for c in cls_p], [cl(r) for r in reg_p], anchors, [m['img_shape'] for m in mt],
+                                              [m['scale_factor'] for m in mt], head.test_cfg, rescale=True, with_nms=True, isUnc='Epistemic',
+                                              uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', isEval=False,
+                                              L_scores=[cl(l) for l in L_p], _return_internals=True, batchIdx=0)
+    torch.cuda.synchronize()
+    o = ossd.score_images(None, torch.zeros(2, 3, 300, 300), [m['img_shape'] for m in mt], [m['scale_factor'] for m in mt],
+                          sampler='philox', seed=20, heads=(cls_p, reg_p, L_p))
+    return dict(unc=unc, it=internals, o=o, gold=np.load(os.path.join(G, 'ssd_scoring.npz')), scoring=scoring)
+
+
+def test_ssd_candidates_and_nms_vs_reference(run):
+    it, g, o = run['it'], run['gold'], run['o']
+    cand = it['cand']
+    assert cand.level_start == [0, 1000, 2000, 2600, 2750, 2786, 2790]
+    assert np.array_equal(cand.lam.cpu().numpy(), g['lam'])                                   # identical top-k order + gather
+    assert np.allclose(cand.boxes.cpu().numpy(), g['boxes_cat'], rtol=1e-5, atol=1e-4)
+    assert np.allclose(cand.scores.cpu().numpy(), o['pre']['cat_scores'].numpy(), rtol=1e-5, atol=1e-8)
+    assert tuple(cand.scores.shape) == (2, 2790, 21)
+    num = it['num'].cpu().tolist()
+    for b in range(2):
+        gd = g[f'det{b}']
+        assert num[b] == gd.shape[0] and num[b] > 0
+        assert np.array_equal(it['keep'][b, :num[b]].cpu().numpy(), g[f'keep{b}'])
+        assert np.array_equal(it['labels'][b, :num[b]].cpu().numpy(), gd[:, 5].astype(np.int64))
+        assert np.allclose(it['dets'][b, :num[b]].cpu().numpy(), gd[:, :5], rtol=1e-5, atol=1e-4)
+        d, lab, keep, _ = odetect.multiclass_nms(cand.boxes[b].cpu(), cand.scores[b].cpu(), score_thr=0.02, max_num=200)
+        assert np.array_equal(it['keep'][b, :num[b]].cpu().numpy(), keep.numpy()) and torch.equal(it['dets'][b, :num[b]].cpu(), d)
+
+
+def test_ssd_hua_pairs_and_values_vs_philox_oracle(run):
+    sc, it, o, g = run['scoring'], run['it'], run['o'], run['gold']
+    cand = it['cand']
+    ids = torch.arange(2, device='cuda', dtype=torch.int64)
+    unc, pc, pout = sc.hua_score(cand, it['dets'], it['num'], ids, 200, want_pairs=True, seed=20, dirichlet_cols=21)
+    torch.cuda.synchronize()
+    pc, pout = pc.cpu().tolist(), pout.cpu().numpy()
+    lvl_off = np.asarray(cand.level_start)
+    for b in range(2):
+        exp = sorted([p for p in o['pairs'] if p['image'] == b], key=lambda p: p['level'])
+        ec = np.concatenate([p['cand'].numpy() + lvl_off[p['level']] for p in exp])
+        eo = np.concatenate([p['obj'].numpy() for p in exp])
+        ee = np.concatenate([p['epi'].numpy() for p in exp])
+        assert pc[b] == len(ec) and pc[b] > 20
+        got = pout[b, :pc[b]]
+        assert np.array_equal(got[:, 0].astype(np.int64), ec) and np.array_equal(got[:, 1].astype(np.int64), eo)
+        err = np.abs(got[:, 3] - ee)
+        print('ssd pair epi err: median', np.median(err), 'max', err.max())
+        assert np.median(err) < 5e-5 and (err < 5e-3).all(), (np.median(err), err.max())
+    assert np.allclose(unc.cpu().numpy(), np.array(o['unc']), rtol=2e-3), (unc, o['unc'])
+    assert torch.equal(run['unc'], unc)                                                       # deterministic
+    mu, sd = g['unc_runs'].mean(0), g['unc_runs'].std(0)                                      # reference MC-500, 16 reseeded runs
+    for seed in (1, 2, 20):
+        u = sc.hua_score(cand, it['dets'], it['num'], ids, 200, seed=seed, dirichlet_cols=21).cpu().numpy()
+        assert (np.abs(u - mu) <= 4 * sd + 0.02 * mu).all(), (seed, u, mu, sd)
+
+
+def test_ssd_full_model_scoring_runs_and_is_partition_invariant(built):
+    """simple_test through the detector on seeded weights: whole batch vs one image at a time give identical scores."""
+    model, _ = built
+    model.eval()
+    img = synth.images(4, 300, 300, seed=43).cuda()
+    kw = dict(rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', scaleUnc=False,
+              showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False)
+    with torch.no_grad():
+        _, unc = model(img=[img], img_metas=[synth.metas(4, 300, 300)], return_loss=False, image_ids=torch.arange(4, device='cuda'), **kw)
+        singles = [model(img=[img[b:b + 1]], img_metas=[synth.metas(1, 300, 300)], return_loss=False,
+                         image_ids=torch.tensor([b], device='cuda'), **kw)[1] for b in range(4)]
+    model.train()
+    u = torch.as_tensor(unc).float().cpu()
+    s = torch.cat([torch.as_tensor(x).float().cpu().reshape(-1) for x in singles])
+    assert torch.isfinite(u).all() and torch.equal(u, s)

@@ -39,10 +39,10 @@ score_thr = 0.3
 iou_thr = 0.9
 
 
-def parse_args():
+def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
     base_dir = osp.dirname(osp.dirname(osp.abspath(__file__)))
     p = argparse.ArgumentParser(description='Train a detector (active learning, MEH + HUA)')
-    p.add_argument('--config', default=osp.join(base_dir, 'configs/_base_/Config_RetinaNet.py'))
+    p.add_argument('--config', default=osp.join(base_dir, default_config))
     p.add_argument('--work-dir', default='WORK_DIR')
     p.add_argument('--resume-from')
     p.add_argument('--load-from')
@@ -53,7 +53,7 @@ def parse_args():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--Unc-type', type=str)
     p.add_argument('--synthetic', type=int, default=0, help='run on a synthetic VOC-shaped pool of this many images')
-    p.add_argument('--synthetic-size', type=int, default=512)
+    p.add_argument('--synthetic-size', type=int, default=default_size)
     p.add_argument('--cycles', type=int, default=None, help='override the number of AL cycles')
     p.add_argument('--samples-per-gpu', type=int, default=None)
     args = p.parse_args()
@@ -61,8 +61,8 @@ def parse_args():
     return args
 
 
-def main():
-    args = parse_args()
+def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
+    args = parse_args(default_config, default_size)
     cfg = Config.fromfile(args.config)
     seed = 20
     torch.manual_seed(seed), np.random.seed(seed), random.seed(seed)
@@ -125,8 +125,13 @@ def main():
         model = build_detector(cfg.model)
         model.init_weights()
         if cfg.model.train_cfg.get('bias') == 'uniform':                     # :158-162
-            N, k = model.bbox_head.num_anchors, model.bbox_head.retina_cls.bias.numel()
-            torch.nn.init.uniform_(model.bbox_head.retina_cls.bias, -math.sqrt(1 / (N * k)), math.sqrt(1 / (N * k)))
+            head = model.bbox_head
+            if hasattr(head, 'retina_cls'):
+                N, k = head.num_anchors, head.retina_cls.bias.numel()
+                torch.nn.init.uniform_(head.retina_cls.bias, -math.sqrt(1 / (N * k)), math.sqrt(1 / (N * k)))
+            else:                                                             # tools/train_SSD.py:172-178
+                for conv in head.cls_convs:
+                    torch.nn.init.uniform_(conv[-1].bias, -math.sqrt(1 / 2000), math.sqrt(1 / 2000))
         if load_cycle >= 0:
             from aod_meh_hua_amd.mmcv_lite import load_checkpoint
             cfg_name = osp.splitext(osp.basename(args.config))[0]
