@@ -649,21 +649,39 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ w, bf16_t* __restric
     o[i] = (c < I) ? (bf16_t)w[((long long)oo * I + c) * RS + rs] : (bf16_t)0.f;
   }
 }
-__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ o, int O, int I, int RS, int Opad) {
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, bf16_t* __restrict__ o, int O, int I, int RS,
+                                    int Opad) {
   const long long n = (long long)Opad * RS * I;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int oo = i % Opad; const long long r1 = i / Opad; const int rs = r1 % RS; const int c = r1 / RS;
-    o[i] = (oo < O) ? (bf16_t)w[((long long)oo * I + c) * RS + rs] : (bf16_t)0.f;
+    o[i] = (oo < O) ? (bf16_t)(w[((long long)oo * I + c) * RS + rs] * (scale ? scale[oo] : 1.f)) : (bf16_t)0.f;
   }
 }
-__global__ void unpack_wgrad_kernel(float* __restrict__ dw, float* __restrict__ g, int O, int I, int RS, int Ipad, int accumulate, int clear) {
-  const long long n = (long long)O * I * RS;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int rs = i % RS; const long long r1 = i / RS; const int c = r1 % I; const int oo = r1 / I;
+// One block per output channel o: g[o][c][rs] (+)= scale[o] * dw[o][rs][c], and wdot[o] = <w[o], dw[o]>.
+// With y = (z - mean) * invstd * gamma + beta and z = <w[o], patch>, the BN-scale gradient needs sum_m gm[m,o] * z[m,o]
+// = <w[o], sum_m gm[m,o] * patch(m)> = <w[o], dW_gm[o]>: the pre-BN activations never have to be stored or re-read.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ dw, float* __restrict__ g, const float* __restrict__ scale,
+                                                          const float* __restrict__ w, float* __restrict__ wdot, int O, int I, int RS, int Ipad,
+                                                          int accumulate, int clear) {
+  __shared__ float red[4];
+  const int oo = blockIdx.x;
+  const int n = I * RS;
+  const float sc = scale ? scale[oo] : 1.f;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int rs = i % RS, c = i / RS;
     const long long si = ((long long)oo * RS + rs) * Ipad + c;
+    const long long gi = (long long)oo * n + i;
     const float v = dw[si];
     if (clear) dw[si] = 0.f;          // hand the accumulator back all-zero: no separate memset launch per conv
-    g[i] = accumulate ? g[i] + v : v;
+    if (w) dot += w[gi] * v;
+    g[gi] = accumulate ? g[gi] + v * sc : v * sc;
+  }
+  if (wdot) {
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) wdot[oo] = red[0] + red[1] + red[2] + red[3];
   }
 }
 static inline int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -674,15 +692,18 @@ extern "C" int aod_pack_weight_fwd(const float* w, void* o, int O, int I, int R,
   AOD_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int aod_pack_weight_dgrad(const float* w, void* o, int O, int I, int R, int S, int Opad, aod_stream_t stream) {
+extern "C" int aod_pack_weight_dgrad(const float* w, void* o, int O, int I, int R, int S, int Opad, const float* scale, aod_stream_t stream) {
   AOD_CHECK_ARG(w && o && Opad >= O && Opad % 8 == 0, "pack_weight_dgrad: Opad must be a multiple of 8 and >= O");
-  hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(grid_for((long long)Opad * R * S * I)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)o, O, I, R * S, Opad);
+  hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(grid_for((long long)Opad * R * S * I)), dim3(256), 0, (hipStream_t)stream, w, scale, (bf16_t*)o, O, I, R * S, Opad);
   AOD_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int aod_unpack_wgrad(float* dw, float* g, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src, aod_stream_t stream) {
+extern "C" int aod_unpack_wgrad(float* dw, float* g, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src, const float* scale,
+                                const float* w_oihw, float* wdot, aod_stream_t stream) {
   AOD_CHECK_ARG(dw && g, "unpack_wgrad: null");
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for((long long)O * R * S * I)), dim3(256), 0, (hipStream_t)stream, dw, g, O, I, R * S, Ipad, accumulate, clear_src);
+  AOD_CHECK_ARG(!wdot || w_oihw, "unpack_wgrad: wdot needs the weights");
+  if (O == 0) return 0;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, dw, g, scale, w_oihw, wdot, O, I, R * S, Ipad, accumulate, clear_src);
   AOD_LAUNCH_CHECK();
   return 0;
 }

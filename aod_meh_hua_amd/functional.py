@@ -105,23 +105,22 @@ class ConvFn(Function):
             scale, shift, invstd = fold_bn(gamma, beta, mean, var, meta['eps'])
         elif bias is not None:
             shift = bias.detach()
-        need_z = gamma is not None and ctx.needs_input_grad[2]
         res_rows = as_rows(res) if res is not None else None
         out_rows = as_rows(meta['out']) if meta.get('out') is not None else None      # caller-provided destination (pyramid slice)
+        # the pre-BN activations z are NOT kept: the BN weight gradient comes from <w, dW> (see backward)
         r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
-                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], save_z=need_z, out=out_rows)
+                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], out=out_rows)
         y_rows, y_segs = r[0], r[1]
-        z_rows = r[2] if need_z else None
         ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
         ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
         ctx.nx = len(xs)
-        ctx.save_for_backward(w, gamma, mean, scale, invstd, x_rows, y_rows if meta['relu'] else None, z_rows)
+        ctx.save_for_backward(w, gamma, mean, scale, invstd, x_rows, y_rows if meta['relu'] else None)
         outs = tuple(as_nchw(y_rows[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for s in y_segs)
         return outs
 
     @staticmethod
     def backward(ctx, *gouts):
-        w, gamma, mean, scale, invstd, x_rows, a_rows, z_rows = ctx.saved_tensors
+        w, gamma, mean, scale, invstd, x_rows, a_rows = ctx.saved_tensors
         meta = ctx.meta
         O, I, R, S = w.shape
         cin = x_rows.shape[1]
@@ -153,32 +152,38 @@ class ConvFn(Function):
             dz, gbias_v = ho.pad_cast_colsum(g_rows, Opad, a_rows if meta['relu'] else None)
             gm = None
         else:
+            # gm = g * [y > 0] (bf16) and its column sums S1.  With y = z*scale + shift the gradient w.r.t. z is gm*scale[n]; it is never
+            # materialised: the scale is folded into the dgrad weights and into the unpack of dW.  BN gradients (eval-mode statistics):
+            #   dbeta = S1,   dgamma = invstd * (sum_m gm*z - mean*S1),   sum_m gm[m,n]*z[m,n] = <w[n], dW_gm[n]>   (z = <w[n], patch(m)>)
             relu = meta['relu']
-            if ctx.has_bn:
-                need_bn = ctx.needs_input_grad[2]
-                dz, gm, dbeta, dgamma = ho.act_bwd(g_rows, a_rows, z_rows if need_bn else None, scale, mean.float() if need_bn else None,
-                                                  invstd if need_bn else None, relu=relu, want_gm=need_res)
-                if need_bn:
-                    ggamma, gbeta = dgamma.to(gamma.dtype), dbeta
-                gbias_v = None
-            else:
-                plain = (not relu) and g_rows.dtype == torch.bfloat16 and not need_res
-                dz, gm, dbeta, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=need_res, want_dz=not plain)
-                if plain:
-                    dz = g_rows
-                gbias_v = dbeta
+            plain = (not relu) and g_rows.dtype == torch.bfloat16
+            dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=False, want_dz=not plain)
+            if plain:
+                dz = g_rows
+            gbias_v = s1
+        need_bn = ctx.has_bn and ctx.needs_input_grad[2]
         if ctx.has_bias and ctx.needs_input_grad[6]:
             gbias = gbias_v[:O]
         if need_res:
             s = y_segs[0]
-            gres = as_nchw(gm, s.B, s.H, s.W)
+            gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
         x_segs = ctx.x_segs
-        if need_w:
+        if need_w or need_bn:
             dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'])
-            gw = ho.unpack_wgrad(dw, O, I)
+            if need_bn:
+                gw, wdot = ho.unpack_wgrad(dw, O, I, scale=scale, w_oihw=w.detach().float(), want_wdot=True)
+                ggamma = (invstd * (wdot - mean.float() * s1)).to(gamma.dtype)
+                gbeta = s1
+            else:
+                gw = ho.unpack_wgrad(dw, O, I, scale=scale if ctx.has_bn else None)
+            if not need_w:
+                gw = None
         gxs = [None] * ctx.nx
         if need_x:
-            wd = CACHE.get('wd%d' % Opad, (w,), lambda: ho.pack_weight_dgrad(w.detach(), Opad))
+            if ctx.has_bn:
+                wd = CACHE.get('wds%d' % Opad, (w, scale), lambda: ho.pack_weight_dgrad(w.detach(), Opad, scale))
+            else:
+                wd = CACHE.get('wd%d' % Opad, (w,), lambda: ho.pack_weight_dgrad(w.detach(), Opad))
             if I != cin:   # stem: channel-padded input; dX only for the real channels is never needed (image)
                 raise RuntimeError('dgrad through a channel-padded input is not supported')
             xd = dense_segs(x_segs)

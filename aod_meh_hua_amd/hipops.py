@@ -81,11 +81,12 @@ def pack_weight_fwd(w_oihw: torch.Tensor, cpad: Optional[int] = None) -> torch.T
     return out
 
 
-def pack_weight_dgrad(w_oihw: torch.Tensor, opad: Optional[int] = None) -> torch.Tensor:
+def pack_weight_dgrad(w_oihw: torch.Tensor, opad: Optional[int] = None, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`scale` fp32 [O]: folded eval-BN scale of the conv's own BatchNorm (dX = conv_T(gm, scale*W))."""
     O, I, R, S = w_oihw.shape
     opad = opad or (O + 7) // 8 * 8
     out = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=w_oihw.device)
-    call('aod_pack_weight_dgrad', ptr(w_oihw.contiguous()), ptr(out), O, I, R, S, opad, stream())
+    call('aod_pack_weight_dgrad', ptr(w_oihw.contiguous()), ptr(out), O, I, R, S, opad, ptr(scale), stream())
     return out
 
 
@@ -149,7 +150,8 @@ def _dw_scratch(n, device):
     return buf[:n]
 
 
-def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None):
+def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False):
+    """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot."""
     Opad, R, S, Ipad = dw_orsi.shape
     if grad_oihw is None:
         grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
@@ -159,8 +161,10 @@ def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None):
     if clear and (O != Opad or I != Ipad):
         # dZ pad columns / x pad channels are zero, so wgrad added exact zeros there: nothing to clear beyond [O, I]
         pass
-    call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), int(bool(clear)), stream())
-    return grad_oihw
+    wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
+    call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), int(bool(clear)), ptr(scale),
+         ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), stream())
+    return (grad_oihw, wdot) if want_wdot else grad_oihw
 
 
 def nchw_to_rows(img_f32, cpad=8):

@@ -74,14 +74,18 @@ int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz,
 size_t aod_conv_row_table_bytes(const aod_conv_desc_t* desc);
 int aod_conv_row_table(const aod_conv_desc_t* desc, void* table, aod_stream_t stream);
 
-/* OIHW fp32 -> [O][R][S][Ipad] bf16 (forward) / [I][R][S][Opad] bf16 (dgrad); pads zero-filled, multiples of 8 */
+/* OIHW fp32 -> [O][R][S][Ipad] bf16 (forward) / [I][R][S][Opad] bf16 (dgrad); pads zero-filled, multiples of 8.
+ * dgrad: `scale` (nullable, fp32 [O]) multiplies output channel o -- the eval-BN scale gamma*rsqrt(var+eps) of
+ * resnet.py:647-656 folded into the weights, so that dX = conv_T(gm, scale*W) needs no scaled copy of the gradient. */
 int aod_pack_weight_fwd(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Ipad, aod_stream_t stream);
-int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Opad, aod_stream_t stream);
-/* [Opad][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient (first O rows / I channels); accumulate != 0 adds;
- * clear_src != 0 zeroes every element it reads, so a persistent accumulator is all-zero again (needs O == Opad, I == Ipad
- * or a caller that tolerates the untouched pad rows staying zero -- wgrad only ever adds zeros there). */
+int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int R, int S, int Opad, const float* scale,
+                          aod_stream_t stream);
+/* [Opad][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient (first O rows / I channels), times scale[o] when given;
+ * accumulate != 0 adds; clear_src != 0 zeroes every element it reads, so a persistent accumulator is all-zero again.
+ * wdot (nullable, fp32 [O], overwritten) receives <w_oihw[o], dw[o]> = sum_m gm[m,o] * z[m,o]: the BatchNorm weight
+ * gradient of an eval-mode BN behind the conv (resnet.py:262-301) without keeping the pre-BN activations z. */
 int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src,
-                     aod_stream_t stream);
+                     const float* scale, const float* w_oihw, float* wdot, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ layout / elementwise
  * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the

@@ -2,7 +2,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aod_meh_hua_amd import hipops as ho
-B = 16
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
 segs, r = [], 0
 for h, w in sizes:
@@ -25,6 +25,10 @@ def timeit(fn, name, flops):
     print(f'{name:6s} {us:8.1f} us  {flops / us / 1e6:7.1f} TF')
 fl = 2.0 * M * 256 * 2304
 if which in ('all', 'fwd'): timeit(lambda: ho.conv2d_rows(x, segs, wp, 256, 3, 3, 1, 1, 1, relu=True), 'fwd', fl)
+if which == 'fwd1':
+    w1 = torch.randn(256, 256, 1, 1, device='cuda') * 0.02
+    wp1 = ho.pack_weight_fwd(w1)
+    timeit(lambda: ho.conv2d_rows(x, segs, wp1, 256, 1, 1, 1, 0, 1, relu=True), 'fwd1', 2.0 * M * 256 * 256)
 if which in ('all', 'dgrad'): timeit(lambda: ho.conv2d_dgrad_rows(dz, segs, segs, wd, 256, 3, 3, 1, 1, 1), 'dgrad', fl)
 if which in ('all', 'wgrad'):
     def f():
