@@ -22,6 +22,7 @@ struct ConvKParams {
   const bf16_t* mask;
   const float* post_scale;
   bf16_t* zraw;
+  float* colsum;      // optional fp32 [N]: += column sums of the stored values (fused bias / BN-shift gradient in dgrad launches)
   int C, N, K, R, S, stride, pad, dil, transposed, relu, out_f32;
   int nseg, M;
   int tiles_m, tiles_n;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
     }
   }
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int it = 0; it < E_IT; ++it) {
     const int row = er + it * (256 / NCH);
@@ -264,6 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum[j] += v[j];
       if (p.out_f32) {
         float* o = reinterpret_cast<float*>(p.y) + off;
         if ((p.N & 3) == 0) {
@@ -295,10 +299,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         if (p.mask) u = ((float)p.mask[off] > 0.f) ? u : 0.f;
         if (p.post_scale) u *= p.post_scale[n + j];
         if (p.relu) u = fmaxf(u, 0.f);
+        csum[j] += u;
         if (p.out_f32) reinterpret_cast<float*>(p.y)[off] = u;
         else reinterpret_cast<bf16_t*>(p.y)[off] = (bf16_t)u;
         if (p.zraw) p.zraw[off] = (bf16_t)raw[j];
       }
+    }
+  }
+  if (p.colsum) {
+    // column sums of this tile: per-thread partials -> LDS [256 / NCH][BN] -> one fp32 atomic per column
+    __syncthreads();
+    float* sr = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sr[er * BN + ec * 8 + j] = csum[j];
+    __syncthreads();
+    if (t < BN && n0 + t < p.N) {
+      float s = 0.f;
+      for (int r = 0; r < 256 / NCH; ++r) s += sr[r * BN + t];
+      atomicAdd(p.colsum + n0 + t, s);
     }
   }
 }
@@ -352,7 +370,7 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
 
 extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
                           const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
-                          const float* post_scale, void* zraw, aod_stream_t stream) {
+                          const float* post_scale, void* zraw, float* colsum, aod_stream_t stream) {
   AOD_CHECK_ARG(desc && src && w_packed && dst, "conv: null pointer");
   ConvKParams p;
   memset(&p, 0, sizeof(p));
@@ -362,7 +380,7 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   if (p.M == 0) return 0;
   p.x = (const bf16_t*)src; p.w = (const bf16_t*)w_packed; p.y = dst;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
-  p.post_scale = post_scale; p.zraw = (bf16_t*)zraw;
+  p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
   long long xrows = 0;
   for (int i = 0; i < desc->nseg; ++i) {
     const aod_conv_seg_t& sg = desc->seg[i];

@@ -88,6 +88,20 @@ def fold_bn(gamma, beta, mean, var, eps):
 
 
 # --------------------------------------------------------------------------- conv (+BN/bias, +res, +ReLU)
+import os as _os
+_FUSE_ACT = _os.environ.get('AOD_FUSE_ACT', '1') != '0'      # debug switch for A/B timing
+
+
+class ActSlot:
+    """Side channel between a conv and the ONE conv that consumes its ReLU output.  The consumer's dgrad epilogue applies the producer's
+    ReLU mask and sums the columns (aod_conv2d res / mask / colsum), so the producer's backward receives the finished masked gradient and
+    its bias / BN-shift gradient instead of running an elementwise pass over the activation."""
+    __slots__ = ('masked', 's1')
+
+    def __init__(self):
+        self.masked, self.s1 = False, None
+
+
 class ConvFn(Function):
     """y = act(conv(x, w) * scale + shift + res) over one or several pyramid levels sharing `w`.
 
@@ -156,10 +170,15 @@ class ConvFn(Function):
             # materialised: the scale is folded into the dgrad weights and into the unpack of dW.  BN gradients (eval-mode statistics):
             #   dbeta = S1,   dgamma = invstd * (sum_m gm*z - mean*S1),   sum_m gm[m,n]*z[m,n] = <w[n], dW_gm[n]>   (z = <w[n], patch(m)>)
             relu = meta['relu']
-            plain = (not relu) and g_rows.dtype == torch.bfloat16
-            dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=False, want_dz=not plain)
-            if plain:
-                dz = g_rows
+            slot = meta.get('slot')
+            if slot is not None and slot.masked and g_rows.dtype == torch.bfloat16:
+                dz, s1 = g_rows, slot.s1                      # the consumer's dgrad epilogue already did the activation backward
+                slot.masked, slot.s1 = False, None
+            else:
+                plain = (not relu) and g_rows.dtype == torch.bfloat16
+                dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=False, want_dz=not plain)
+                if plain:
+                    dz = g_rows
             gbias_v = s1
         need_bn = ctx.has_bn and ctx.needs_input_grad[2]
         if ctx.has_bias and ctx.needs_input_grad[6]:
@@ -187,21 +206,39 @@ class ConvFn(Function):
             if I != cin:   # stem: channel-padded input; dX only for the real channels is never needed (image)
                 raise RuntimeError('dgrad through a channel-padded input is not supported')
             xd = dense_segs(x_segs)
-            dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'])
+            in_slot = meta.get('in_slot')
+            fuse = in_slot is not None and all(a.row0 == b.row0 for a, b in zip(x_segs, xd)) and all(ctx.needs_input_grad[8:])
+            s1_in = torch.zeros(cin, dtype=torch.float32, device=dz.device) if fuse else None
+            dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
+                                      mask=x_rows if fuse else None, colsum=s1_in)
+            if fuse:
+                in_slot.masked, in_slot.s1 = True, s1_in
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
                    for i, s in enumerate(xd)]
         return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
 
 
-def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None):
-    """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps."""
+def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False):
+    """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps.
+    sole_consumer: the caller guarantees that every x is the ReLU output of a conv_bn_act call and feeds NOTHING but this conv, which
+    lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot)."""
     single = torch.is_tensor(xs)
     xl = [xs] if single else list(xs)
     meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out)
+    if torch.is_grad_enabled():
+        if relu and not out_f32 and res is None:
+            meta['slot'] = ActSlot()
+        if sole_consumer and _FUSE_ACT:
+            slots = [getattr(x, '_aod_slot', None) for x in xl]
+            if slots[0] is not None and all(sl is slots[0] for sl in slots):
+                meta['in_slot'] = slots[0]
     if bn is not None:
         outs = ConvFn.apply(meta, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, res, *xl)
     else:
         outs = ConvFn.apply(meta, w, None, None, None, None, bias, res, *xl)
+    if meta.get('slot') is not None:
+        for o in outs:
+            o._aod_slot = meta['slot']
     return outs[0] if single else list(outs)
 
 

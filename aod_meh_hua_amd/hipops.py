@@ -102,20 +102,21 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
     _prof('fwd', d, lambda: call('aod_conv2d', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
-                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), stream()))
+                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, stream()))
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
 def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,
-                      post_scale=None, out=None, x_rows_total=None):
-    """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad]."""
+                      post_scale=None, out=None, x_rows_total=None, colsum=None):
+    """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad].
+    res / mask / colsum: fused activation backward of the producer of x (see aod_conv2d)."""
     Npad = dz_rows.shape[1]
     rows = x_rows_total if x_rows_total is not None else sum(s.rows for s in x_segs)
     if out is None:
         out = torch.empty(rows, Cin, dtype=torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
     _prof('dgrad', d, lambda: call('aod_conv2d', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
-                                   ptr(post_scale), None, stream()))
+                                   ptr(post_scale), None, ptr(colsum), stream()))
     return out
 
 

@@ -60,18 +60,19 @@ class Lambda_L2Net(L_AnchorHead):
         """Lambda_L2.py:79-94, all levels per launch.  Returns (cls_scores[L], bbox_preds[L]) fp32 [B, A*C, h, w]."""
         feats = list(feats)
         cls_feat, reg_feat = feats, feats
-        for conv in self.cls_convs:
-            cls_feat = conv(cls_feat)
-        for conv in self.reg_convs:
-            reg_feat = conv(reg_feat)
-        return self.retina_cls(cls_feat, out_f32=True), self.retina_reg(reg_feat, out_f32=True)
+        for i, conv in enumerate(self.cls_convs):          # every tower activation has exactly one consumer (the next conv)
+            cls_feat = conv(cls_feat, sole_consumer=i > 0)
+        for i, conv in enumerate(self.reg_convs):
+            reg_feat = conv(reg_feat, sole_consumer=i > 0)
+        return (self.retina_cls(cls_feat, out_f32=True, sole_consumer=len(self.cls_convs) > 0),
+                self.retina_reg(reg_feat, out_f32=True, sole_consumer=len(self.reg_convs) > 0))
 
     def forward_L(self, feats, head_out=None, **kwargs):
         """Lambda_L2.py:82-83,96-103: MEH tower + retina_L + ReLU (fused)."""
         L_feat = list(feats)
-        for conv in self.L_convs:
-            L_feat = conv(L_feat)
-        return self.retina_L(L_feat, relu=True, out_f32=True)
+        for i, conv in enumerate(self.L_convs):
+            L_feat = conv(L_feat, sole_consumer=i > 0)
+        return self.retina_L(L_feat, relu=True, out_f32=True, sole_consumer=len(self.L_convs) > 0)
 
     def forward_single(self, x):
         c, r = self.forward([x])

@@ -57,11 +57,15 @@ typedef struct {
  *   into pre_scale/pre_shift), mmdet/models/necks/fpn.py:156-202,
  *   mmdet/models/dense_heads/Lambda_L2.py:85-103.
  * v = acc * pre_scale[n] + pre_shift[n] + res[m][n]; if (mask) v = mask[m][n] > 0 ? v : 0;
- * v *= post_scale[n]; if (relu) v = max(v, 0); dst[m][n] = v; optional zraw[m][n] = acc (bf16).
- * Any of pre_scale/pre_shift/res/mask/post_scale/zraw may be NULL. */
+ * v *= post_scale[n]; if (relu) v = max(v, 0); dst[m][n] = v; optional zraw[m][n] = acc (bf16);
+ * optional colsum[n] += sum_m v (fp32 atomics).  In a dgrad launch res / mask / colsum fuse the ACTIVATION backward
+ * of the layer below into the epilogue: dst = (dX + res) * [mask > 0] is the masked gradient w.r.t. that layer's
+ * pre-activation output and colsum its bias / BN-shift gradient (the autograd chain of Lambda_L2.py:85-94 and
+ * resnet.py:262-301 without a separate elementwise pass).
+ * Any of pre_scale/pre_shift/res/mask/post_scale/zraw/colsum may be NULL. */
 int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
                const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
-               const float* post_scale, void* zraw, aod_stream_t stream);
+               const float* post_scale, void* zraw, float* colsum, aod_stream_t stream);
 
 /* replaces: the weight-gradient half of autograd's conv backward (cuDNN wgrad) for the same
  * call sites.  dw_f32 is [N][R][S][C] fp32 and is ACCUMULATED into (caller zeroes it);

@@ -37,7 +37,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     d.C, d.N, d.R, d.S, d.stride, d.pad, d.dil, d.nseg = 12, 64, 3, 3, 1, 1, 1, 1      # C not a multiple of 8
     one = ctypes.c_void_p(16)
     lib.aod_conv2d.restype = ctypes.c_int
-    rc = lib.aod_conv2d(ctypes.byref(d), one, one, one, None, None, None, None, None, None, None)
+    rc = lib.aod_conv2d(ctypes.byref(d), one, one, one, None, None, None, None, None, None, None, None)
     assert rc == -1
     lib.aod_last_error.restype = ctypes.c_char_p
     assert b'multiple of 8' in lib.aod_last_error()
