@@ -96,10 +96,13 @@ class ActSlot:
     """Side channel between a conv and the ONE conv that consumes its ReLU output.  The consumer's dgrad epilogue applies the producer's
     ReLU mask and sums the columns (aod_conv2d res / mask / colsum), so the producer's backward receives the finished masked gradient and
     its bias / BN-shift gradient instead of running an elementwise pass over the activation."""
-    __slots__ = ('masked', 's1')
+    __slots__ = ('masked', 's1', 'res_ok', 'res_grad')
 
     def __init__(self):
         self.masked, self.s1 = False, None
+        # residual form (ResNet identity blocks): the activation also feeds the `res` input of a later conv; that conv leaves its
+        # residual gradient here instead of returning it, and the consuming conv's dgrad epilogue adds it before masking
+        self.res_ok, self.res_grad = False, None
 
 
 class ConvFn(Function):
@@ -184,8 +187,12 @@ class ConvFn(Function):
         if ctx.has_bias and ctx.needs_input_grad[6]:
             gbias = gbias_v[:O]
         if need_res:
-            s = y_segs[0]
-            gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
+            res_slot = meta.get('res_slot')
+            if res_slot is not None:
+                res_slot.res_grad = dz                  # picked up by the dgrad epilogue of the conv that consumes the same activation
+            else:
+                s = y_segs[0]
+                gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
         x_segs = ctx.x_segs
         if need_w or need_bn:
             dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'])
@@ -209,10 +216,13 @@ class ConvFn(Function):
             in_slot = meta.get('in_slot')
             fuse = in_slot is not None and all(a.row0 == b.row0 for a, b in zip(x_segs, xd)) and all(ctx.needs_input_grad[8:])
             s1_in = torch.zeros(cin, dtype=torch.float32, device=dz.device) if fuse else None
+            res_g = in_slot.res_grad if in_slot is not None else None
+            if res_g is not None and not fuse:
+                raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')
             dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
-                                      mask=x_rows if fuse else None, colsum=s1_in)
+                                      res=res_g, mask=x_rows if fuse else None, colsum=s1_in)
             if fuse:
-                in_slot.masked, in_slot.s1 = True, s1_in
+                in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
                    for i, s in enumerate(xd)]
         return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
@@ -221,17 +231,24 @@ class ConvFn(Function):
 def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False):
     """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps.
     sole_consumer: the caller guarantees that every x is the ReLU output of a conv_bn_act call and feeds NOTHING but this conv, which
-    lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot)."""
+    lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot).  sole_consumer='res': x additionally feeds
+    the `res` input of ONE later conv_bn_act call (ResNet identity block), whose residual gradient is then routed through this conv."""
     single = torch.is_tensor(xs)
     xl = [xs] if single else list(xs)
     meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out)
     if torch.is_grad_enabled():
-        if relu and not out_f32 and res is None:
+        if relu and not out_f32:
             meta['slot'] = ActSlot()
         if sole_consumer and _FUSE_ACT:
             slots = [getattr(x, '_aod_slot', None) for x in xl]
-            if slots[0] is not None and all(sl is slots[0] for sl in slots):
-                meta['in_slot'] = slots[0]
+            if slots[0] is not None and all(sl is slots[0] for sl in slots) and all(x.requires_grad for x in xl):
+                if sole_consumer != 'res' or len(xl) == 1:
+                    meta['in_slot'] = slots[0]
+                    slots[0].res_ok = sole_consumer == 'res'
+        rs = getattr(res, '_aod_slot', None) if res is not None else None
+        if rs is not None and rs.res_ok:
+            meta['res_slot'] = rs
+            rs.res_ok = False                      # exactly one residual consumer
     if bn is not None:
         outs = ConvFn.apply(meta, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, res, *xl)
     else:
