@@ -19,6 +19,7 @@ class FusedSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        touched = []
         for group in self.param_groups:
             ps, gs, ms, ns, first = [], [], [], [], None
             for p in group['params']:
@@ -36,7 +37,12 @@ class FusedSGD(torch.optim.Optimizer):
                     self._launch(ps, gs, ms, ns, group, first)
                     ps, gs, ms, ns, first = [], [], [], [], is_first
                 ps.append(p.data_ptr()), gs.append(g.data_ptr()), ms.append(st['momentum_buffer'].data_ptr()), ns.append(p.numel())
+                touched.append(p)
             self._launch(ps, gs, ms, ns, group, first)
+        # the kernel writes through raw pointers: tell autograd / the packed-weight cache (functional._VersionCache keys on
+        # tensor._version) that these parameters changed, without one no-op kernel per tensor
+        if touched:
+            torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])
 
     def _launch(self, ps, gs, ms, ns, group, first):
         n = len(ps)
