@@ -679,8 +679,9 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, const float* __
 // With y = (z - mean) * invstd * gamma + beta and z = <w[o], patch>, the BN-scale gradient needs sum_m gm[m,o] * z[m,o]
 // = <w[o], sum_m gm[m,o] * patch(m)> = <w[o], dW_gm[o]>: the pre-BN activations never have to be stored or re-read.
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ dw, float* __restrict__ g, const float* __restrict__ scale,
-                                                          const float* __restrict__ w, float* __restrict__ wdot, int O, int I, int RS, int Ipad,
-                                                          int accumulate, int clear) {
+                                                          const float* __restrict__ w, float* __restrict__ wdot, const float* __restrict__ bn_s1,
+                                                          const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd, int O, int I,
+                                                          int RS, int Ipad, int accumulate, int clear) {
   __shared__ float red[4];
   const int oo = blockIdx.x;
   const int n = I * RS;
@@ -699,7 +700,10 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ d
     dot = wave_sum(dot);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) wdot[oo] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+      const float d = red[0] + red[1] + red[2] + red[3];
+      wdot[oo] = bn_s1 ? bn_invstd[oo] * (d - bn_mean[oo] * bn_s1[oo]) : d;      // BN weight gradient when the statistics are given
+    }
   }
 }
 static inline int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -717,11 +721,14 @@ extern "C" int aod_pack_weight_dgrad(const float* w, void* o, int O, int I, int 
   return 0;
 }
 extern "C" int aod_unpack_wgrad(float* dw, float* g, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src, const float* scale,
-                                const float* w_oihw, float* wdot, aod_stream_t stream) {
+                                const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean, const float* bn_invstd,
+                                aod_stream_t stream) {
   AOD_CHECK_ARG(dw && g, "unpack_wgrad: null");
   AOD_CHECK_ARG(!wdot || w_oihw, "unpack_wgrad: wdot needs the weights");
+  AOD_CHECK_ARG(!bn_s1 || (wdot && bn_mean && bn_invstd), "unpack_wgrad: BN mode needs wdot, mean and invstd");
   if (O == 0) return 0;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, dw, g, scale, w_oihw, wdot, O, I, R * S, Ipad, accumulate, clear_src);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, dw, g, scale, w_oihw, wdot, bn_s1, bn_mean, bn_invstd, O, I,
+                     R * S, Ipad, accumulate, clear_src);
   AOD_LAUNCH_CHECK();
   return 0;
 }

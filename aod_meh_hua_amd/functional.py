@@ -197,8 +197,7 @@ class ConvFn(Function):
         if need_w or need_bn:
             dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'])
             if need_bn:
-                gw, wdot = ho.unpack_wgrad(dw, O, I, scale=scale, w_oihw=w.detach().float(), want_wdot=True)
-                ggamma = (invstd * (wdot - mean.float() * s1)).to(gamma.dtype)
+                gw, ggamma = ho.unpack_wgrad(dw, O, I, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
                 gbeta = s1
             else:
                 gw = ho.unpack_wgrad(dw, O, I, scale=scale if ctx.has_bn else None)
@@ -215,7 +214,7 @@ class ConvFn(Function):
             xd = dense_segs(x_segs)
             in_slot = meta.get('in_slot')
             fuse = in_slot is not None and all(a.row0 == b.row0 for a, b in zip(x_segs, xd)) and all(ctx.needs_input_grad[8:])
-            s1_in = torch.zeros(cin, dtype=torch.float32, device=dz.device) if fuse else None
+            s1_in = ho.zeros_f32(cin, dz.device) if fuse else None
             res_g = in_slot.res_grad if in_slot is not None else None
             if res_g is not None and not fuse:
                 raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')

@@ -151,8 +151,25 @@ def _dw_scratch(n, device):
     return buf[:n]
 
 
-def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False):
-    """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot."""
+_ZEROS = {}
+
+
+def zeros_f32(n, device):
+    """An all-zero fp32 vector carved out of a per-device arena (one fill per ~64K floats instead of one tiny fill launch per
+    accumulator).  Slices are handed out once and never reused, so they may be kept as gradients."""
+    n_al = (n + 63) // 64 * 64
+    ar = _ZEROS.get(device)
+    if ar is None or ar[1] + n_al > ar[0].numel():
+        ar = [torch.zeros(max(1 << 16, n_al), dtype=torch.float32, device=device), 0]
+        _ZEROS[device] = ar
+    out = ar[0][ar[1]:ar[1] + n]
+    ar[1] += n_al
+    return out
+
+
+def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None):
+    """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot; with bn = (s1, mean, invstd) wdot is the
+    BatchNorm weight gradient invstd * (<w, dw> - mean * s1)."""
     Opad, R, S, Ipad = dw_orsi.shape
     if grad_oihw is None:
         grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
@@ -164,7 +181,8 @@ def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, sc
         pass
     wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
     call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), int(bool(clear)), ptr(scale),
-         ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), stream())
+         ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
+         ptr(bn[2]) if bn else None, stream())
     return (grad_oihw, wdot) if want_wdot else grad_oihw
 
 
@@ -212,8 +230,8 @@ def act_bwd(g, a=None, z=None, scale=None, mean=None, invstd=None, relu=True, wa
     M, N = g.shape
     dz = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_dz else None
     gm = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_gm else None
-    dbeta = torch.zeros(N, dtype=torch.float32, device=g.device)
-    dgamma = torch.zeros(N, dtype=torch.float32, device=g.device) if z is not None else None
+    dbeta = zeros_f32(N, g.device)
+    dgamma = zeros_f32(N, g.device) if z is not None else None
     call('aod_act_bwd', ptr(g), ptr(a), ptr(z), ptr(scale), ptr(mean), ptr(invstd), ptr(dz), ptr(gm), ptr(dbeta),
          ptr(dgamma), M, N, int(relu), int(g.dtype == torch.float32), stream())
     return dz, gm, dbeta, dgamma
@@ -224,7 +242,7 @@ def edl_focal_l1_fwd(cls, labels, label_w, bbox_pred=None, bbox_tgt=None, bbox_w
     rows, Cc = cls.shape
     loss_noR = torch.empty(rows, dtype=torch.float32, device=cls.device)
     if sums is None:
-        sums = torch.zeros(3, dtype=torch.float32, device=cls.device)
+        sums = zeros_f32(3, cls.device)
     part = torch.empty(max(int(_C.lib.aod_loss_partials_len(rows)), 1), dtype=torch.float32, device=cls.device)
     call('aod_edl_focal_l1_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
          gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream())
@@ -250,7 +268,7 @@ def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g
 def meh_loss_fwd(lam, loss_noR, bbox_w4, out_sum=None):
     n = lam.numel()
     if out_sum is None:
-        out_sum = torch.zeros(1, dtype=torch.float32, device=lam.device)
+        out_sum = zeros_f32(1, lam.device)
     part = torch.empty(max(int(_C.lib.aod_loss_partials_len(n)), 1), dtype=torch.float32, device=lam.device)
     call('aod_meh_loss_fwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), n, ptr(out_sum), ptr(part), stream())
     return out_sum
@@ -269,7 +287,7 @@ def pad_cast_colsum(g, npad, relu_out=None):
     M, N = g.shape
     assert relu_out is None or relu_out.dtype == torch.float32
     dz = torch.empty(M, npad, dtype=torch.bfloat16, device=g.device)
-    cs = torch.zeros(npad, dtype=torch.float32, device=g.device)
+    cs = zeros_f32(npad, g.device)
     call('aod_pad_cast_colsum', ptr(g), ptr(relu_out), ptr(dz), ptr(cs), M, N, npad, int(g.dtype == torch.float32), stream())
     return dz, cs
 

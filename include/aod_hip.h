@@ -86,10 +86,12 @@ int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int
                           aod_stream_t stream);
 /* [Opad][R][S][Ipad] fp32 (wgrad result) -> OIHW fp32 gradient (first O rows / I channels), times scale[o] when given;
  * accumulate != 0 adds; clear_src != 0 zeroes every element it reads, so a persistent accumulator is all-zero again.
- * wdot (nullable, fp32 [O], overwritten) receives <w_oihw[o], dw[o]> = sum_m gm[m,o] * z[m,o]: the BatchNorm weight
- * gradient of an eval-mode BN behind the conv (resnet.py:262-301) without keeping the pre-BN activations z. */
+ * wdot (nullable, fp32 [O], overwritten) receives <w_oihw[o], dw[o]> = sum_m gm[m,o] * z[m,o]; with bn_s1 (= sum_m gm[m,o]),
+ * bn_mean and bn_invstd it receives invstd * (that - mean * s1) instead: the weight gradient of the eval-mode BatchNorm behind
+ * the conv (resnet.py:262-301) without keeping the pre-BN activations z. */
 int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src,
-                     const float* scale, const float* w_oihw, float* wdot, aod_stream_t stream);
+                     const float* scale, const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean,
+                     const float* bn_invstd, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ layout / elementwise
  * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the
