@@ -55,14 +55,27 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
     prog_bar = ProgressBar(hi - lo)
     chunks = []
     kwargs.setdefault('scaleUnc', False)
+    # HIP-graph replay of the scoring batch (graphs.GraphedScore) while batches keep one shape; side-effect options stay eager
+    import os
+    plain = not any(kwargs.get(k) for k in ('showNMS', 'saveUnc', 'saveMaxConf', 'scaleUnc', 'draw'))
+    gscore = None
+    if plain and os.environ.get('AOD_HIP_GRAPH', '1') != '0' and next(model.parameters()).is_cuda:
+        from ..graphs import GraphedScore
+        gscore = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
     for s in range(lo, hi, bs):
         idxs = list(range(s, min(s + bs, hi)))
         data = collate([dataset[i] for i in idxs])
         data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
         dev = next(model.parameters()).device
         image_ids = torch.tensor(idxs, dtype=torch.int64).to(dev, non_blocking=True)
-        with torch.no_grad():
-            result, unc, *others = model(return_loss=False, rescale=True, isEval=False, batchIdx=s // bs, image_ids=image_ids, **data, **kwargs)
+        out = None
+        if gscore is not None and isinstance(data['img'], (list, tuple)) and len(data['img']) == 1:
+            out = gscore.maybe(data['img'][0], data['img_metas'][0], image_ids)
+        if out is not None:
+            result, unc = out
+        else:
+            with torch.no_grad():
+                result, unc, *others = model(return_loss=False, rescale=True, isEval=False, batchIdx=s // bs, image_ids=image_ids, **data, **kwargs)
         chunks.append(torch.as_tensor(unc, dtype=torch.float32, device=dev).reshape(-1))
         prog_bar.update(len(idxs))
     dev = next(model.parameters()).device

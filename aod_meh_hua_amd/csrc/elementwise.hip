@@ -237,8 +237,9 @@ struct SgdChunk {
   long long n[48];
   int count;
 };
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int blocks_per_tensor, float lr, float momentum, float wd,
-                                                        int first_step, float grad_scale) {
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int blocks_per_tensor, float lr_arg, const float* __restrict__ lr_dev,
+                                                        float momentum, float wd, int first_step, float grad_scale) {
+  const float lr = lr_dev ? *lr_dev : lr_arg;      // device-resident learning rate: a captured launch follows the schedule
   const int ti = blockIdx.x / blocks_per_tensor, bi = blockIdx.x % blocks_per_tensor;
   float* p = c.p[ti];
   const float* g = c.g[ti];
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int bl
   }
 }
 extern "C" int aod_sgd_multi(void* const* params, void* const* grads, void* const* moms, const int64_t* sizes, int ntensors,
-                             float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream) {
+                             float lr, const float* lr_dev, float momentum, float weight_decay, int first_step, float grad_scale,
+                             aod_stream_t stream) {
   AOD_CHECK_ARG(params && grads && moms && sizes && ntensors >= 0, "sgd_multi: bad args");
   for (int s0 = 0; s0 < ntensors; s0 += 48) {
     SgdChunk c;
@@ -267,7 +269,7 @@ extern "C" int aod_sgd_multi(void* const* params, void* const* grads, void* cons
     int bpt = (int)((mx + 256 * 16 - 1) / (256 * 16));
     if (bpt < 1) bpt = 1;
     if (bpt > 96) bpt = 96;
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3(c.count * bpt), dim3(256), 0, (hipStream_t)stream, c, bpt, lr, momentum, weight_decay, first_step, grad_scale);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(c.count * bpt), dim3(256), 0, (hipStream_t)stream, c, bpt, lr, lr_dev, momentum, weight_decay, first_step, grad_scale);
   }
   AOD_LAUNCH_CHECK();
   return 0;

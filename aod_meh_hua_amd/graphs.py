@@ -1,0 +1,230 @@
+"""HIP-graph replay of the two fixed-shape inner loops of the active-learning cycle.
+
+A training iteration (`MyEpochBasedRunnerLambda.run_iter`, Epoch_Based_Runner_Lambda.py:20-38) enqueues ~700 kernels; on MI355X they
+take ~20 ms while the Python that launches them takes about as long, so the GPU work is captured once per input shape
+(`torch.cuda.CUDAGraph` == hipGraph on ROCm) and replayed:
+
+  GraphedTrainStep   main forward / backward / SGD step + MEH forward / backward / SGD step.  One graph on a single GPU; with
+                     data parallelism three graphs with the two eager gradient all-reduces (parallel.GradSync) between them.
+  GraphedScore       one batch of the HUA scoring pass (`calculate_uncertainty`, apis/test.py:65-135).
+
+Both keep STATIC input buffers (image batch, packed ground truth, image ids); a call copies the new batch in and replays.  Rules the
+captured code obeys: no host<->device copies, no `.item()`, every accumulator is zeroed inside the graph, learning rates live in device
+memory (FusedSGD.device_lr), and after a replay the versions of the updated parameters are bumped so that eager code (evaluation,
+checkpoints) rebuilds its packed weights."""
+import torch
+
+from . import hipops as ho
+
+torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # warm-up runs on a side stream by design
+from .models.dense_heads.L_anchor_head import PackedGT
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, 'module') else model
+
+
+def _plain(data, dev):
+    """DataContainer batch (runner) or plain dict (bench / tests) -> plain dict; tensors stay where they are (the image is copied into the
+    static device buffer, ground truth is packed on the host)."""
+    from .mmcv_lite import DataContainer
+
+    def un(x):
+        if isinstance(x, DataContainer):
+            d = x.data
+            return d[0] if isinstance(d, list) and len(d) == 1 else d
+        return x
+    return {k: un(v) for k, v in data.items()}
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, optimizer_L, grad_sync=None, gmax=64, warmup=2, **step_kwargs):
+        self.model, self.module = model, _unwrap(model)
+        self.opt, self.opt_L, self.sync = optimizer, optimizer_L, grad_sync
+        self.gmax, self.warmup, self.kw = gmax, warmup, step_kwargs
+        self.sig, self.graphs, self.static = None, None, None
+        self.dev = next(self.module.parameters()).device
+
+    # ------------------------------------------------------------------ input staging
+    def _signature(self, d):
+        return (tuple(d['img'].shape), tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in d['img_metas']))
+
+    def _load(self, d):
+        st = self.static
+        st['img'].copy_(d['img'], non_blocking=True)
+        B, G = st['gts'].shape[:2]
+        # fresh pinned staging every call: the copies below are asynchronous, and torch's caching host allocator only recycles a pinned
+        # block once the copy that read it has completed (re-using one fixed buffer races with the next call's host writes)
+        hg, hl = torch.zeros(B, G, 4, pin_memory=True), torch.zeros(B, G, dtype=torch.long, pin_memory=True)
+        hc = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+        for b, (bb, ll) in enumerate(zip(d['gt_bboxes'], d['gt_labels'])):
+            n = int(bb.shape[0])
+            if n > G:
+                raise ValueError(f'{n} ground-truth boxes in one image exceed the graph capacity gmax={G}')
+            hc[b] = n
+            if n:
+                hg[b, :n] = bb.detach().float().cpu() if bb.device.type != 'cpu' else bb.float()
+                hl[b, :n] = ll.detach().long().cpu() if ll.device.type != 'cpu' else ll.long()
+        st['gts'].copy_(hg, non_blocking=True), st['counts'].copy_(hc, non_blocking=True), st['labs'].copy_(hl, non_blocking=True)
+
+    def _alloc(self, d):
+        B, dev, G = d['img'].shape[0], self.dev, self.gmax
+        self.static = dict(img=torch.empty(tuple(d['img'].shape), dtype=torch.float32, device=dev),
+                           gts=torch.zeros(B, G, 4, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
+                           labs=torch.zeros(B, G, dtype=torch.long, device=dev), metas=[dict(m) for m in d['img_metas']])
+
+    # ------------------------------------------------------------------ the three segments of run_iter
+    def _seg_a(self):
+        st = self.static
+        data = dict(img=st['img'], img_metas=st['metas'], gt_bboxes=PackedGT((st['gts'], st['counts'], st['labs'])), gt_labels=None)
+        out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
+        self.opt.zero_grad()
+        out['loss'].backward()
+        self.live = (out, head_out, feat_out, prev)
+
+    def _seg_b(self):
+        out, head_out, feat_out, prev = self.live
+        self.opt.step()
+        loss_L = self.module.train_step_L(prev, head_out, feat_out, **self.kw)
+        self.opt_L.zero_grad()
+        loss_L['loss'].backward()
+        self.live_L = loss_L
+
+    def _seg_c(self):
+        self.opt_L.step()
+
+    def _params(self, opt):
+        return [p for g in opt.param_groups for p in g['params']]
+
+    def _run_eager(self):
+        self._seg_a()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self._params(self.opt))
+        self._seg_b()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self._params(self.opt_L))
+        self._seg_c()
+
+    def _build(self, d):
+        from .parallel import is_dist
+        self.live = self.live_L = None
+        self._alloc(d)
+        self._load(d)
+        self.opt.device_lr(), self.opt_L.device_lr()
+        self.module.train()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._run_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ho.reset_zero_arena()                     # accumulators handed out during capture must be zeroed INSIDE the graph
+        segs = [self._seg_a, self._seg_b, self._seg_c]
+        self.graphs = []
+        if self.sync is None or not is_dist():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for f in segs:
+                    f()
+            self.graphs.append(g)
+        else:
+            pool = torch.cuda.graph_pool_handle()
+            for f in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    f()
+                self.graphs.append(g)
+        ho.reset_zero_arena()
+        self.touched = self._params(self.opt) + self._params(self.opt_L)
+
+    # ------------------------------------------------------------------ call
+    def maybe(self, data_batch):
+        """Replay when this input shape was also the previous call's shape (capture on its second consecutive appearance); otherwise
+        return None and let the caller run the iteration eagerly (multi-scale data would re-capture on every batch)."""
+        d = _plain(data_batch, self.dev)
+        sig = self._signature(d)
+        if sig != self.sig and sig != getattr(self, 'pending', None):
+            self.pending = sig
+            return None
+        return self(data_batch)
+
+    def __call__(self, data_batch):
+        d = _plain(data_batch, self.dev)
+        sig = self._signature(d)
+        if sig != self.sig:
+            self.graphs = None
+            self._build(d)
+            self.sig = sig
+        self._load(d)
+        self.opt.device_lr(), self.opt_L.device_lr()
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            self.sync.all_reduce_grads(self._params(self.opt))
+            self.graphs[1].replay()
+            self.sync.all_reduce_grads(self._params(self.opt_L))
+            self.graphs[2].replay()
+        tp = [p for p in self.touched if p.grad is not None]
+        torch._C._autograd._unsafe_set_version_counter(tp, [p._version + 1 for p in tp])
+        out, loss_L = self.live[0], self.live_L
+        log_vars = type(out['log_vars'])((k, v.clone()) for k, v in out['log_vars'].items())     # static tensors: hand out copies
+        log_vars.update((k, v.clone()) for k, v in loss_L['log_vars'].items())
+        return dict(loss=out['loss'].detach().clone(), log_vars=log_vars, num_samples=out['num_samples'])
+
+
+class GraphedScore:
+    """One HUA scoring batch: model(img=[img], img_metas=[metas], image_ids=ids, **kw) under no_grad -> unc [B] (a copy)."""
+
+    def __init__(self, model, warmup=2, **score_kwargs):
+        self.model, self.module = model, _unwrap(model)
+        self.kw, self.warmup = score_kwargs, warmup
+        self.sig, self.graph = None, None
+        self.dev = next(self.module.parameters()).device
+
+    def _run(self):
+        with torch.no_grad():
+            res = self.module(img=[self.img], img_metas=[self.metas], return_loss=False, image_ids=self.ids, **self.kw)
+        self.out = res
+
+    @staticmethod
+    def _signature(img, img_metas):
+        return (tuple(img.shape), tuple((tuple(m['img_shape']), tuple(float(v) for v in torch.as_tensor(m['scale_factor']).reshape(-1)))
+                                        for m in img_metas))
+
+    def maybe(self, img, img_metas, image_ids):
+        """Replay if (shape, image sizes, scale factors) repeat from the previous batch, else None (caller scores eagerly)."""
+        sig = self._signature(img, img_metas)
+        if sig != self.sig and sig != getattr(self, 'pending', None):
+            self.pending = sig
+            return None
+        return self(img, img_metas, image_ids)
+
+    def __call__(self, img, img_metas, image_ids):
+        sig = self._signature(img, img_metas)
+        if sig != self.sig:
+            self.graph = None
+            self.img = torch.empty(tuple(img.shape), dtype=torch.float32, device=self.dev)
+            self.ids = torch.zeros(img.shape[0], dtype=torch.int64, device=self.dev)
+            self.metas = [dict(m) for m in img_metas]
+            self.img.copy_(img), self.ids.copy_(image_ids)
+            self.module.eval()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ho.reset_zero_arena()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._run()
+            ho.reset_zero_arena()
+            self.sig = sig
+        self.img.copy_(img, non_blocking=True)
+        self.ids.copy_(image_ids, non_blocking=True)
+        self.graph.replay()
+        unc = self.out[1]
+        return self.out[0], (unc.clone() if torch.is_tensor(unc) else unc)

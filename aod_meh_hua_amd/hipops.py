@@ -167,6 +167,12 @@ def zeros_f32(n, device):
     return out
 
 
+def reset_zero_arena():
+    """Drop the current arena: the next zeros_f32 call allocates (and fills) a fresh one.  Used around HIP-graph capture so that every
+    accumulator used by captured kernels is zeroed by a captured fill."""
+    _ZEROS.clear()
+
+
 def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None):
     """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot; with bn = (s1, mean, invstd) wdot is the
     BatchNorm weight gradient invstd * (<w, dw> - mean * s1)."""

@@ -19,8 +19,18 @@ _NO_SAMPLING = ['EDL_Loss', 'EDL_Loss_2', 'EDL_Loss_3', 'EDL_Loss_BCE', 'FocalLo
                 'EDL_Softmax_SL_FocalLoss', 'SSL_EDL_Softmax_FocalLoss']
 
 
+class PackedGT(tuple):
+    """(gts [B,Gmax,4] f32, counts [B] int32, labels [B,Gmax] int64) already on the device: what pack_gts produces.  Passed as
+    `gt_bboxes` (with gt_labels=None) by callers that keep static input buffers (graphs.GraphedTrainStep)."""
+
+    def __len__(self):          # len(gt_bboxes) == batch size in the callers
+        return int(self[1].shape[0])
+
+
 def pack_gts(gt_bboxes, gt_labels, device):
     """list of [G_i,4] / [G_i] -> ([B,Gmax,4] f32, [B] int32 counts, [B,Gmax] int64); sizes are host-known."""
+    if isinstance(gt_bboxes, PackedGT):
+        return tuple.__getitem__(gt_bboxes, 0), tuple.__getitem__(gt_bboxes, 1), tuple.__getitem__(gt_bboxes, 2)
     B = len(gt_bboxes)
     counts = [int(g.shape[0]) for g in gt_bboxes]
     gmax = max(max(counts), 1)

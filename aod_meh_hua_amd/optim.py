@@ -16,11 +16,25 @@ class FusedSGD(torch.optim.Optimizer):
         assert dampening == 0 and not nesterov, 'the AL configs use plain momentum SGD'
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self._lr_dev = {}          # group index -> [device fp32 scalar, value]: used once device_lr() has been called (HIP-graph replay)
+
+    def device_lr(self):
+        """Keep each group's learning rate in device memory and make step() read it from there, so that a step() captured in a HIP
+        graph follows the schedule.  Call before every replay (outside capture): uploads only when a value changed."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._lr_dev.get(gi)
+            if ent is None:
+                dev = group['params'][0].device
+                self._lr_dev[gi] = [torch.full((1,), float(group['lr']), dtype=torch.float32, device=dev), float(group['lr'])]
+            elif ent[1] != float(group['lr']):
+                ent[0].fill_(float(group['lr']))
+                ent[1] = float(group['lr'])
 
     @torch.no_grad()
     def step(self, closure=None):
         touched = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
+            self._gi = gi
             ps, gs, ms, ns, first = [], [], [], [], None
             for p in group['params']:
                 if p.grad is None:
@@ -49,7 +63,9 @@ class FusedSGD(torch.optim.Optimizer):
         if n == 0:
             return
         arr = C.c_void_p * n
-        call('aod_sgd_multi', arr(*ps), arr(*gs), arr(*ms), (C.c_int64 * n)(*ns), n, float(group['lr']), float(group['momentum']),
+        ent = self._lr_dev.get(self._gi)
+        call('aod_sgd_multi', arr(*ps), arr(*gs), arr(*ms), (C.c_int64 * n)(*ns), n, float(group['lr']),
+             C.c_void_p(ent[0].data_ptr()) if ent is not None else None, float(group['momentum']),
              float(group['weight_decay']), int(bool(first)), float(self.grad_scale), stream())
 
 

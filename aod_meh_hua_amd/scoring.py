@@ -40,6 +40,24 @@ def nhwc_view(x, c):
     return xr.reshape(B, -1, c)
 
 
+_META = {}
+
+
+def _meta_tensors(img_shapes, scale_factors, dev):
+    """[B,2] image sizes and [B,4] scale factors on the device, cached by value: the pool loop re-uses a handful of shapes, and an
+    H2D copy per batch would also break HIP-graph capture of the scoring pass."""
+    key = (tuple((float(s[0]), float(s[1])) for s in img_shapes),
+           None if scale_factors is None else tuple(tuple(float(v) for v in np.asarray(s, np.float32).reshape(-1)[:4]) for s in scale_factors), str(dev))
+    hit = _META.get(key)
+    if hit is None:
+        if len(_META) > 256:
+            _META.clear()
+        hw = torch.tensor(key[0], dtype=torch.float32).to(dev)
+        sc = torch.tensor(key[1], dtype=torch.float32).to(dev) if key[1] is not None else None
+        hit = _META[key] = (hw, sc)
+    return hit
+
+
 class Candidates:
     """Outputs of the pre-NMS stage for a batch (concatenated levels)."""
 
@@ -64,8 +82,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     scores = torch.empty(B, n, C_ if has_bg else C_ + 1, device=dev)
     lam_o = torch.empty(B, n, device=dev)
     cand_anchor = torch.empty(B, n, dtype=torch.int32, device=dev)
-    img_hw = torch.tensor([[float(s[0]), float(s[1])] for s in img_shapes], dtype=torch.float32).to(dev, non_blocking=True)
-    sc4 = torch.tensor(np.stack([np.asarray(s, np.float32).reshape(-1)[:4] for s in scale_factors])).to(dev, non_blocking=True) if rescale else None
+    img_hw, sc4 = _meta_tensors(img_shapes, scale_factors if rescale else None, dev)
     c0 = a0 = 0
     level_start, idxs = [0], []
     for l in range(L):

@@ -26,6 +26,8 @@ class MyEpochBasedRunnerLambda(BaseRunner):
         """Epoch_Based_Runner_Lambda.py:20-38."""
         if self.batch_processor is not None:
             outputs = self.batch_processor(self.model, data_batch, train_mode=train_mode, **kwargs)
+        elif train_mode and self._graphed_iter(data_batch, kwargs):
+            outputs = self.outputs
         elif train_mode:
             loss, head_out, feat_out, prev_loss = self.model.train_step(data_batch, **kwargs)
             self.optimizer.zero_grad()
@@ -38,12 +40,37 @@ class MyEpochBasedRunnerLambda(BaseRunner):
             self._sync(self.optimizer_L)
             self.optimizer_L.step()
             loss['log_vars'].update(loss_L['log_vars'])
+            # keep only the value: a loss that still owns its autograd graph keeps the parameters' AccumulateGrad nodes (bound to
+            # this stream) alive, which makes a later HIP-graph capture of the iteration illegal -- and pins the activations
+            loss['loss'] = loss['loss'].detach()
+            del loss_L, head_out, feat_out, prev_loss
             outputs = loss
         else:
             outputs = self.model.val_step(data_batch, self.optimizer, **kwargs)
         if 'log_vars' in outputs:
             self.log_buffer.update(outputs['log_vars'], outputs['num_samples'])
         self.outputs = outputs
+
+    def _graphed_iter(self, data_batch, kwargs):
+        """HIP-graph replay of the iteration (graphs.GraphedTrainStep) once the input shape repeats; False -> run it eagerly.
+        Disabled by `runner.hip_graph = False` or AOD_HIP_GRAPH=0."""
+        import os
+        if not getattr(self, 'hip_graph', True) or os.environ.get('AOD_HIP_GRAPH', '1') == '0' or not hasattr(self, 'optimizer_L'):
+            return False
+        key = tuple(sorted((k, v) for k, v in kwargs.items() if isinstance(v, (bool, int, str))))
+        gs = getattr(self, '_graph_step', None)
+        if gs is None or gs[0] != key:
+            from ..graphs import GraphedTrainStep
+            from ..parallel import is_dist
+            if not hasattr(self, '_gsync'):
+                self._gsync = GradSync()
+            sync = self._gsync if is_dist() else None
+            gs = self._graph_step = (key, GraphedTrainStep(self.model, self.optimizer, self.optimizer_L, grad_sync=sync, **dict(key)))
+        out = gs[1].maybe(data_batch)
+        if out is None:
+            return False
+        self.outputs = out
+        return True
 
     def train(self, data_loader, **kwargs):
         """:40-75 (labeled-only branch; the unlabeled/pseudo loader list is never passed by the AL driver)."""

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--mode', default='train+score', choices=['train', 'score', 'train+score'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
     return ap.parse_args()
 
 
@@ -51,8 +52,8 @@ def synth_batch(B, H, W, device, seed):
         G = int(torch.randint(1, 6, (1,), generator=g))
         wh = torch.rand(G, 2, generator=g) * (384 - 32) * (H / 512.0) + 32 * (H / 512.0)
         xy = torch.rand(G, 2, generator=g) * (torch.tensor([float(W), float(H)]) - wh).clamp(min=0)
-        boxes.append(torch.cat([xy, (xy + wh).clamp(max=float(H))], 1).to(device))
-        labels.append(torch.randint(0, 20, (G,), generator=g).to(device))
+        boxes.append(torch.cat([xy, (xy + wh).clamp(max=float(H))], 1))      # ground truth stays on the host like a data loader's
+        labels.append(torch.randint(0, 20, (G,), generator=g))
     metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3), scale_factor=np.ones(4, np.float32), flip=False)
              for _ in range(B)]
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=boxes, gt_labels=labels)
@@ -112,10 +113,26 @@ def main():
         have_scoring = False
         do_score = False
 
-    def step(it=0, do_train=do_train, do_score=do_score):
+    from aod_meh_hua_amd.graphs import GraphedScore, GraphedTrainStep
+    use_graph = not args.no_graph
+    gstep = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync if world > 1 else None, Labeled=True, Pseudo=False)
+    gscore = GraphedScore(model, **{k: v for k, v in score_kw.items() if k != 'return_loss'}) if have_scoring else None
+    data_dev = dict(data, gt_bboxes=[b.to(dev) for b in data['gt_bboxes']], gt_labels=[l.to(dev) for l in data['gt_labels']])
+
+    def step(it=0, do_train=do_train, do_score=do_score, graph=use_graph):
+        """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python."""
+        if graph:
+            if do_train:
+                gstep(data)
+            if do_score:
+                ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                _, unc = gscore(pool['img'], pool['img_metas'], ids)
+                if world > 1:
+                    gather_scores(unc, B * world)
+            return
         if do_train:
             model.train()
-            out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+            out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
             opt.zero_grad()
             out['loss'].backward()
             gsync.all_reduce_grads(opt.param_groups[0]['params'])
@@ -176,7 +193,7 @@ def main():
     roof = None
     if rank == 0:
         ho.PROFILE = []
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps, graph=False)          # HIP events around every launch need the eager path
         torch.cuda.synchronize()
         agg = {}
         for kind, shape, flops, e0, e1 in ho.PROFILE:
@@ -204,7 +221,8 @@ def main():
                                          + ' + '.join((['train iteration (main fwd/bwd/SGD + MEH fwd/bwd/SGD)'] if do_train else [])
                                                       + (['HUA scoring pass'] if do_score else [])),
                                 global_batch=B * world, image_size=H, num_classes=20, anchors_per_image=49104 if H == 512 else None,
-                                parallelism=f'dp{world}', phases=args.mode if (do_score or not have_scoring) else 'train'),
+                                parallelism=f'dp{world}', phases=args.mode if (do_score or not have_scoring) else 'train',
+                                launch='hip-graph replay' if use_graph else 'eager'),
                     phase_rates=phase, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

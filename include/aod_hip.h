@@ -230,9 +230,11 @@ int aod_ssd_loss_bwd(const float* cls, const int64_t* labels, const float* label
 
 /* ------------------------------------------------------------------ optimizer (K16)
  * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61): d = g*grad_scale + wd*p; buf = first ? d : mom*buf + d;
- * p -= lr*buf, over HOST arrays of device pointers (params/grads/momentum buffers, fp32) and element counts. */
+ * p -= lr*buf, over HOST arrays of device pointers (params/grads/momentum buffers, fp32) and element counts.
+ * lr_dev (nullable): device fp32 scalar that overrides `lr` -- lets a launch captured in a HIP graph follow the LR schedule. */
 int aod_sgd_multi(void* const* params, void* const* grads, void* const* moms, const int64_t* sizes, int ntensors,
-                  float lr, float momentum, float weight_decay, int first_step, float grad_scale, aod_stream_t stream);
+                  float lr, const float* lr_dev, float momentum, float weight_decay, int first_step, float grad_scale,
+                  aod_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""HIP-graph replay (aod_meh_hua_amd/graphs.py) must do exactly what the eager iteration does: same losses, same parameter updates
+(up to the fp32 atomics of wgrad / column sums), same scores, and it must follow a changing learning rate and new input data."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as omodel
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    from aod_meh_hua_amd.optim import FusedSGD
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    cfg.model.backbone.pop('init_cfg')
+    model = build_detector(cfg.model)
+    model.load_state_dict(omodel.seeded_state_dict(cls_bias=-2.0), strict=True)
+    model = model.cuda().train()
+    head = model.bbox_head
+    meh = set(id(p) for n in ('retina_L', 'L_convs') for p in getattr(head, n).parameters())
+    main = [p for p in model.parameters() if p.requires_grad and id(p) not in meh]
+    opt = FusedSGD(main, lr=2e-4, momentum=0.9, weight_decay=1e-4)      # small steps: the comparison must not be chaotic
+    opt_L = FusedSGD([p for p in model.parameters() if id(p) in meh], lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    return model, opt, opt_L
+
+
+def _batch(seed, B=2, H=128):
+    gtb, gtl = synth.random_gts(B, H, H, seed=seed, gmin=1, gmax=3)
+    return dict(img=synth.images(B, H, H, seed=seed).cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=gtb, gt_labels=gtl)
+
+
+def _eager_iter(model, opt, opt_L, data):
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    opt.zero_grad()
+    out['loss'].backward()
+    opt.step()
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    opt_L.zero_grad()
+    lossL['loss'].backward()
+    opt_L.step()
+    return float(out['loss'].detach()), float(lossL['loss'].detach())
+
+
+def test_graphed_train_step_equals_eager():
+    from aod_meh_hua_amd.graphs import GraphedTrainStep
+    batches = [_batch(31), _batch(32), _batch(33)]
+    lrs = [2e-4, 2e-4, 5e-5]
+    # eager reference
+    model, opt, opt_L = _build()
+    ref_losses = []
+    for d, lr in zip(batches, lrs):
+        opt.param_groups[0]['lr'] = lr
+        ref_losses.append(_eager_iter(model, opt, opt_L, d))
+    ref = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    # graphed: capture happens on the first call (its warm-up iterations must not leak into the result, so reload afterwards)
+    model2, opt2, opt_L2 = _build()
+    sd0 = {k: v.detach().clone() for k, v in model2.state_dict().items()}
+    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=1, Labeled=True, Pseudo=False)
+    gs(batches[0])
+    model2.load_state_dict(sd0, strict=True)
+    for st in (opt2.state, opt_L2.state):
+        for s in st.values():
+            s['momentum_buffer'].zero_()      # first replay then behaves like a first step (buf = 0*m + d)
+    got = []
+    for d, lr in zip(batches, lrs):
+        opt2.param_groups[0]['lr'] = lr
+        o = gs(d)
+        got.append((float(o['loss']), float(o['log_vars']['loss_L'])))
+    torch.cuda.synchronize()
+    assert np.allclose(np.array(got), np.array(ref_losses), rtol=2e-3), (got, ref_losses)
+    new = {k: v.detach().float().cpu() for k, v in model2.state_dict().items()}
+    worst = max(float((new[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-12)) for k in ref if ref[k].is_floating_point())
+    assert worst < 5e-3, worst
+    moved = float((new['bbox_head.retina_cls.weight'] - sd0['bbox_head.retina_cls.weight'].float().cpu()).abs().max())
+    assert moved > 0
+    # eager code after replays sees the updated parameters (version bump -> packed weights rebuilt)
+    model2.train()
+    l_eager = float(model2.train_step(batches[0], Labeled=True, Pseudo=False)[0]['loss'].detach())
+    model.train()
+    l_ref = float(model.train_step(batches[0], Labeled=True, Pseudo=False)[0]['loss'].detach())
+    assert np.allclose(l_eager, l_ref, rtol=2e-3), (l_eager, l_ref)
+
+
+def test_graphed_score_equals_eager_and_follows_inputs():
+    from aod_meh_hua_amd.graphs import GraphedScore
+    model, _, _ = _build()
+    model.eval()
+    kw = dict(rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', scaleUnc=False,
+              showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
+    gsc = GraphedScore(model, **kw)
+    metas = synth.metas(2, 128, 128)
+    for seed in (41, 42, 43):
+        img = synth.images(2, 128, 128, seed=seed).cuda()
+        ids = torch.tensor([seed * 2, seed * 2 + 1], device='cuda')
+        with torch.no_grad():
+            _, unc_e = model(img=[img], img_metas=[metas], return_loss=False, image_ids=ids, **kw)
+        _, unc_g = gsc(img, metas, ids)
+        assert torch.equal(torch.as_tensor(unc_e).float().cpu(), unc_g.float().cpu()), (seed, unc_e, unc_g)
+    assert gsc.maybe(synth.images(1, 128, 128).cuda(), synth.metas(1, 128, 128), torch.zeros(1, dtype=torch.int64, device='cuda')) is None
