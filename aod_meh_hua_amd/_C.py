@@ -41,6 +41,8 @@ _SIGS = {
     'aod_conv_row_table_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv_row_table': (C.c_int, [C.POINTER(ConvDesc), P, P]),
     'aod_pack_weight_fwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
+    'aod_param_prep': (C.c_int, [P, I32, I32, P]),
+    'aod_param_prep_item_bytes': (C.c_int, []),
     'aod_pack_weight_dgrad': (C.c_int, [P, P, I32, I32, I32, I32, I32, P, P]),
     'aod_unpack_wgrad': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, I32, P, P, P, P, P, P, P]),
     'aod_nchw_f32_to_nhwc_bf16': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),

@@ -706,6 +706,100 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ d
     }
   }
 }
+// ---- batched parameter preparation: ONE launch re-derives, for every registered conv layer, the folded eval-BN vectors
+// (scale = gamma * rsqrt(var + eps), shift = beta - mean * scale, invstd) and both packed bf16 weight images (forward
+// [O][R][S][Ipad]; dgrad [I][R][S][Opad] with the BN scale folded in).  After an optimizer step every trainable layer is stale; doing
+// this per layer costs ~270 launches of a few microseconds each per iteration.
+struct PrepItem {            // 16 x 8 bytes, filled by the host into a device table
+  const float* w; const float* gamma; const float* beta; const float* mean; const float* var;
+  bf16_t* wf; bf16_t* wd; float* scale; float* shift; float* invstd;
+  int O, I, RS, Ipad, Opad, blk0;      // blk0: first block of this item
+  float eps; int pad_;
+  long long pad2_[2];
+};
+// One block = one 32 (out channels) x 32 (in channels) tile of one layer, all R*S taps: the fp32 master weights are read ONCE, coalesced
+// (for a fixed output channel the (c, tap) run is contiguous), staged in LDS and written out as both packed images in 64-byte runs.
+// Layers with more than 9 taps (the frozen 7x7 stem) take the element-wise path.
+constexpr int PREP_T = 32, PREP_RS = 9;
+__global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restrict__ items, int nitems) {
+  __shared__ float tile[PREP_RS][PREP_T][PREP_T + 1];
+  int lo = 0, hi = nitems - 1;
+  while (lo < hi) {      // block -> item: binary search over blk0 (items are in block order)
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PrepItem it = items[lo];
+  const int lb = blockIdx.x - it.blk0;
+  const int t = threadIdx.x;
+  if (it.RS > PREP_RS) {
+    const long long nf = (long long)it.O * it.RS * it.Ipad, nd = it.wd ? (long long)it.I * it.RS * it.Opad : 0;
+    for (int u = 0; u < 8; ++u) {
+      const long long i = (long long)lb * 2048 + u * 256 + t;
+      if (i < nf) {
+        const int c = i % it.Ipad; const long long r1 = i / it.Ipad; const int rs = r1 % it.RS; const int oo = r1 / it.RS;
+        it.wf[i] = (c < it.I) ? (bf16_t)it.w[((long long)oo * it.I + c) * it.RS + rs] : (bf16_t)0.f;
+      }
+      if (i < nd) {
+        const int oo = i % it.Opad; const long long r1 = i / it.Opad; const int rs = r1 % it.RS; const int c = r1 / it.RS;
+        float v = 0.f;
+        if (oo < it.O) { v = it.w[((long long)oo * it.I + c) * it.RS + rs]; if (it.gamma) v *= it.gamma[oo] * rsqrtf(it.var[oo] + it.eps); }
+        it.wd[i] = (bf16_t)v;
+      }
+      if (it.gamma && i < it.O) {
+        const float inv = rsqrtf(it.var[i] + it.eps), sc = it.gamma[i] * inv;
+        it.invstd[i] = inv; it.scale[i] = sc; it.shift[i] = it.beta[i] - it.mean[i] * sc;
+      }
+    }
+    return;
+  }
+  const int tiles_c = (it.Ipad + PREP_T - 1) / PREP_T;
+  const int to = lb / tiles_c, tc = lb - to * tiles_c;
+  const int o0 = to * PREP_T, c0 = tc * PREP_T;
+  const int RS = it.RS;
+  // load: for each output channel the run w[o][c0 .. c0+32)[0 .. RS) is contiguous
+  const int run = PREP_T * RS;
+  for (int ol = 0; ol < PREP_T; ++ol) {
+    const int o = o0 + ol;
+    for (int idx = t; idx < run; idx += 256) {
+      const int cl = idx / RS, rs = idx - cl * RS;
+      const int c = c0 + cl;
+      tile[rs][ol][cl] = (o < it.O && c < it.I) ? it.w[((long long)o * it.I + c0) * RS + idx] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int l32 = t & 31, g8 = t >> 5;      // 8 groups of 32 lanes
+  // forward image [O][RS][Ipad]: runs of 32 input channels
+  for (int j = g8; j < PREP_T * RS; j += 8) {
+    const int ol = j / RS, rs = j - ol * RS;
+    const int o = o0 + ol, c = c0 + l32;
+    if (o < it.O && c < it.Ipad) it.wf[((long long)o * RS + rs) * it.Ipad + c] = (bf16_t)tile[rs][ol][l32];
+  }
+  // dgrad image [I][RS][Opad] (x BN scale): runs of 32 output channels
+  if (it.wd) {
+    const int o = o0 + l32;
+    float sc = 1.f;
+    if (it.gamma && o < it.O) sc = it.gamma[o] * rsqrtf(it.var[o] + it.eps);
+    for (int j = g8; j < PREP_T * RS; j += 8) {
+      const int cl = j / RS, rs = j - cl * RS;
+      const int c = c0 + cl;
+      if (c < it.I && o < it.Opad) it.wd[((long long)c * RS + rs) * it.Opad + o] = (bf16_t)(tile[rs][l32][cl] * sc);
+    }
+  }
+  if (it.gamma && tc == 0 && t < PREP_T && o0 + t < it.O) {
+    const int o = o0 + t;
+    const float inv = rsqrtf(it.var[o] + it.eps), sc = it.gamma[o] * inv;
+    it.invstd[o] = inv; it.scale[o] = sc; it.shift[o] = it.beta[o] - it.mean[o] * sc;
+  }
+}
+extern "C" int aod_param_prep(const void* items_dev, int nitems, int total_blocks, aod_stream_t stream) {
+  AOD_CHECK_ARG(items_dev && nitems >= 0 && total_blocks >= 0, "param_prep: bad args");
+  if (nitems == 0 || total_blocks == 0) return 0;
+  hipLaunchKernelGGL(param_prep_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, nitems);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_param_prep_item_bytes(void) { return (int)sizeof(PrepItem); }
+
 static inline int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 extern "C" int aod_pack_weight_fwd(const float* w, void* o, int O, int I, int R, int S, int Ipad, aod_stream_t stream) {

@@ -87,6 +87,104 @@ def fold_bn(gamma, beta, mean, var, eps):
     return CACHE.get('bn', (gamma, beta, mean, var), make)
 
 
+# --------------------------------------------------------------------------- batched parameter preparation
+import ctypes as _C
+import weakref as _weakref
+
+
+class _PrepRec(_C.Structure):
+    _fields_ = [('w', _C.c_void_p), ('gamma', _C.c_void_p), ('beta', _C.c_void_p), ('mean', _C.c_void_p), ('var', _C.c_void_p),
+                ('wf', _C.c_void_p), ('wd', _C.c_void_p), ('scale', _C.c_void_p), ('shift', _C.c_void_p), ('invstd', _C.c_void_p),
+                ('O', _C.c_int32), ('I', _C.c_int32), ('RS', _C.c_int32), ('Ipad', _C.c_int32), ('Opad', _C.c_int32), ('blk0', _C.c_int32),
+                ('eps', _C.c_float), ('pad_', _C.c_int32), ('pad2_', _C.c_int64 * 2)]
+
+
+class _PrepItem:
+    __slots__ = ('srcs', 'ver', 'wf', 'wd', 'scale', 'shift', 'invstd', 'eps', 'dims', 'nblk')
+
+
+class ParamPrep:
+    """Everything a conv launch derives from its parameters -- packed bf16 weight images (forward and dgrad) and the folded eval-mode BN
+    vectors -- kept in per-layer STATIC buffers and refreshed for ALL registered layers by ONE kernel (aod_param_prep) the first time a
+    stale layer is used: after an optimizer step that is one launch per iteration instead of ~270 small ones.  Staleness is detected
+    through tensor._version of (weight, gamma, beta, running_mean, running_var)."""
+
+    def __init__(self):
+        self.items, self.order, self.table, self.dirty = {}, [], None, True
+
+    def _versions(self, it):
+        return tuple(-1 if t is None else t._version for t in (r() if r is not None else None for r in it.srcs))
+
+    def get(self, w, bn, cin_pad, eps):
+        it = self.items.get(id(w))
+        if it is not None and it.srcs[0]() is not w:
+            it = None
+        if it is None:
+            it = self._register(w, bn, cin_pad, eps)
+        if it.ver != self._versions(it):
+            self.refresh()
+        return it
+
+    def _register(self, w, bn, cin_pad, eps):
+        O, I, R, S = w.shape
+        dev = w.device
+        it = _PrepItem()
+        it.srcs = [_weakref.ref(w)] + [(_weakref.ref(t) if t is not None else None) for t in (bn if bn is not None else (None,) * 4)]
+        opad = (O + 7) // 8 * 8
+        it.wf = torch.empty(O, R, S, cin_pad, dtype=torch.bfloat16, device=dev)
+        it.wd = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=dev) if cin_pad == I else None      # no dgrad through a padded stem
+        if bn is not None:
+            it.scale, it.shift, it.invstd = (torch.empty(O, dtype=torch.float32, device=dev) for _ in range(3))
+        else:
+            it.scale = it.shift = it.invstd = None
+        it.eps, it.dims, it.ver = float(eps), (O, I, R * S, cin_pad, opad), None
+        if R * S <= 9:
+            it.nblk = ((opad + 31) // 32) * ((cin_pad + 31) // 32)           # 32 x 32 channel tiles (aod_param_prep)
+        else:
+            it.nblk = (max(O * R * S * cin_pad, I * R * S * opad if it.wd is not None else 0, O) + 2047) // 2048
+        self.items[id(w)] = it
+        self.dirty = True
+        return it
+
+    def refresh_if_stale(self):
+        if any(it.ver != self._versions(it) for it in self.items.values()):
+            self.refresh()
+
+    def refresh(self):
+        assert not torch.cuda.is_current_stream_capturing(), \
+            'parameter preparation inside a HIP-graph capture: call PREP.refresh_if_stale() before capturing / replaying'
+        # drop layers whose weight died (a model is rebuilt every active-learning cycle)
+        dead = [k for k, it in self.items.items() if it.srcs[0]() is None or any(r is not None and r() is None for r in it.srcs[1:])]
+        for k in dead:
+            del self.items[k]
+            self.dirty = True
+        if self.dirty:
+            self.order = list(self.items.values())
+            recs = (_PrepRec * max(len(self.order), 1))()
+            blk = 0
+            for r, it in zip(recs, self.order):
+                src = [x() if x is not None else None for x in it.srcs]
+                for t in src:
+                    assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), 'parameters must be contiguous fp32'
+                r.w, r.gamma, r.beta, r.mean, r.var = (None if t is None else t.data_ptr() for t in src)
+                r.wf, r.wd = it.wf.data_ptr(), (it.wd.data_ptr() if it.wd is not None else None)
+                r.scale, r.shift, r.invstd = ((t.data_ptr() if t is not None else None) for t in (it.scale, it.shift, it.invstd))
+                r.O, r.I, r.RS, r.Ipad, r.Opad = it.dims
+                r.blk0, r.eps = blk, it.eps
+                blk += it.nblk
+            self.nblocks = blk
+            host = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
+            self.table = host.to(self.order[0].wf.device) if self.order else None
+            self.dirty = False
+        if self.order:
+            ho.call('aod_param_prep', ho.ptr(self.table), len(self.order), self.nblocks, ho.stream())
+        for it in self.order:
+            it.ver = self._versions(it)
+
+
+PREP = ParamPrep()
+
+
 # --------------------------------------------------------------------------- conv (+BN/bias, +res, +ReLU)
 import os as _os
 _FUSE_ACT = _os.environ.get('AOD_FUSE_ACT', '1') != '0'      # debug switch for A/B timing
@@ -116,11 +214,9 @@ class ConvFn(Function):
         O, I, R, S = w.shape
         cin = xs[0].shape[1]
         x_rows, x_segs = multi_rows(xs)
-        wp = CACHE.get('wf%d' % cin, (w,), lambda: ho.pack_weight_fwd(w.detach(), cin))
-        scale = shift = invstd = None
-        if gamma is not None:
-            scale, shift, invstd = fold_bn(gamma, beta, mean, var, meta['eps'])
-        elif bias is not None:
+        pi = PREP.get(w, (gamma, beta, mean, var) if gamma is not None else None, cin, meta['eps'])
+        wp, scale, shift, invstd = pi.wf, pi.scale, pi.shift, pi.invstd
+        if gamma is None and bias is not None:
             shift = bias.detach()
         res_rows = as_rows(res) if res is not None else None
         out_rows = as_rows(meta['out']) if meta.get('out') is not None else None      # caller-provided destination (pyramid slice)
@@ -205,10 +301,7 @@ class ConvFn(Function):
                 gw = None
         gxs = [None] * ctx.nx
         if need_x:
-            if ctx.has_bn:
-                wd = CACHE.get('wds%d' % Opad, (w, scale), lambda: ho.pack_weight_dgrad(w.detach(), Opad, scale))
-            else:
-                wd = CACHE.get('wd%d' % Opad, (w,), lambda: ho.pack_weight_dgrad(w.detach(), Opad))
+            wd = PREP.get(w, (gamma, None, mean, None) if ctx.has_bn else None, cin, meta['eps']).wd    # registered in forward
             if I != cin:   # stem: channel-padded input; dX only for the real channels is never needed (image)
                 raise RuntimeError('dgrad through a channel-padded input is not supported')
             xd = dense_segs(x_segs)

@@ -14,6 +14,7 @@ memory (FusedSGD.device_lr), and after a replay the versions of the updated para
 checkpoints) rebuilds its packed weights."""
 import torch
 
+from . import functional as AF
 from . import hipops as ho
 
 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # warm-up runs on a side stream by design
@@ -120,6 +121,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ho.reset_zero_arena()                     # accumulators handed out during capture must be zeroed INSIDE the graph
+        # packed weights / folded BN are re-derived EAGERLY before every replay (one launch, only when a parameter changed): the graph
+        # itself must not contain the refresh, or its position would depend on which layers happened to be stale at capture time
+        AF.PREP.refresh_if_stale()
         segs = [self._seg_a, self._seg_b, self._seg_c]
         self.graphs = []
         if self.sync is None or not is_dist():
@@ -158,6 +162,7 @@ class GraphedTrainStep:
             self.sig = sig
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
+        AF.PREP.refresh_if_stale()
         if len(self.graphs) == 1:
             self.graphs[0].replay()
         else:
@@ -218,6 +223,7 @@ class GraphedScore:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             ho.reset_zero_arena()
+            AF.PREP.refresh_if_stale()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._run()
@@ -225,6 +231,7 @@ class GraphedScore:
             self.sig = sig
         self.img.copy_(img, non_blocking=True)
         self.ids.copy_(image_ids, non_blocking=True)
+        AF.PREP.refresh_if_stale()        # e.g. a training replay or a checkpoint load since the last scoring batch
         self.graph.replay()
         unc = self.out[1]
         return self.out[0], (unc.clone() if torch.is_tensor(unc) else unc)

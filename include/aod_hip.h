@@ -93,6 +93,17 @@ int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int 
                      const float* scale, const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean,
                      const float* bn_invstd, aod_stream_t stream);
 
+/* Batched re-derivation of everything the conv launches read from the parameters, for ALL layers in one launch (after an optimizer
+ * step every trainable layer is stale): items_dev = device array of `nitems` records of aod_param_prep_item_bytes() bytes,
+ *   { const float* w_oihw, gamma, beta, mean, var;  void* w_fwd_packed, w_dgrad_packed;  float* scale, shift, invstd;
+ *     int32 O, I, RS, Ipad, Opad, blk0;  float eps;  int32 pad;  int64 pad[2] }
+ * gamma == NULL: conv without BatchNorm (plain packs); w_dgrad_packed == NULL: no dgrad image.  With BN the dgrad image carries
+ * scale[o] = gamma*rsqrt(var+eps) (see aod_pack_weight_dgrad) and scale/shift/invstd receive the folded eval-mode BN vectors
+ * (resnet.py:647-656).  blk0 = first block of the item; an item owns ceil(Opad/32)*ceil(Ipad/32) blocks (32 x 32 channel tiles), or
+ * ceil(max(O*RS*Ipad, I*RS*Opad, O)/2048) blocks when RS > 9. */
+int aod_param_prep(const void* items_dev, int nitems, int total_blocks, aod_stream_t stream);
+int aod_param_prep_item_bytes(void);
+
 /* ------------------------------------------------------------------ layout / elementwise
  * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the
  * implicit layout of `img` in SSL_L_single_stage.py:45-49 extract_feat. */
