@@ -4,8 +4,9 @@ A training iteration (`MyEpochBasedRunnerLambda.run_iter`, Epoch_Based_Runner_La
 take ~20 ms while the Python that launches them takes about as long, so the GPU work is captured once per input shape
 (`torch.cuda.CUDAGraph` == hipGraph on ROCm) and replayed:
 
-  GraphedTrainStep   main forward / backward / SGD step + MEH forward / backward / SGD step.  One graph on a single GPU; with
-                     data parallelism three graphs with the two eager gradient all-reduces (parallel.GradSync) between them.
+  GraphedTrainStep   main forward / backward, MEH forward / backward, the two SGD steps.  One graph on a single GPU; with data
+                     parallelism four graphs with the eager gradient all-reduces (parallel.GradSync) between them, the main
+                     network's all-reduce overlapping the whole MEH segment.
   GraphedScore       one batch of the HUA scoring pass (`calculate_uncertainty`, apis/test.py:65-135).
 
 Both keep STATIC input buffers (image batch, packed ground truth, image ids); a call copies the new batch in and replays.  Rules the
@@ -84,27 +85,38 @@ class GraphedTrainStep:
         self.live = (out, head_out, feat_out, prev)
 
     def _seg_b(self):
+        # the MEH step only reads detached features / losses and its own parameters, so the main update (segment C) may follow it:
+        # with data parallelism the main gradients' all-reduce then runs under this whole segment
         out, head_out, feat_out, prev = self.live
-        self.opt.step()
         loss_L = self.module.train_step_L(prev, head_out, feat_out, **self.kw)
         self.opt_L.zero_grad()
         loss_L['loss'].backward()
         self.live_L = loss_L
 
     def _seg_c(self):
+        self.opt.step()
+
+    def _seg_d(self):
         self.opt_L.step()
 
     def _params(self, opt):
         return [p for g in opt.param_groups for p in g['params']]
 
-    def _run_eager(self):
-        self._seg_a()
-        if self.sync is not None:
-            self.sync.all_reduce_grads(self._params(self.opt))
-        self._seg_b()
-        if self.sync is not None:
+    def _between(self, i):
+        """Eager communication between segment i and i+1 (data parallelism only)."""
+        if self.sync is None:
+            return
+        if i == 0:
+            self.pending = self.sync.start(self._params(self.opt))         # overlaps segment B
+        elif i == 1:
+            self.pending.wait()
+        elif i == 2:
             self.sync.all_reduce_grads(self._params(self.opt_L))
-        self._seg_c()
+
+    def _run_eager(self):
+        for i, f in enumerate((self._seg_a, self._seg_b, self._seg_c, self._seg_d)):
+            f()
+            self._between(i)
 
     def _build(self, d):
         from .parallel import is_dist
@@ -124,7 +136,7 @@ class GraphedTrainStep:
         # packed weights / folded BN are re-derived EAGERLY before every replay (one launch, only when a parameter changed): the graph
         # itself must not contain the refresh, or its position would depend on which layers happened to be stale at capture time
         AF.PREP.refresh_if_stale()
-        segs = [self._seg_a, self._seg_b, self._seg_c]
+        segs = [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
         self.graphs = []
         if self.sync is None or not is_dist():
             g = torch.cuda.CUDAGraph()
@@ -163,14 +175,10 @@ class GraphedTrainStep:
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
         AF.PREP.refresh_if_stale()
-        if len(self.graphs) == 1:
-            self.graphs[0].replay()
-        else:
-            self.graphs[0].replay()
-            self.sync.all_reduce_grads(self._params(self.opt))
-            self.graphs[1].replay()
-            self.sync.all_reduce_grads(self._params(self.opt_L))
-            self.graphs[2].replay()
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if len(self.graphs) > 1:
+                self._between(i)
         tp = [p for p in self.touched if p.grad is not None]
         torch._C._autograd._unsafe_set_version_counter(tp, [p._version + 1 for p in tp])
         out, loss_L = self.live[0], self.live_L

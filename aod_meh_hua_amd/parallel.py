@@ -26,29 +26,52 @@ def get_dist_info():
     return 0, 1
 
 
+class _PendingSync:
+    """In-flight bucketed all-reduce: wait() finishes the collectives and scatters the averaged buckets back into the gradients."""
+
+    def __init__(self, buckets, world):
+        self.buckets, self.world = buckets, world
+
+    def wait(self):
+        for grads, flat, work in self.buckets:
+            if work is not None:
+                work.wait()
+            flat.div_(self.world)
+            parts = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)]
+            if hasattr(torch, '_foreach_copy_'):
+                torch._foreach_copy_(grads, parts)          # one batched launch instead of one copy per parameter
+            else:
+                for g, v in zip(grads, parts):
+                    g.copy_(v)
+        self.buckets = []
+
+
 class GradSync:
     def __init__(self, bucket_mb=64):
         self.bucket_elems = bucket_mb * (1 << 20) // 4
 
-    def all_reduce_grads(self, params):
+    def start(self, params):
+        """Launch the bucketed all-reduce of the parameters' gradients WITHOUT waiting (RCCL runs it on its own stream; xGMI rings are
+        per-link bound, so a few large buckets).  Returns a handle whose wait() must be called before the gradients are read.  The
+        runner overlaps the main network's all-reduce with the whole MEH forward/backward (disjoint parameters)."""
         if not is_dist():
-            return
+            return _PendingSync([], 1)
         world = dist.get_world_size()
         grads = [p.grad for p in params if p.grad is not None]
-        i = 0
+        buckets, i = [], 0
         while i < len(grads):
             j, n = i, 0
             while j < len(grads) and (n == 0 or n + grads[j].numel() <= self.bucket_elems):
                 n += grads[j].numel()
                 j += 1
             flat = torch.cat([g.reshape(-1).float() for g in grads[i:j]])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(world)
-            o = 0
-            for g in grads[i:j]:
-                g.copy_(flat[o:o + g.numel()].view_as(g))
-                o += g.numel()
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            buckets.append((grads[i:j], flat, work))
             i = j
+        return _PendingSync(buckets, world)
+
+    def all_reduce_grads(self, params):
+        self.start(params).wait()
 
 
 def shard_range(n_total, rank=None, world=None):

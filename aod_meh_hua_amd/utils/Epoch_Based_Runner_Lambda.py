@@ -17,10 +17,13 @@ class MyEpochBasedRunnerLambda(BaseRunner):
     def _module(self):
         return self.model.module if hasattr(self.model, 'module') else self.model
 
-    def _sync(self, optimizer):
+    def _sync_start(self, optimizer):
         if not hasattr(self, '_gsync'):
             self._gsync = GradSync()
-        self._gsync.all_reduce_grads([p for g in optimizer.param_groups for p in g['params']])
+        return self._gsync.start([p for g in optimizer.param_groups for p in g['params']])
+
+    def _sync(self, optimizer):
+        self._sync_start(optimizer).wait()
 
     def run_iter(self, data_batch, train_mode, **kwargs):
         """Epoch_Based_Runner_Lambda.py:20-38."""
@@ -32,11 +35,15 @@ class MyEpochBasedRunnerLambda(BaseRunner):
             loss, head_out, feat_out, prev_loss = self.model.train_step(data_batch, **kwargs)
             self.optimizer.zero_grad()
             loss['loss'].backward()
-            self._sync(self.optimizer)
-            self.optimizer.step()
+            # The MEH step reads only detached features / losses and its own parameters (train_step_L), so the main update may be
+            # applied after it: the main all-reduce then runs under the whole MEH forward/backward.  Same values as the reference order
+            # (optimizer.step() before train_step_L, Epoch_Based_Runner_Lambda.py:27-35).
+            pending = self._sync_start(self.optimizer)
             loss_L = self._module().train_step_L(prev_loss, head_out, feat_out, _data=data_batch, **kwargs)
             self.optimizer_L.zero_grad()
             loss_L['loss'].backward()
+            pending.wait()
+            self.optimizer.step()
             self._sync(self.optimizer_L)
             self.optimizer_L.step()
             loss['log_vars'].update(loss_L['log_vars'])

@@ -135,11 +135,12 @@ def main():
             out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
             opt.zero_grad()
             out['loss'].backward()
-            gsync.all_reduce_grads(opt.param_groups[0]['params'])
-            opt.step()
+            pending = gsync.start(opt.param_groups[0]['params'])       # overlaps the MEH step (disjoint parameters, detached inputs)
             lossL = model.train_step_L(prev, head_out, feat_out)
             opt_L.zero_grad()
             lossL['loss'].backward()
+            pending.wait()
+            opt.step()
             gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
             opt_L.step()
         if do_score:
