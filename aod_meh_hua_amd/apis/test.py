@@ -90,5 +90,7 @@ def single_gpu_test(model, data_loader, show=False, out_dir=None, show_score_thr
     results = []
     for data in data_loader:
         data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
-        results.extend(model(return_loss=False, rescale=True, isEval=True, isUnc=False, **data, **kwargs))
+        kw = dict(kwargs)
+        kw.setdefault('isUnc', False)              # EvalHook forwards the whole `evaluation` dict (interval popped): isUnc, metric, ...
+        results.extend(model(return_loss=False, rescale=True, isEval=True, **data, **kw))
     return results

@@ -42,8 +42,17 @@ def train_detector_SSL(model, dataset, cfg, distributed=False, validate=False, t
         if type(hook).__name__ == 'OptimizerHook':
             runner.hooks.pop(i)
             break
-    if validate:
-        logger.info('EvalHook / mAP evaluation is a "next" row (SURVEY 8f rank 2); validation is skipped')
+    if validate:                      # train_Lambda.py:60-70
+        from ..datasets import build_dataloader, build_dataset
+        from ..mmcv_lite import EvalHook
+        val_cfg = dict(cfg.data.val)
+        val_samples_per_gpu = val_cfg.pop('samples_per_gpu', 1)
+        val_dataset = build_dataset(val_cfg, dict(test_mode=True))
+        val_dataloader = build_dataloader(val_dataset, samples_per_gpu=val_samples_per_gpu, workers_per_gpu=cfg.data.workers_per_gpu,
+                                          dist=distributed, shuffle=False)
+        eval_cfg = dict(cfg.get('evaluation', {}))
+        eval_cfg['by_epoch'] = cfg.runner['type'] != 'IterBasedRunner'
+        runner.register_hook(EvalHook(val_dataloader, **eval_cfg))
     if cfg.get('resume_from'):
         runner.resume(cfg.resume_from)
     elif cfg.get('load_from'):

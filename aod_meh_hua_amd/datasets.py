@@ -31,6 +31,19 @@ class SyntheticVOCDataset(Dataset):
     def __len__(self):
         return len(self.indices)
 
+    def get_ann_info(self, i):
+        """XMLDataset.get_ann_info format (xml_style.py:95-160): numpy boxes / labels (+ empty ignore sets)."""
+        d = self[i]
+        return dict(bboxes=d['gt_bboxes'].numpy().astype(np.float32), labels=d['gt_labels'].numpy().astype(np.int64),
+                    bboxes_ignore=np.zeros((0, 4), np.float32), labels_ignore=np.zeros((0,), np.int64))
+
+    def evaluate(self, results, metric='mAP', logger=None, proposal_nums=(100, 300, 1000), iou_thr=0.5, scale_ranges=None, **kwargs):
+        """VOCDataset.evaluate (datasets/voc.py:37-94), VOC07 11-point mode; extra EvalHook kwargs (show, isUnc, out_dir) are ignored
+        like the reference's signature swallows them."""
+        from .core.evaluation import evaluate_voc
+        return evaluate_voc(results, [self.get_ann_info(i) for i in range(len(self))], year=2007, classes=self.CLASSES, metric=metric,
+                            logger=logger, iou_thr=iou_thr)
+
     def __getitem__(self, i):
         idx = int(self.indices[i])
         H, W = self.size

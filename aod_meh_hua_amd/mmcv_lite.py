@@ -212,6 +212,20 @@ class Config:
         return self.dump()
 
 
+def print_log(msg, logger=None, level=logging.INFO):
+    """mmcv.utils.print_log: None -> print, 'silent' -> drop, Logger or logger name -> log."""
+    if logger is None:
+        print(msg)
+    elif logger == 'silent':
+        return
+    elif isinstance(logger, logging.Logger):
+        logger.log(level, msg)
+    elif isinstance(logger, str):
+        logging.getLogger(logger).log(level, msg)
+    else:
+        raise TypeError(f'logger should be a Logger, "silent" or None, got {type(logger)}')
+
+
 def mkdir_or_exist(d, mode=0o777):
     if d:
         os.makedirs(osp.expanduser(d), mode=mode, exist_ok=True)
@@ -557,6 +571,32 @@ class CheckpointHook(Hook):
     def after_train_epoch(self, runner):
         if self.every_n_epochs(runner, self.interval) and runner.rank == 0 and runner.work_dir:
             runner.save_checkpoint(self.out_dir or runner.work_dir, save_optimizer=self.save_optimizer)
+
+
+class EvalHook(Hook):
+    """mmdet/core/evaluation/eval_hooks.py:9-25 on mmcv's EvalHook: every `interval` epochs run single_gpu_test (isEval=True) on the
+    validation loader and `dataset.evaluate(results, logger=..., **eval_kwargs)`; the metrics land in runner.log_buffer.output."""
+
+    def __init__(self, dataloader, interval=1, by_epoch=True, start=None, save_best=None, **eval_kwargs):
+        self.dataloader, self.interval, self.by_epoch, self.start = dataloader, interval, by_epoch, start
+        self.eval_kwargs = eval_kwargs
+
+    def _should_evaluate(self, runner):
+        if self.start is not None and runner.epoch + 1 < self.start:
+            return False
+        return self.every_n_epochs(runner, self.interval)
+
+    def after_train_epoch(self, runner):
+        if not self.by_epoch or not self._should_evaluate(runner):
+            return None
+        from .apis.test import single_gpu_test
+        results = single_gpu_test(runner.model, self.dataloader, **self.eval_kwargs)
+        runner.log_buffer.output['eval_iter_num'] = len(self.dataloader)
+        eval_res = self.dataloader.dataset.evaluate(results, logger=runner.logger, **self.eval_kwargs)
+        for name, val in eval_res.items():
+            runner.log_buffer.output[name] = val
+        runner.log_buffer.ready = True
+        return eval_res
 
 
 class IterTimerHook(Hook):

@@ -104,3 +104,35 @@ def planted_heads_ssd(B=2, C1=21, seed=23, n_plant=5):
         reg.append(0.3 * torch.randn(B, A * 4, h, h, generator=g))
         Ls.append(torch.rand(B, A, h, h, generator=g) * 0.3 + 0.01)
     return cls, reg, Ls
+
+
+def detection_eval_case(seed=50, n_img=24, num_classes=20, with_ignore=True):
+    """Seeded detections + annotations in eval_map's format (numpy): per image 0-4 gts, detections = jittered copies of most gts
+    (some duplicated) + random false positives, a few ignored gts; scores in (0, 1)."""
+    import numpy as np
+    r = np.random.RandomState(seed)
+    dets, anns = [], []
+    for i in range(n_img):
+        G = r.randint(0, 5)
+        wh = r.uniform(20, 200, (G, 2))
+        xy = r.uniform(0, 300, (G, 2))
+        gtb = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        gtl = r.randint(0, num_classes, G).astype(np.int64)
+        ign = np.zeros(G, bool)
+        if with_ignore and G and i % 5 == 0:
+            ign[r.randint(0, G)] = True
+        per_cls = [[] for _ in range(num_classes)]
+        for b, l in zip(gtb, gtl):
+            for _ in range(r.randint(0, 3)):
+                j = b + r.normal(0, 8, 4).astype(np.float32)
+                per_cls[l].append(np.concatenate([j, [r.uniform(0.05, 1.0)]]).astype(np.float32))
+        for _ in range(r.randint(0, 6)):
+            l = r.randint(0, num_classes)
+            xy2, wh2 = r.uniform(0, 300, 2), r.uniform(20, 200, 2)
+            per_cls[l].append(np.concatenate([xy2, xy2 + wh2, [r.uniform(0.05, 0.9)]]).astype(np.float32))
+        dets.append([np.stack(c).astype(np.float32) if c else np.zeros((0, 5), np.float32) for c in per_cls])
+        ann = dict(bboxes=gtb[~ign], labels=gtl[~ign])
+        if with_ignore:
+            ann.update(bboxes_ignore=gtb[ign], labels_ignore=gtl[ign])
+        anns.append(ann)
+    return dets, anns
