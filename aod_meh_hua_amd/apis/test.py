@@ -27,11 +27,13 @@ class Uncertainty_fns:
                                      uPool2=cfg.uncertainty_pool2, **kwargs)
         return unc.cpu() if torch.is_tensor(unc) else [u.cpu() if torch.is_tensor(u) else u for u in unc]
 
-    @staticmethod
-    def Entropy_ALL(cfg, *args, **kwargs):
-        raise NotImplementedError('Entropy_ALL is a "next" row (SURVEY 8f rank 4)')
+    Entropy_ALL = Entropy_NMS          # test.py:52-63: same loop; the head switches on cfg.uncertainty_pool (ComputeScaleUnc path)
 
-    Entropy_NoNMS = Entropy_ALL
+    @staticmethod
+    def Entropy_NoNMS(cfg, *args, **kwargs):
+        # the reference's own Entropy_NoNMS path calls ComputeScaleUnc with L_scores=None (Lambda_L2.py:404-405,364) and raises a
+        # TypeError on the first batch: there is no behaviour to reproduce
+        raise NotImplementedError('uncertainty_pool=Entropy_NoNMS is not runnable in the reference either (L_scores is None there)')
 
 
 def calculate_uncertainty(cfg, *args, **kwargs):
@@ -53,11 +55,12 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
     bs = data_loader.batch_size or 1
     collate = data_loader.collate_fn
     prog_bar = ProgressBar(hi - lo)
-    chunks = []
+    chunks, conf_chunks = [], []
     kwargs.setdefault('scaleUnc', False)
     # HIP-graph replay of the scoring batch (graphs.GraphedScore) while batches keep one shape; side-effect options stay eager
     import os
     plain = not any(kwargs.get(k) for k in ('showNMS', 'saveUnc', 'saveMaxConf', 'scaleUnc', 'draw'))
+    others = []
     gscore = None
     if plain and os.environ.get('AOD_HIP_GRAPH', '1') != '0' and next(model.parameters()).is_cuda:
         from ..graphs import GraphedScore
@@ -77,9 +80,14 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
             with torch.no_grad():
                 result, unc, *others = model(return_loss=False, rescale=True, isEval=False, batchIdx=s // bs, image_ids=image_ids, **data, **kwargs)
         chunks.append(torch.as_tensor(unc, dtype=torch.float32, device=dev).reshape(-1))
+        if kwargs.get('saveMaxConf'):          # test.py:130,134
+            conf_chunks.append(torch.as_tensor(others[0], dtype=torch.float32, device=dev).reshape(-1))
         prog_bar.update(len(idxs))
     dev = next(model.parameters()).device
     local = torch.cat(chunks) if chunks else torch.zeros(0, device=dev)
+    if kwargs.get('saveMaxConf'):
+        conf = torch.cat(conf_chunks) if conf_chunks else torch.zeros(0, device=dev)
+        return gather_scores(local, N), gather_scores(conf, N)
     return gather_scores(local, N)
 
 

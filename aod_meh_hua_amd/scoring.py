@@ -61,9 +61,14 @@ def _meta_tensors(img_shapes, scale_factors, dev):
 class Candidates:
     """Outputs of the pre-NMS stage for a batch (concatenated levels)."""
 
-    def __init__(self, boxes, scores, lam, cand_anchor, level_start, any_fg, topk_idx):
+    def __init__(self, boxes, scores, lam, cand_anchor, level_start, any_fg, topk_idx, rowmax=None):
         self.boxes, self.scores, self.lam, self.cand_anchor = boxes, scores, lam, cand_anchor
         self.level_start, self.any_fg, self.topk_idx = level_start, any_fg, topk_idx
+        self.rowmax = rowmax              # per level [B, A_l]: max normalised class score of every anchor (before top-k)
+
+    def max_conf(self):
+        """getMaxConf (mmdet/utils/functions.py:467-476): per image, the largest class probability over all levels / anchors."""
+        return torch.stack([r.amax(dim=1) for r in self.rowmax], dim=1).amax(dim=1)
 
 
 def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors, nms_pre, C_, means, stds, rescale=True,
@@ -84,7 +89,7 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     cand_anchor = torch.empty(B, n, dtype=torch.int32, device=dev)
     img_hw, sc4 = _meta_tensors(img_shapes, scale_factors if rescale else None, dev)
     c0 = a0 = 0
-    level_start, idxs = [0], []
+    level_start, idxs, rowmaxes = [0], [], []
     for l in range(L):
         rowmax = torch.empty(B, A[l], device=dev)
         call('aod_softmax_rowmax', ptr(cls[l]), B, A[l], C_, fg_thr, ptr(rowmax), ptr(any_fg[l]), int(has_bg), stream())
@@ -93,13 +98,14 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
             idx = torch.empty(B, ks[l], dtype=torch.int32, device=dev)
             call('aod_topk_stable', ptr(rowmax), B, A[l], ks[l], ptr(idx), ks[l], stream())
         idxs.append(idx)
+        rowmaxes.append(rowmax)
         call('aod_gather_decode', ptr(cls[l]), ptr(reg[l]), ptr(lam[l]), ptr(mlvl_anchors[l].contiguous()), ptr(idx), B, A[l], ks[l], C_,
              ks[l], ptr(img_hw), ptr(sc4), _F4(*means), _F4(*stds), float(wh_ratio_clip), ptr(boxes), ptr(scores), ptr(lam_o),
              ptr(cand_anchor), n, c0, a0, 2 if has_bg else int(bool(normalize)), stream())
         c0 += ks[l]
         a0 += A[l]
         level_start.append(c0)
-    return Candidates(boxes, scores, lam_o, cand_anchor, level_start, any_fg, idxs)
+    return Candidates(boxes, scores, lam_o, cand_anchor, level_start, any_fg, idxs, rowmaxes)
 
 
 def multiclass_nms_batch(boxes, scores, score_thr, iou_thr, max_num):
@@ -146,7 +152,7 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
     isUnc = kwargs.get('isUnc')
     uPool = kwargs.get('uPool')
     if isUnc and uPool == 'Entropy_NoNMS':
-        raise NotImplementedError('uncertainty_pool=Entropy_NoNMS is a "next" row (SURVEY 8f rank 4)')
+        raise NotImplementedError('uncertainty_pool=Entropy_NoNMS crashes in the reference too (ComputeScaleUnc with L_scores=None)')
     if isUnc and uPool == 'Entropy_ALL':
         # Lambda_L2.py:281-283 (no top-k), :354 (no NMS), :364-365 ComputeScaleUnc + AggregateScaleUnc
         assert not has_bg, 'Entropy_ALL is built for the RetinaNet evidence head'
@@ -188,4 +194,6 @@ def score_batch(head, mlvl_cls_scores, mlvl_bbox_preds, mlvl_anchors, img_shapes
     det_results = [(dets[b], labels[b]) for b in range(B)]   # zero-padded to max_per_img rows (num_det rows are valid)
     if kwargs.get('_return_internals'):
         return det_results, unc, dict(cand=cand, dets=dets, labels=labels, keep=keep, num=num)
+    if kwargs.get('saveMaxConf'):            # Lambda_L2.py:375-380: third output = per-image max confidence (device tensor here)
+        return det_results, unc, cand.max_conf()
     return det_results, unc

@@ -220,3 +220,11 @@ def test_entropy_all_mode_vs_oracle_and_reference():
         if mode == 'scaleAvg_classAvg':
             assert (np.abs(u - umu) <= 5 * usd + 0.02 * umu).all(), (u, umu, usd)
     assert det[0][0].shape == (3069, 4) and det[0][1].shape == (3069, 21)
+
+
+def test_save_max_conf_matches_get_max_conf(run):
+    """saveMaxConf third output = getMaxConf (mmdet/utils/functions.py:467-476): max softmax probability over levels / anchors / classes."""
+    cand = run['it']['cand']
+    cls_p, _, _ = synth.planted_heads(2, 128, 128)
+    exp = torch.stack([c.permute(0, 2, 3, 1).reshape(2, -1, 20).softmax(-1).reshape(2, -1).max(-1)[0] for c in cls_p], 1).max(-1)[0]
+    assert np.allclose(cand.max_conf().cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-7)

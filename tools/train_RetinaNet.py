@@ -163,8 +163,12 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
             with torch.no_grad():
                 uncertainty = calculate_uncertainty(cfg, poolModel, data_loader, return_box=False, showNMS=False, saveUnc=False,
                                                     saveMaxConf=saveMaxConf, clsW=clsW, scaleUnc=False, score_thr=score_thr, iou_thr=iou_thr)
-            uncertainty = uncertainty.numpy() if torch.is_tensor(uncertainty) else np.asarray(uncertainty)
-            X_L, X_U = update_X_L(uncertainty, X_all, X_L, cfg.X_S_size, zeroRate=zeroRate, maxconf=None, useMaxConf=useMaxConf)
+            maxconf = None
+            if saveMaxConf:                                                   # :236-240
+                uncertainty, maxconf = uncertainty
+                maxconf = maxconf.cpu().numpy() if torch.is_tensor(maxconf) else np.asarray(maxconf)
+            uncertainty = uncertainty.cpu().numpy() if torch.is_tensor(uncertainty) else np.asarray(uncertainty)
+            X_L, X_U = update_X_L(uncertainty, X_all, X_L, cfg.X_S_size, zeroRate=zeroRate, maxconf=maxconf, useMaxConf=useMaxConf)
             if rank == 0:
                 np.save(cfg.work_dir + f'/X_L_{cycle + 1}.npy', X_L), np.save(cfg.work_dir + f'/X_U_{cycle + 1}.npy', X_U)
                 np.save(cfg.work_dir + f'/Unc_{cycle + 1}.npy', uncertainty)
