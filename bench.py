@@ -89,11 +89,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # debugging aid only: AOD_BENCH_ONE_GPU=1 runs every rank on device 0 over gloo (functional check of the multi-rank path on a
+    # single-GPU box); the driver's multi-GPU runs use one GPU per rank over RCCL
+    one_gpu = os.environ.get('AOD_BENCH_ONE_GPU') == '1'
+    local = 0 if one_gpu else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     from aod_meh_hua_amd import hipops as ho
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
     model, cfg = build_model(dev)
@@ -192,10 +199,12 @@ def main():
 
     # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv launch
     roof = None
+    barrier()
     if rank == 0:
         ho.PROFILE = []
-        step(args.warmup + args.steps, graph=False)          # HIP events around every launch need the eager path
-        torch.cuda.synchronize()
+    step(args.warmup + args.steps, graph=False)              # EVERY rank (the step contains collectives); HIP events need the eager path
+    barrier()
+    if rank == 0:
         agg = {}
         for kind, shape, flops, e0, e1 in ho.PROFILE:
             a = agg.setdefault(kind, [0, 0.0, 0.0])

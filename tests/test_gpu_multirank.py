@@ -1,0 +1,25 @@
+"""GPU: the multi-rank bench path (per-segment HIP graphs, asynchronous GradSync between them, sharded scoring + all-gather) runs end to
+end.  A 1-GPU box cannot host two RCCL ranks, so both ranks share device 0 over gloo (AOD_BENCH_ONE_GPU=1): same code path, slower
+collectives.  The collective semantics themselves are covered by the world-size-2 CPU tests (tests/test_distributed_cpu.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_on_one_gpu():
+    env = dict(os.environ, AOD_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2',
+           '--size', '128', '--no-cpu-baseline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
+    assert out['config']['launch'] == 'hip-graph replay' and out['roofline'] is not None
