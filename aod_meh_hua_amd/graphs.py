@@ -140,7 +140,7 @@ class GraphedTrainStep:
         self.graphs = []
         if self.sync is None or not is_dist():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):      # other threads (RCCL watchdog) may touch the runtime
                 for f in segs:
                     f()
             self.graphs.append(g)
@@ -148,7 +148,7 @@ class GraphedTrainStep:
             pool = torch.cuda.graph_pool_handle()
             for f in segs:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                     f()
                 self.graphs.append(g)
         ho.reset_zero_arena()
@@ -233,7 +233,7 @@ class GraphedScore:
             ho.reset_zero_arena()
             AF.PREP.refresh_if_stale()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._run()
             ho.reset_zero_arena()
             self.sig = sig

@@ -126,8 +126,11 @@ def main():
     gscore = GraphedScore(model, **{k: v for k, v in score_kw.items() if k != 'return_loss'}) if have_scoring else None
     data_dev = dict(data, gt_bboxes=[b.to(dev) for b in data['gt_bboxes']], gt_labels=[l.to(dev) for l in data['gt_labels']])
 
-    def step(it=0, do_train=do_train, do_score=do_score, graph=use_graph):
+    state = dict(graph_ok=use_graph)
+
+    def step(it=0, do_train=do_train, do_score=do_score, graph=None):
         """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python."""
+        graph = state['graph_ok'] if graph is None else graph
         if graph:
             if do_train:
                 gstep(data)
@@ -165,6 +168,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:        # capture up front; if the runtime refuses (it must not take the bench down), fall back to the eager path on ALL ranks
+        ok = 1
+        try:
+            step(0)
+        except Exception as e:      # noqa: BLE001
+            ok = 0
+            print(f'[bench] HIP-graph capture failed on rank {rank}: {type(e).__name__}: {e}; falling back to eager launches', file=sys.stderr)
+        if world > 1:
+            import torch.distributed as dist
+            t_ok = torch.tensor([ok], device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok)
+        state['graph_ok'] = use_graph = bool(ok)
     for i in range(args.warmup):
         step(i)
     barrier()
