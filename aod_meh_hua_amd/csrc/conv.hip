@@ -79,8 +79,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const int m = m0 + 32 * i + 8 * uw + prow;
     rH[i] = 0; rW[i] = 0; ry0[i] = 0; rx0[i] = 0; rbase[i] = 0;
     if (m < p.M) {
-      int sg = 0, mstart = 0;
-      while (sg < p.nseg - 1 && m >= p.seg_mend[sg]) { mstart = p.seg_mend[sg]; ++sg; }
+      // segment of row m: seg_mend[] is padded with M, so counting the boundaries <= m needs no loop and no dependent loads (the
+      // eight boundaries are scalar loads with constant indices); the geometry fields are then ONE level of indexed loads
+      int sg = 0;
+      if (p.nseg > 1) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
+      }
+      const int mstart = sg ? p.seg_mend[sg - 1] : 0;
       const int ml = m - mstart;
       const int ohw = p.segOH[sg] * p.segOW[sg];
       const int b = ml / ohw, rem = ml - b * ohw;
@@ -209,6 +215,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         sc[(wm * WM + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
+  // destination row of every tile row, resolved ONCE per tile (thread r < BM takes row r) and parked in LDS behind the fp32 staging:
+  // the segment search is a chain of dependent loads from the argument buffer, far too slow to repeat in each of the store iterations
+  long long* s_drow = reinterpret_cast<long long*>(smem + (size_t)BM * CP * 4);
+  if (t < BM) {
+    const int m = m0 + t;
+    int sg = 0;
+    if (p.nseg > 1) {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
+    }
+    s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0));
+  }
   __syncthreads();
 
   constexpr int NCH = BN / 8;              // 8-column chunks per tile row
@@ -233,9 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const int m = m0 + row;
     const int n = n0 + ec * 8;
     if (m >= p.M || n >= p.N) continue;
-    int sg = 0, mstart = 0;
-    while (sg < p.nseg - 1 && m >= p.seg_mend[sg]) { mstart = p.seg_mend[sg]; ++sg; }
-    const long long drow = p.seg_dst0[sg] + (m - mstart);
+    const long long drow = s_drow[row];
     float v[8], raw[8];
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
@@ -327,7 +343,7 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   const size_t stage = (size_t)(BM + BN) * 128 * 2;
-  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  const size_t epi = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;      // fp32 staging + destination-row table
   const size_t lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
