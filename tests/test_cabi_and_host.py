@@ -168,5 +168,5 @@ def test_synthetic_dataset_and_loader_contract():
     data = scatter_kwargs(batch, 'cpu')
     assert data['img'].shape == (2, 3, 64, 64) and len(data['img_metas']) == 2 and data['img_metas'][0]['pad_shape'] == (64, 64, 3)
     assert len(data['gt_bboxes']) == 2 and data['gt_bboxes'][0].shape[1] == 4 and data['gt_labels'][0].dtype == torch.int64
-    with pytest.raises(NotImplementedError):
-        build_dataset(dict(type='VOCDataset', ann_file='x'))
+    with pytest.raises(FileNotFoundError):                         # the real VOC path is built (tests/test_voc_data.py); no data here
+        build_dataset(dict(type='VOCDataset', ann_file='/nonexistent/ImageSets/Main/x.txt', img_prefix='/nonexistent/VOC2007/', pipeline=[]))
