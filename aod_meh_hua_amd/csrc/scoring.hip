@@ -246,7 +246,7 @@ extern "C" int aod_gather_decode(const float* cls, const float* reg, const float
 
 // ---------------------------------------------------------------- S4: multiclass NMS, one block per image
 // workspace per image: vflat[n*C] ints (flat index of the p-th valid entry)
-constexpr int TR = 4096;  // tranche of candidates sorted at a time
+constexpr int TR = 1024;  // tranche of candidates sorted at a time (max_num <= 256 detections usually come from the first one)
 __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
                                                  float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
                                                  long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat) {
