@@ -43,12 +43,12 @@ def train_detector_SSL(model, dataset, cfg, distributed=False, validate=False, t
             runner.hooks.pop(i)
             break
     if validate:                      # train_Lambda.py:60-70
-        from ..datasets import build_dataloader, build_dataset
+        from .. import datasets as _ds
         from ..mmcv_lite import EvalHook
         val_cfg = dict(cfg.data.val)
         val_samples_per_gpu = val_cfg.pop('samples_per_gpu', 1)
-        val_dataset = build_dataset(val_cfg, dict(test_mode=True))
-        val_dataloader = build_dataloader(val_dataset, samples_per_gpu=val_samples_per_gpu, workers_per_gpu=cfg.data.workers_per_gpu,
+        val_dataset = _ds.build_dataset(val_cfg, dict(test_mode=True))
+        val_dataloader = _ds.build_dataloader(val_dataset, samples_per_gpu=val_samples_per_gpu, workers_per_gpu=cfg.data.workers_per_gpu,
                                           dist=distributed, shuffle=False)
         eval_cfg = dict(cfg.get('evaluation', {}))
         eval_cfg['by_epoch'] = cfg.runner['type'] != 'IterBasedRunner'
