@@ -55,38 +55,6 @@ def dense_segs(segs):
     return out
 
 
-class _VersionCache:
-    """Derived tensors (packed weights, folded BN) keyed by the source tensors' (id, _version)."""
-
-    def __init__(self):
-        self.store = {}
-
-    def get(self, tag, srcs, make):
-        key = (tag,) + tuple(id(s) for s in srcs)
-        ver = tuple(s._version for s in srcs)
-        hit = self.store.get(key)
-        if hit is not None and hit[0] == ver and all(r() is s for r, s in zip(hit[2], srcs)):
-            return hit[1]
-        import weakref
-        val = make()
-        self.store[key] = (ver, val, [weakref.ref(s) for s in srcs])
-        return val
-
-
-CACHE = _VersionCache()
-
-
-def fold_bn(gamma, beta, mean, var, eps):
-    """Eval-mode BN as y = z*scale + shift (resnet.py:647-656 norm_eval): scale = gamma*rsqrt(var+eps)."""
-    def make():
-        with torch.no_grad():
-            invstd = torch.rsqrt(var.float() + eps)
-            scale = gamma.float() * invstd
-            shift = beta.float() - mean.float() * scale
-        return scale, shift, invstd
-    return CACHE.get('bn', (gamma, beta, mean, var), make)
-
-
 # --------------------------------------------------------------------------- batched parameter preparation
 import ctypes as _C
 import weakref as _weakref

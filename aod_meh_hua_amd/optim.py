@@ -53,7 +53,7 @@ class FusedSGD(torch.optim.Optimizer):
                 ps.append(p.data_ptr()), gs.append(g.data_ptr()), ms.append(st['momentum_buffer'].data_ptr()), ns.append(p.numel())
                 touched.append(p)
             self._launch(ps, gs, ms, ns, group, first)
-        # the kernel writes through raw pointers: tell autograd / the packed-weight cache (functional._VersionCache keys on
+        # the kernel writes through raw pointers: tell autograd / the parameter-preparation registry (functional.ParamPrep keys on
         # tensor._version) that these parameters changed, without one no-op kernel per tensor
         if touched:
             torch._C._autograd._unsafe_set_version_counter(touched, [p._version + 1 for p in touched])
