@@ -90,74 +90,138 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_warp, int& total) {
   return base + inc - v;
 }
 
-// in-LDS bitonic sort of n (power of two, <= 4096) u64 keys, DESCENDING
+// bitonic sort of n (power of two, 64 <= n <= TB) u64 keys in LDS, DESCENDING.  One key per thread, kept in a register: the 45 of 55
+// compare-exchange steps (n = 1024) whose partner sits in the same wave are two shuffles, only the 10 with stride >= 64 go through LDS
+// (a block-wide barrier costs about as much as everything else in a step).
 __device__ void bitonic_desc(unsigned long long* k, int n) {
+  __syncthreads();
+  const int t = threadIdx.x;
+  unsigned long long v = t < n ? k[t] : 0ull;
   for (int size = 2; size <= n; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < n / 2; i += TB) {
-        const int lo = 2 * i - (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = k[lo], b = k[hi];
-        if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
+      unsigned long long o;
+      if (stride >= 64) {
+        __syncthreads();                       // earlier partner reads are done
+        if (t < n) k[t] = v;
+        __syncthreads();
+        o = t < n ? k[t ^ stride] : 0ull;
+      } else {
+        const unsigned lo = __shfl_xor((unsigned)v, stride, 64), hi = __shfl_xor((unsigned)(v >> 32), stride, 64);
+        o = ((unsigned long long)hi << 32) | lo;
       }
+      const bool keep_max = (((t & stride) == 0) == ((t & size) == 0));     // lower index of a descending run keeps the larger key
+      v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
     }
+  __syncthreads();
+  if (t < n) k[t] = v;
   __syncthreads();
 }
 
 // Radix-select over u64 keys produced on the fly by `key(i)` for i in [0, n): finds the value of the k-th
 // largest key among those < upper (k >= 1, at least k such keys must exist).  8 passes x 8 bits.
+// Histogram increment with wave-level aggregation: score keys share their leading bytes, so a plain atomicAdd per lane serialises a
+// whole wave (often the whole block) on one LDS word.  Two rounds of "leader's bin -> ballot -> one add of the popcount" absorb the
+// dominant bins; whatever is left (high-entropy digits, little contention) takes the ordinary atomic.
+__device__ __forceinline__ void hist_add(int* hist, int bin, bool active) {
+  unsigned long long rem = __ballot(active);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (!rem) break;                                   // wave-uniform
+    const int leader = __ffsll((long long)rem) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb);
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+    rem &= ~same;
+    if (bin == lb) active = false;
+  }
+  if (active) atomicAdd(&hist[bin], 1);
+}
+
 template <typename KeyFn>
-__device__ unsigned long long radix_select_kth(KeyFn key, long long n, unsigned long long upper, int k, int* hist /*256 LDS ints*/) {
+__device__ unsigned long long radix_select_kth(KeyFn key, long long n, unsigned long long upper, int k, int* hist /*264 LDS ints*/) {
   unsigned long long prefix = 0ull, mask = 0ull;
   int remaining = k;
   for (int pass = 7; pass >= 0; --pass) {
     for (int i = threadIdx.x; i < 256; i += TB) hist[i] = 0;
     __syncthreads();
     const int shift = pass * 8;
-    for (long long i = threadIdx.x; i < n; i += TB) {
-      const unsigned long long v = key(i);
-      if (v < upper && (v & mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 0xffull)], 1);
+    for (long long i0 = 0; i0 < n; i0 += TB) {         // whole waves stay in the loop: hist_add uses wave-wide ballots
+      const long long i = i0 + threadIdx.x;
+      unsigned long long v = 0ull;
+      bool act = false;
+      if (i < n) { v = key(i); act = v < upper && (v & mask) == prefix; }
+      hist_add(hist, (int)((v >> shift) & 0xffull), act);
     }
     __syncthreads();
-    // every thread walks the histogram from the top (256 LDS reads, uniform)
-    int d = 255, acc = 0;
-    for (; d >= 0; --d) {
-      const int h = hist[d];
-      if (acc + h >= remaining) break;
-      acc += h;
+    // digit of the k-th key: the bin d with  sum(hist[d+1..255]) < remaining <= sum(hist[d..255]).  Suffix sums by shuffles inside the
+    // four waves that hold the 256 bins + their totals through LDS (a serial walk of the histogram is a chain of 256 dependent LDS
+    // reads per pass and used to be most of the kernel's time)
+    const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+    const int h_ = threadIdx.x < 256 ? hist[threadIdx.x] : 0;
+    int suf = h_;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_down(suf, o, 64);
+      if (lane_ + o < 64) suf += v;
     }
+    if (threadIdx.x < 256 && lane_ == 0) hist[256 + w_] = suf;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      int above = 0;
+      for (int ww = w_ + 1; ww < 4; ++ww) above += hist[256 + ww];
+      const int incl = suf + above, excl = incl - h_;
+      if (excl < remaining && remaining <= incl) { hist[260] = threadIdx.x; hist[261] = excl; hist[263] = (h_ == remaining - excl) ? 1 : 0; }
+    }
+    __syncthreads();
+    const int d = hist[260], acc = hist[261];
+    const bool whole_bin = hist[263] != 0;
     remaining -= acc;
     prefix |= ((unsigned long long)d) << shift;
     mask |= 0xffull << shift;
     __syncthreads();
+    // every key left in the selected bin is needed (always the case once the score bits are resolved and there are no ties): the
+    // threshold `key >= prefix` with the undetermined low digits at zero selects exactly the same set, the remaining passes are moot
+    if (whole_bin) break;
   }
   return prefix;
 }
 
 // ---------------------------------------------------------------- S2: stable top-k per (image, level)
 // key = (score bits << 32) | (0xffffffff - index): larger key = higher score, then lower index; keys are unique.
-__global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ score, long long A, int k, int* __restrict__ idx_out, long long out_pitch) {
-  __shared__ int hist[256];
+__global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ score, long long A, int k, int* __restrict__ idx_out, long long out_pitch,
+                                                  int cache_n) {
+  __shared__ int hist[264];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[1024];
-  const int b = blockIdx.x;
+  extern __shared__ float s_cache[];          // the row's scores: the 8 select passes + the compaction re-read them, and a dependent
+  const int b = blockIdx.x;                   // L2 round trip per 1024 elements and pass is what the kernel's time used to be
   const float* s = score + (long long)b * A;
-  auto key = [&](long long i) { return ((unsigned long long)__float_as_uint(s[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i); };
-  const unsigned long long kth = radix_select_kth(key, A, ~0ull, k, hist);
-  // compaction of keys >= kth (exactly k of them)
-  for (int i = threadIdx.x; i < 1024; i += TB) keys[i] = 0ull;
+  const long long ncache = A < (long long)cache_n ? A : (long long)cache_n;
+  for (long long i = threadIdx.x; i < ncache; i += TB) s_cache[i] = s[i];
   __syncthreads();
-  int base = 0;
+  auto key = [&](long long i) {
+    const float v = i < ncache ? s_cache[i] : s[i];
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+  };
+  const unsigned long long kth = radix_select_kth(key, A, ~0ull, k, hist);
+  // keys >= kth (exactly k of them) into LDS in ANY order -- the sort follows: one wave-aggregated counter instead of a block scan
+  for (int i = threadIdx.x; i < 1024; i += TB) keys[i] = 0ull;
+  if (threadIdx.x == 0) hist[262] = 0;
+  __syncthreads();
   for (long long c0 = 0; c0 < A; c0 += TB) {
     const long long i = c0 + threadIdx.x;
-    const bool take = i < A && key(i) >= kth;
-    int tot;
-    const int pos = block_excl_scan(take ? 1 : 0, s_warp, tot);
-    if (take) keys[base + pos] = key(i);
-    base += tot;
-    __syncthreads();
+    unsigned long long kv = 0ull;
+    bool take = false;
+    if (i < A) { kv = key(i); take = kv >= kth; }
+    const unsigned long long m = __ballot(take);
+    if (m) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&hist[262], __popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64);
+      if (take) keys[base + __popcll(m & ((1ull << lane) - 1ull))] = kv;
+    }
   }
   bitonic_desc(keys, 1024);
   for (int i = threadIdx.x; i < k; i += TB) idx_out[(long long)b * out_pitch + i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
@@ -166,7 +230,14 @@ __global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ scor
 extern "C" int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, int64_t out_pitch, aod_stream_t stream) {
   if (B == 0 || k == 0) return 0;
   AOD_CHECK_ARG(score && idx && k >= 1 && k <= 1024 && k <= A && out_pitch >= k, "topk: need 1 <= k <= min(1024, A)");
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, score, (long long)A, k, idx, (long long)out_pitch);
+  // static LDS of the kernel: keys 8 KB + histogram 1 KB + scan; the rest of the 160 KB caches the row
+  const int cache_n = (int)(A < 36864 ? A : 36864);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TB), (size_t)cache_n * 4, (hipStream_t)stream, score, (long long)A, k, idx, (long long)out_pitch, cache_n);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -250,7 +321,7 @@ constexpr int TR = 1024;  // tranche of candidates sorted at a time (max_num <= 
 __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
                                                  float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
                                                  long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat) {
-  __shared__ int hist[256];
+  __shared__ int hist[264];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[TR];
   __shared__ float kbox[256][4];
