@@ -339,20 +339,30 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   __syncthreads();
   int base = 0;
   float mymax = -INFINITY;
-  for (long long c0 = 0; c0 < NC; c0 += TB) {
-    const long long f = c0 + threadIdx.x;
-    bool v = false;
-    if (f < NC) {
-      const int cand = (int)(f / C), cl = (int)(f - (long long)cand * C);
-      v = sc[(long long)cand * (C + 1) + cl] > score_thr;
-      if (v) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
-        mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
+  // four consecutive flat entries per thread and iteration: one block scan per 4096 entries (the scan's two barriers dominate)
+  for (long long c0 = 0; c0 < NC; c0 += 4 * TB) {
+    const long long f0 = c0 + 4 * threadIdx.x;
+    bool v[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long f = f0 + u;
+      v[u] = false;
+      if (f < NC) {
+        const int cand = (int)(f / C), cl = (int)(f - (long long)cand * C);
+        v[u] = sc[(long long)cand * (C + 1) + cl] > score_thr;
+        if (v[u]) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+          mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
+          ++cnt;
+        }
       }
     }
     int tot;
-    const int pos = block_excl_scan(v ? 1 : 0, s_warp, tot);
-    if (v) vflat[base + pos] = (int)f;
+    int pos = base + block_excl_scan(cnt, s_warp, tot);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v[u]) vflat[pos++] = (int)(f0 + u);
     base += tot;
     __syncthreads();
   }
@@ -377,17 +387,21 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
     while (np2 < take) np2 <<= 1;
     for (int i = threadIdx.x; i < np2; i += TB) keys[i] = 0ull;
     __syncthreads();
-    int kb = 0;
-    for (int c0 = 0; c0 < nvalid; c0 += TB) {
+    if (threadIdx.x == 0) hist[262] = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nvalid; c0 += TB) {          // any order: the sort follows
       const int i = c0 + threadIdx.x;
       unsigned long long kv = 0ull;
       bool t = false;
       if (i < nvalid) { kv = key(i); t = kv < upper && kv >= kth; }
-      int tot;
-      const int pos = block_excl_scan(t ? 1 : 0, s_warp, tot);
-      if (t) keys[kb + pos] = kv;
-      kb += tot;
-      __syncthreads();
+      const unsigned long long m = __ballot(t);
+      if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        int b0 = 0;
+        if (lane == leader) b0 = atomicAdd(&hist[262], __popcll(m));
+        b0 = __shfl(b0, leader, 64);
+        if (t) keys[b0 + __popcll(m & ((1ull << lane) - 1ull))] = kv;
+      }
     }
     bitonic_desc(keys, np2);
     // greedy scan by wave 0, 64 candidates per round
