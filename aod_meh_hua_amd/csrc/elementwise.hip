@@ -245,7 +245,25 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int bl
   const float* g = c.g[ti];
   float* mbuf = c.m[ti];
   const long long n = c.n[ti];
-  for (long long i = (long long)bi * 256 + threadIdx.x; i < n; i += (long long)blocks_per_tensor * 256) {
+  // 16-B accesses (torch allocations are 512-B aligned; a tensor whose pointers are not 16-B aligned or whose tail is short takes
+  // the scalar path): 20 B of traffic per parameter, nothing else
+  const bool vec = ((((size_t)p) | ((size_t)g) | ((size_t)mbuf)) & 15) == 0;
+  const long long n4 = vec ? n / 4 : 0;
+  for (long long i = (long long)bi * 256 + threadIdx.x; i < n4; i += (long long)blocks_per_tensor * 256) {
+    const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = first_step ? (f32x4){0.f, 0.f, 0.f, 0.f} : reinterpret_cast<const f32x4*>(mbuf)[i];
+    f32x4 po;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float d = gv[u] * grad_scale + wd * pv[u];
+      const float b = first_step ? d : momentum * mv[u] + d;
+      mv[u] = b;
+      po[u] = pv[u] - lr * b;
+    }
+    reinterpret_cast<f32x4*>(mbuf)[i] = mv;
+    reinterpret_cast<f32x4*>(p)[i] = po;
+  }
+  for (long long i = n4 * 4 + (long long)bi * 256 + threadIdx.x; i < n; i += (long long)blocks_per_tensor * 256) {
     const float pv = p[i];
     const float d = g[i] * grad_scale + wd * pv;
     const float b = first_step ? d : momentum * mbuf[i] + d;
