@@ -738,7 +738,7 @@ struct PrepItem {            // 16 x 8 bytes, filled by the host into a device t
 // Layers with more than 9 taps (the frozen 7x7 stem) take the element-wise path.
 constexpr int PREP_T = 32, PREP_RS = 9;
 __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restrict__ items, int nitems) {
-  __shared__ float tile[PREP_RS][PREP_T][PREP_T + 1];
+  __shared__ float tile[PREP_RS][PREP_T][PREP_T + 1];     // used as a linear [32][32*RS | 1] array
   int lo = 0, hi = nitems - 1;
   while (lo < hi) {      // block -> item: binary search over blk0 (items are in block order)
     const int mid = (lo + hi + 1) >> 1;
@@ -772,33 +772,35 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
   const int to = lb / tiles_c, tc = lb - to * tiles_c;
   const int o0 = to * PREP_T, c0 = tc * PREP_T;
   const int RS = it.RS;
-  // load: for each output channel the run w[o][c0 .. c0+32)[0 .. RS) is contiguous
-  const int run = PREP_T * RS;
+  const int run = PREP_T * RS;                 // floats of one output channel inside the tile: (c0 .. c0+32) x taps, contiguous in OIHW
+  const int pitch = run | 1;                   // odd LDS pitch: column reads (dgrad image) stay conflict-free
+  float* tl = &tile[0][0][0];                  // linear [32][pitch]
+  const int cvalid = it.I - c0 < PREP_T ? it.I - c0 : PREP_T;     // real input channels in this tile (may be <= 0)
   for (int ol = 0; ol < PREP_T; ++ol) {
     const int o = o0 + ol;
-    for (int idx = t; idx < run; idx += 256) {
-      const int cl = idx / RS, rs = idx - cl * RS;
-      const int c = c0 + cl;
-      tile[rs][ol][cl] = (o < it.O && c < it.I) ? it.w[((long long)o * it.I + c0) * RS + idx] : 0.f;
-    }
+    const float* src = it.w + ((long long)o * it.I + c0) * RS;
+    for (int idx = t; idx < run; idx += 256) tl[ol * pitch + idx] = (o < it.O && idx < cvalid * RS) ? src[idx] : 0.f;
   }
   __syncthreads();
   const int l32 = t & 31, g8 = t >> 5;      // 8 groups of 32 lanes
   // forward image [O][RS][Ipad]: runs of 32 input channels
-  for (int j = g8; j < PREP_T * RS; j += 8) {
-    const int ol = j / RS, rs = j - ol * RS;
-    const int o = o0 + ol, c = c0 + l32;
-    if (o < it.O && c < it.Ipad) it.wf[((long long)o * RS + rs) * it.Ipad + c] = (bf16_t)tile[rs][ol][l32];
+  {
+    const int c = c0 + l32;
+    for (int ol = g8; ol < PREP_T; ol += 8) {
+      const int o = o0 + ol;
+      if (o < it.O && c < it.Ipad)
+        for (int rs = 0; rs < RS; ++rs) it.wf[((long long)o * RS + rs) * it.Ipad + c] = (bf16_t)tl[ol * pitch + l32 * RS + rs];
+    }
   }
   // dgrad image [I][RS][Opad] (x BN scale): runs of 32 output channels
   if (it.wd) {
     const int o = o0 + l32;
     float sc = 1.f;
     if (it.gamma && o < it.O) sc = it.gamma[o] * rsqrtf(it.var[o] + it.eps);
-    for (int j = g8; j < PREP_T * RS; j += 8) {
-      const int cl = j / RS, rs = j - cl * RS;
+    for (int cl = g8; cl < PREP_T; cl += 8) {
       const int c = c0 + cl;
-      if (c < it.I && o < it.Opad) it.wd[((long long)c * RS + rs) * it.Opad + o] = (bf16_t)(tile[rs][l32][cl] * sc);
+      if (c < it.I && o < it.Opad)
+        for (int rs = 0; rs < RS; ++rs) it.wd[((long long)c * RS + rs) * it.Opad + o] = (bf16_t)(tl[l32 * pitch + cl * RS + rs] * sc);
     }
   }
   if (it.gamma && tc == 0 && t < PREP_T && o0 + t < it.O) {
