@@ -135,3 +135,27 @@ def test_optimizer_step_reaches_the_packed_weights(built):
     model.load_state_dict(sd, strict=True)
     assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)
     assert l1 == l2, (l1, l2)
+
+
+def test_train_step_with_an_image_without_ground_truth(built):
+    """Edge case of the reference's assigner (max_iou_assigner.py:145-161, num_gts == 0): every anchor of that image is background,
+    num_total_samples counts max(num_pos, 1) per image.  HIP path vs the fp32 oracle."""
+    model, sd0 = built
+    model.load_state_dict(sd0, strict=True)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    H = W = 128
+    img = synth.images(2, H, W, seed=77)
+    gtb, gtl = synth.random_gts(2, H, W, seed=78, gmin=2, gmax=3)
+    gtb[1], gtl[1] = torch.zeros(0, 4), torch.zeros(0, dtype=torch.long)
+    torch.set_num_threads(8)
+    o = omodel.train_step(sd, img, gtb, gtl)
+    data = dict(img=img.cuda(), img_metas=synth.metas(2, H, W), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    model.train()
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    assert int(head_out[8]) == o['targets']['num_total_pos']
+    assert np.allclose(float(out['loss'].detach()), float(o['loss']), rtol=2e-2), (float(out['loss']), float(o['loss']))
+    lab = torch.cat([l.reshape(2, -1) for l in head_out[4]], 1).cpu()
+    assert bool((lab[1] == 20).all()) and int((lab[0] < 20).sum()) > 0        # image 1: background everywhere
+    model.zero_grad()
+    out['loss'].backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
