@@ -22,6 +22,13 @@ torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)      # w
 from .models.dense_heads.L_anchor_head import PackedGT
 
 
+def _pin_caches():
+    """References to every cached device buffer a captured kernel may point at (row tables, the wgrad scratch, parameter-preparation
+    buffers and table, scoring meta tensors): the host-side caches evict / regrow, a graph must keep what it captured alive."""
+    from . import scoring
+    return (dict(ho._ROW_TABLES), dict(ho._DW), list(AF.PREP.items.values()), AF.PREP.table, dict(scoring._META))
+
+
 def _unwrap(model):
     return model.module if hasattr(model, 'module') else model
 
@@ -152,6 +159,7 @@ class GraphedTrainStep:
                     f()
                 self.graphs.append(g)
         ho.reset_zero_arena()
+        self._keep = _pin_caches()
         self.touched = self._params(self.opt) + self._params(self.opt_L)
 
     # ------------------------------------------------------------------ call
@@ -236,6 +244,7 @@ class GraphedScore:
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._run()
             ho.reset_zero_arena()
+            self._keep = _pin_caches()
             self.sig = sig
         self.img.copy_(img, non_blocking=True)
         self.ids.copy_(image_ids, non_blocking=True)
