@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libaodhip.so')
+LIB_PATH = os.environ.get('AOD_HIP_LIB') or os.path.join(_HERE, 'lib', 'libaodhip.so')      # AOD_HIP_LIB: instrumented debug builds (tools/dbg)
 
 
 class AodHipError(RuntimeError):

@@ -26,11 +26,29 @@ struct ConvKParams {
   int C, N, K, R, S, stride, pad, dil, transposed, relu, out_f32;
   int nseg, M;
   int tiles_m, tiles_n;
+  int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
   long long seg_src0[8], seg_dst0[8];
   int seg_mend[8];
 };
+
+#ifdef AOD_TILE_TIMING
+// debug build only (tools/dbg/tile_timing.py): per-workgroup wall-clock stamps (100 MHz) at the phase boundaries of the tile
+__device__ unsigned long long* g_tile_stamps = nullptr;
+extern "C" int aod_dbg_set_tile_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), &buf, sizeof(buf)); }
+#define TSTAMP(k) do { if (g_tile_stamps && threadIdx.x == 0) g_tile_stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(k) do {} while (0)
+#endif
+
+// n / d for n < 2^22 (the float product is within 1 of the quotient; one correction step makes it exact)
+__device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned d) {
+  unsigned q = (unsigned)((float)n * __builtin_amdgcn_rcpf((float)d));
+  const int r = (int)(n - q * d);
+  q = r < 0 ? q - 1 : ((unsigned)r >= d ? q + 1 : q);
+  return q;
+}
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   // bijective remap: blocks that share an XCD (bid % 8) get a contiguous range of tiles
@@ -52,12 +70,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
+  TSTAMP(0);
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tiles_m * p.tiles_n;
   const int tile = xcd_swizzle(blockIdx.x, nwg);
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+#ifdef AOD_TILE_TIMING
+  if (m0 < 0) return;      // (forces the argument loads ahead of the stamp)
+  TSTAMP(8);
+#endif
 
   // ---- operand staging: LDS-DMA (buffer_load_dwordx4 ... lds), no VGPR round trip, no ds_write.
   // One wave-instruction fills 1 KiB = 8 tile rows x 8 chunks LINEARLY (lane l -> row l>>3, slot l&7); the
@@ -74,29 +97,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 
   unsigned rbase[A_IT];                             // byte offset of pixel (b, 0, 0) of the row's source block
   int ry0[A_IT], rx0[A_IT], rH[A_IT], rW[A_IT];
+  // segment of a row: seg_mend[] is padded with M, so counting the boundaries <= m needs no loop.  Nearly every tile lies inside ONE
+  // segment: its index is then workgroup-uniform and the geometry comes from scalar loads; only tiles that straddle a segment boundary
+  // take the per-lane path, whose indexed loads from the argument buffer are a serial chain of vector-memory round trips
+  auto seg_of = [&](int m) {
+    int sg = 0;
+    if (p.nseg > 1) {
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + 32 * i + 8 * uw + prow;
-    rH[i] = 0; rW[i] = 0; ry0[i] = 0; rx0[i] = 0; rbase[i] = 0;
-    if (m < p.M) {
-      // segment of row m: seg_mend[] is padded with M, so counting the boundaries <= m needs no loop and no dependent loads (the
-      // eight boundaries are scalar loads with constant indices); the geometry fields are then ONE level of indexed loads
-      int sg = 0;
-      if (p.nseg > 1) {
-#pragma unroll
-        for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
-      }
-      const int mstart = sg ? p.seg_mend[sg - 1] : 0;
-      const int ml = m - mstart;
-      const int ohw = p.segOH[sg] * p.segOW[sg];
-      const int b = ml / ohw, rem = ml - b * ohw;
-      const int oy = rem / p.segOW[sg], ox = rem - oy * p.segOW[sg];
-      rH[i] = p.segH[sg]; rW[i] = p.segW[sg];
-      rbase[i] = (unsigned)((p.seg_src0[sg] + (long long)b * p.segH[sg] * p.segW[sg]) * p.C * 2);
-      if (p.transposed) { ry0[i] = oy + p.pad; rx0[i] = ox + p.pad; }
-      else { ry0[i] = oy * p.stride - p.pad; rx0[i] = ox * p.stride - p.pad; }
+      for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
     }
+    return sg;
+  };
+  const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+  const int sg_first = seg_of(m0);
+  const bool one_seg = sg_first == seg_of(m_last);
+  struct Geo { unsigned mstart, OW, ohw, H, W, src0b, imgb; };
+  auto load_geo = [&](int sg) {
+    Geo g;
+    g.mstart = sg ? (unsigned)p.seg_mend[sg - 1] : 0u;
+    g.OW = (unsigned)p.segOW[sg]; g.ohw = (unsigned)p.segOH[sg] * g.OW;
+    g.H = (unsigned)p.segH[sg]; g.W = (unsigned)p.segW[sg];
+    // byte offsets fit 32 bits (x_bytes < 3.5 GiB is checked on the host), so the arithmetic may wrap on the way
+    g.src0b = (unsigned)((unsigned long long)p.seg_src0[sg] * (unsigned)(p.C * 2));
+    g.imgb = g.H * g.W * (unsigned)(p.C * 2);
+    return g;
+  };
+  const Geo gu = load_geo(sg_first);          // workgroup-uniform: scalar loads, once
+  // destination row of every tile row, parked in LDS behind the staging / epilogue area (read by the general epilogue, and by the
+  // fast one on tiles that straddle a segment boundary)
+  constexpr int EPI_BYTES = BM * CP * 4;
+  constexpr int DROW_OFF = (2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES);
+  long long* s_drow = reinterpret_cast<long long*>(smem + DROW_OFF);
+  if (t < BM) {
+    const int m = m0 + t;
+    if (one_seg) s_drow[t] = p.seg_dst0[sg_first] + (long long)((unsigned)m - gu.mstart);
+    else { const int sg = m < p.M ? seg_of(m) : 0; s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0)); }
   }
+  TSTAMP(10);
   // tap state of this lane's k-chunk
   int c8 = kc, tr = 0, ts = 0;
   while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
@@ -124,9 +161,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   bool new_tap = true;
   const int steps_per_tap = fast_tap ? C8 / CPR : 1;
 
-  auto gload = [&](int kt, int buf) {
+  auto load_a = [&](int buf) {
     char* sa = smem + buf * STAGE;
-    char* sb = sa + A_BYTES;
     if (new_tap) {
       const bool tapok = tr < p.R;
       const int dy = tr * p.dil, dx = ts * p.dil;
@@ -149,13 +185,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       const unsigned off = aoff[i];     // (a plain local: a subscript of a template-sized array is type-dependent and the host pass rejects it as a builtin argument)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
+  };
+  auto load_b = [&](int kt, int buf) {
+    char* sb = smem + buf * STAGE + A_BYTES;
     const bool kok = (kt * BK + kc * 8) < p.K;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const unsigned off = kok ? woff[i] : OOB_BASE;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
-    // advance by one K-step
+  };
+  auto advance = [&]() {      // state of the next K-step
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) woff[i] += BK * 2;
     c8 += CPR;
@@ -168,6 +208,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       new_tap = true;
     }
   };
+  auto gload = [&](int kt, int buf) { load_a(buf); load_b(kt, buf); advance(); };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -176,8 +217,100 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  gload(0, 0);
+  TSTAMP(1);
+  // epilogue operands (bias / scale vectors of this thread's 8 columns; residual and ReLU mask of its E_IT row segments): issued
+  // together with the first operand tile and consumed after the main loop -- a load-use chain per store iteration would expose one
+  // memory latency per 16 B and cap memory-bound layers at a third of the bandwidth
+  constexpr int NCH = BN / 8;              // 8-column chunks per tile row
+  constexpr int E_IT = BM * NCH / 256;
+  const int ec = t % NCH, er = t / NCH;
+  float cs1[8], cb1[8], cs2[8];
+  bf16x8 pres[E_IT], pmask[E_IT];
+  // interior tiles of the common configuration (bf16 destination, bias only, N % 8 == 0) take an epilogue without per-thread
+  // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
+  const bool fast = !p.out_f32 && !p.zraw && !p.pre_scale && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
+  const long long drow_lin = one_seg ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
+  const long long lin_off = (drow_lin + m0 + er) * p.N + n0 + ec * 8;     // element offset of this thread's first row segment
+  const long long lin_step = (long long)(256 / NCH) * p.N;                // ... and the distance to its next one
+  auto prefetch_epilogue = [&](bool from_table) {
+    const int n = n0 + ec * 8;
+    if (fast) {
+      {
+        // bias through a buffer descriptor that is EMPTY when there is no bias: the range check then returns zeros and the load needs
+        // no branch (a branch would make the compiler wait for the loaded values where the two paths merge, i.e. right here)
+        const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_shift, 0, p.pre_shift ? p.N * 4 : 0, 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4 + 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cb1[j] = __uint_as_float(b0[j]); cb1[4 + j] = __uint_as_float(b1[j]); }
+      }
+      if (!from_table) {
+        if (p.res) {
+#pragma unroll
+          for (int it = 0; it < E_IT; ++it) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + lin_off + it * lin_step);
+        }
+        if (p.mask) {
+#pragma unroll
+          for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + lin_off + it * lin_step);
+        }
+        return;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = n + j < p.N;
+        cs1[j] = (p.pre_scale && ok) ? p.pre_scale[n + j] : 1.f;
+        cb1[j] = (p.pre_shift && ok) ? p.pre_shift[n + j] : 0.f;
+        cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
+      }
+    }
+    if (p.res || p.mask) {
+#pragma unroll
+      for (int it = 0; it < E_IT; ++it) {
+        const int row = er + it * (256 / NCH);
+        const bool ok = (m0 + row < p.M) && (n + 8 <= p.N);
+        const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
+        const long long off = ok ? drow * p.N + n : 0;
+        if (p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
+        if (p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
+      }
+    }
+  };
+  // first stage: the weight tile and the epilogue operands do not depend on the row decode -- they go out first and are in flight
+  // while the rows are resolved
+  load_b(0, 0);
+  if (one_seg) prefetch_epilogue(false);
+  {
+    // Row decode: lane j of a wave resolves the wave's row j & 31 ONCE (source block, top-left tap, image size); the 8 lanes that
+    // gather the 8 k-chunks of a row then pick the record up with a lane shuffle (decoding per lane repeated the two divisions of a
+    // row 8 times, four rows per lane)
+    const int j = lane & 31;
+    const int m = m0 + 32 * (j >> 3) + 8 * uw + (j & 7);
+    const int sg = one_seg ? sg_first : (m < p.M ? seg_of(m) : 0);
+    const Geo gl = one_seg ? gu : load_geo(sg);
+    const unsigned ml = (unsigned)m - gl.mstart;
+    const unsigned b = p.bigrows ? ml / gl.ohw : udiv_small(ml, gl.ohw);
+    const unsigned rem = ml - b * gl.ohw;
+    const unsigned oy = p.bigrows ? rem / gl.OW : udiv_small(rem, gl.OW);
+    const unsigned ox = rem - oy * gl.OW;
+    const int d_hw = m < p.M ? (int)(gl.H | (gl.W << 16)) : 0;     // rows past M keep H = W = 0: every tap of theirs is out of the image
+    const int d_base = (int)(gl.src0b + b * gl.imgb);
+    const int d_y = p.transposed ? (int)oy + p.pad : (int)oy * p.stride - p.pad;
+    const int d_x = p.transposed ? (int)ox + p.pad : (int)ox * p.stride - p.pad;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int src = i * 8 + prow;
+      const int hw = __shfl(d_hw, src);
+      rbase[i] = (unsigned)__shfl(d_base, src); ry0[i] = __shfl(d_y, src); rx0[i] = __shfl(d_x, src);
+      rH[i] = hw & 0xffff; rW[i] = (int)((unsigned)hw >> 16);
+    }
+  }
+  TSTAMP(9);
+  load_a(0);
+  advance();
   __syncthreads();
+  if (!one_seg) prefetch_epilogue(true);    // tile straddles a segment boundary: destination rows come from the LDS table
+  TSTAMP(2);
   const int lr = lane & 15, lq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -207,6 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, [BM][CP]) -> row-major vector stores
+  TSTAMP(3);
   float* sc = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -215,37 +349,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         sc[(wm * WM + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
-  // destination row of every tile row, resolved ONCE per tile (thread r < BM takes row r) and parked in LDS behind the fp32 staging:
-  // the segment search is a chain of dependent loads from the argument buffer, far too slow to repeat in each of the store iterations
-  long long* s_drow = reinterpret_cast<long long*>(smem + (size_t)BM * CP * 4);
-  if (t < BM) {
-    const int m = m0 + t;
-    int sg = 0;
-    if (p.nseg > 1) {
-#pragma unroll
-      for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
-    }
-    s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0));
-  }
   __syncthreads();
+  TSTAMP(4);
 
-  constexpr int NCH = BN / 8;              // 8-column chunks per tile row
-  constexpr int E_IT = BM * NCH / 256;
-  const int ec = t % NCH, er = t / NCH;
-  // this thread always owns the same 8 output columns: fetch their scale/shift vectors once
-  float cs1[8], cb1[8], cs2[8];
-  {
-    const int n = n0 + ec * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = n + j < p.N;
-      cs1[j] = (p.pre_scale && ok) ? p.pre_scale[n + j] : 1.f;
-      cb1[j] = (p.pre_shift && ok) ? p.pre_shift[n + j] : 0.f;
-      cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
-    }
-  }
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+  // fast tiles: no per-thread predicates at all, only workgroup-uniform branches -- the general loop below costs ~500 instructions
+  // per 16-B store, this one under 100
+  if (fast) {
+    bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + n0 + ec * 8;
+    bf16_t* const yl = reinterpret_cast<bf16_t*>(p.y) + lin_off;
+#pragma unroll
+    for (int it = 0; it < E_IT; ++it) {
+      const int row = er + it * (256 / NCH);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = v0[j] + cb1[j]; v[4 + j] = v1[j] + cb1[4 + j]; }
+      if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)pres[it][j];
+      }
+      if (p.mask) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)pmask[it][j] > 0.f) ? v[j] : 0.f;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      bf16x8 ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { csum[j] += v[j]; ov[j] = (bf16_t)v[j]; }
+      *reinterpret_cast<bf16x8*>(one_seg ? yl + it * lin_step : yb + s_drow[row] * p.N) = ov;
+    }
+  } else
+#pragma unroll
   for (int it = 0; it < E_IT; ++it) {
     const int row = er + it * (256 / NCH);
     const int m = m0 + row;
@@ -265,12 +404,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
       if (p.res) {
-        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.res + off);
+        const bf16x8 rv = pres[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
       if (p.mask) {
-        const bf16x8 mv = *reinterpret_cast<const bf16x8*>(p.mask + off);
+        const bf16x8 mv = pmask[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }
@@ -322,6 +461,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       }
     }
   }
+  TSTAMP(5);
+#ifdef AOD_TILE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);      // vmcnt/lgkmcnt 0: stores acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSTAMP(6);
+  if (g_tile_stamps && threadIdx.x == 0)
+    g_tile_stamps[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#endif
   if (p.colsum) {
     // column sums of this tile: per-thread partials -> LDS [256 / NCH][BN] -> one fp32 atomic per column
     __syncthreads();
@@ -343,8 +490,8 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   const size_t stage = (size_t)(BM + BN) * 128 * 2;
-  const size_t epi = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;      // fp32 staging + destination-row table
-  const size_t lds = stage > epi ? stage : epi;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -373,6 +520,7 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
       const int ew = (s.OW + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
       AOD_CHECK_ARG(eh == s.H && ew == s.W, "dgrad: segment %d dZ %dx%d != expected %dx%d", i, s.H, s.W, eh, ew);
     }
+    AOD_CHECK_ARG(s.H < 65536 && s.W < 65536 && s.OH < 65536 && s.OW < 65536, "conv: segment %d image side >= 65536", i);
     p.segB[i] = s.B; p.segH[i] = s.H; p.segW[i] = s.W; p.segOH[i] = s.OH; p.segOW[i] = s.OW;
     p.seg_src0[i] = s.src_row0; p.seg_dst0[i] = s.dst_row0;
     m += (long long)s.B * s.OH * s.OW;
@@ -381,6 +529,9 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
   }
   for (int i = d->nseg; i < 8; ++i) { p.segB[i] = p.segH[i] = p.segW[i] = p.segOH[i] = p.segOW[i] = 0; p.seg_src0[i] = p.seg_dst0[i] = 0; p.seg_mend[i] = (int)m; }
   p.M = (int)m;
+  p.bigrows = 0;
+  for (int i = 0; i < d->nseg; ++i)
+    if ((long long)d->seg[i].B * d->seg[i].OH * d->seg[i].OW >= (1ll << 22)) p.bigrows = 1;
   return 0;
 }
 
@@ -411,6 +562,12 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups
   auto ntiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const long long want = 512;
+  static const char* dbg = getenv("AOD_TILE_1X1");
+  if (dbg && p.R * p.S == 1 && p.K <= 1024) {
+    if (!strcmp(dbg, "64x64")) { launch_conv<64, 64>(p, st); AOD_LAUNCH_CHECK(); return 0; }
+    if (!strcmp(dbg, "64x128") && p.N > 64) { launch_conv<64, 128>(p, st); AOD_LAUNCH_CHECK(); return 0; }
+    if (!strcmp(dbg, "128x64")) { launch_conv<128, 64>(p, st); AOD_LAUNCH_CHECK(); return 0; }
+  }
   if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
   else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
   else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);

@@ -33,7 +33,7 @@ def _prof(kind, desc, fn):
     e0.record()
     r = fn()
     e1.record()
-    PROFILE.append((kind, (m, desc.N, desc.R * desc.S * desc.C), flops, e0, e1))
+    PROFILE.append((kind, (m, desc.N, desc.R * desc.S * desc.C, desc.R * desc.S, desc.stride), flops, e0, e1))
     return r
 
 

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--mode', default='train+score', choices=['train', 'score', 'train+score'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--shapes', default=None, help='write the per-shape conv breakdown of the instrumented step to this file')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
     return ap.parse_args()
 
@@ -227,6 +228,19 @@ def main():
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += flops
+        if args.shapes:
+            by = {}
+            for kind, shape, flops, e0, e1 in ho.PROFILE:
+                a = by.setdefault((kind,) + tuple(shape), [0, 0.0, flops])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1) * 1e3
+            with open(args.shapes, 'w') as f:
+                f.write('kind      M       N     K   RS st   n   us_each   TFLOP/s   GB/s(act in+out)\n')
+                for (kind, m, n, k, rs, st), (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                    c = k // rs
+                    m_in = m * st * st if kind == 'fwd' else m
+                    byts = 2.0 * (m_in * (c if kind != 'dgrad' else n) + m * (n if kind != 'dgrad' else c)) if kind != 'wgrad' else 2.0 * (m_in * c + m * n)
+                    f.write(f'{kind:6s}{m:8d}{n:6d}{k:6d}{rs:4d}{st:3d}{cnt:4d}{us / cnt:10.1f}{fl / (us / cnt) / 1e6:10.1f}{byts / (us / cnt) / 1e3:10.1f}   total {us:8.1f}\n')
         ho.PROFILE = None
         kind = max(agg, key=lambda k: agg[k][1])
         n, tsec, fl = agg[kind]
