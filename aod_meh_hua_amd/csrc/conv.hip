@@ -26,6 +26,8 @@ struct ConvKParams {
   int C, N, K, R, S, stride, pad, dil, transposed, relu, out_f32;
   int nseg, M;
   int tiles_m, tiles_n;
+  int ksplit;         // > 1: split-K launch -- K-steps are divided over ksplit workgroups per tile, each stores its fp32 partial tile
+  float* ws;          // split-K workspace, fp32 [ksplit][M][N] in GEMM-row order; conv_splitk_finalize sums the slabs IN ORDER (deterministic)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  const int tile = xcd_swizzle(blockIdx.x, nwg);
+  const int wg = xcd_swizzle(blockIdx.x, nwg * p.ksplit);
+  const int tile = wg % nwg, kz = wg / nwg;        // kz: which slice of the K-steps (split-K launches)
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef AOD_TILE_TIMING
@@ -135,14 +138,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   }
   TSTAMP(10);
   // tap state of this lane's k-chunk
-  int c8 = kc, tr = 0, ts = 0;
-  while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)((long long)kz * nk_all / p.ksplit), kt_end = (int)((long long)(kz + 1) * nk_all / p.ksplit);
+  int c8 = kc + kt_begin * CPR, tr = 0, ts = 0;
+  if (c8 >= C8) { const int taps = c8 / C8; c8 -= taps * C8; tr = taps / p.S; ts = taps - tr * p.S; }
 
   unsigned wbase[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int n = n0 + 32 * i + 8 * uw + prow;
-    wbase[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8) * 2) : OOB;
+    wbase[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8 + (long long)kt_begin * BK) * 2) : OOB;
   }
 
   // A-operand byte offsets are kept incrementally: inside one filter tap consecutive K-steps only advance the
@@ -157,9 +162,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   for (int i = 0; i < A_IT; ++i) aoff[i] = OOB_BASE;
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) woff[i] = wbase[i] == OOB ? OOB_BASE : wbase[i];
-  int ksteps_in_tap = 0;
-  bool new_tap = true;
   const int steps_per_tap = fast_tap ? C8 / CPR : 1;
+  int ksteps_in_tap = fast_tap ? kt_begin % steps_per_tap : 0;     // (a split-K slice may start inside a tap)
+  bool new_tap = true;
 
   auto load_a = [&](int buf) {
     char* sa = smem + buf * STAGE;
@@ -216,7 +221,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   TSTAMP(1);
   // epilogue operands (bias / scale vectors of this thread's 8 columns; residual and ReLU mask of its E_IT row segments): issued
   // together with the first operand tile and consumed after the main loop -- a load-use chain per store iteration would expose one
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   };
   // first stage: the weight tile and the epilogue operands do not depend on the row decode -- they go out first and are in flight
   // while the rows are resolved
-  load_b(0, 0);
-  if (one_seg) prefetch_epilogue(false);
+  load_b(kt_begin, 0);
+  if (one_seg && p.ksplit == 1) prefetch_epilogue(false);
   {
     // Row decode: lane j of a wave resolves the wave's row j & 31 ONCE (source block, top-left tap, image size); the 8 lanes that
     // gather the 8 k-chunks of a row then pick the record up with a lane shuffle (decoding per lane repeated the two divisions of a
@@ -309,12 +313,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   load_a(0);
   advance();
   __syncthreads();
-  if (!one_seg) prefetch_epilogue(true);    // tile straddles a segment boundary: destination rows come from the LDS table
+  if (!one_seg && p.ksplit == 1) prefetch_epilogue(true);    // tile straddles a segment boundary: destination rows come from the LDS table
   TSTAMP(2);
   const int lr = lane & 15, lq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1, cur ^ 1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) gload(kt + 1, cur ^ 1);
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -339,6 +343,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier: next tile is resident afterwards
   }
 
+  if (p.ksplit > 1) {
+    // split-K: this slice's fp32 partial tile goes to its own slab, straight from the accumulators (one dword per lane, 16
+    // consecutive columns per row group); no atomics, so the finalize pass can add the slabs in a fixed order
+    float* const slab = p.ws + (long long)kz * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * WM + i * 16 + lq * 4 + r, n = n0 + wn * WN + j * 16 + lr;
+          if (m < p.M && n < p.N) slab[(long long)m * p.N + n] = acc[i][j][r];
+        }
+    return;
+  }
   // ---- epilogue: accumulators -> LDS (fp32, [BM][CP]) -> row-major vector stores
   TSTAMP(3);
   float* sc = reinterpret_cast<float*>(smem);
@@ -497,7 +516,7 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(q.tiles_m * q.tiles_n), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(256), lds, st, q);
   return 0;
 }
 
@@ -535,19 +554,113 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
   return 0;
 }
 
-extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
-                          const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
-                          const float* post_scale, void* zraw, float* colsum, aod_stream_t stream) {
+// Split-K second pass: the epilogue of conv_igemm_kernel applied to the fp32 sums in the workspace.  A block takes 64 GEMM rows x 256
+// columns (thread -> one 8-column chunk, 8 rows), so column sums need one LDS reduction and 256 atomics per block.
+__global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKParams p) {
+  __shared__ float sr[8][256];
+  const int t = threadIdx.x, ec = t & 31, er = t >> 5;
+  const int n = (blockIdx.y * 32 + ec) * 8;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float cs1[8], cb1[8], cs2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = n + j < p.N;
+    cs1[j] = (p.pre_scale && ok) ? p.pre_scale[n + j] : 1.f;
+    cb1[j] = (p.pre_shift && ok) ? p.pre_shift[n + j] : 0.f;
+    cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
+  }
+  const bool vec = (p.N & 7) == 0 && n + 8 <= p.N;
+  if (n < p.N) {
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+      const int m = blockIdx.x * 64 + er + 8 * k;
+      if (m >= p.M) break;
+      int sg = 0;
+      if (p.nseg > 1) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) sg += (m >= p.seg_mend[q]) ? 1 : 0;
+      }
+      const long long drow = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0));
+      const float* w = p.ws + (long long)m * p.N + n;
+      float raw[8], v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = 0.f;
+      const long long slab = (long long)p.M * p.N;
+      for (int z = 0; z < p.ksplit; ++z) {           // fixed order: the sum does not depend on which slice finished first
+        if (vec) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(w + z * slab), b = *reinterpret_cast<const f32x4*>(w + z * slab + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { raw[j] += a[j]; raw[4 + j] += b[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) raw[j] += n + j < p.N ? w[z * slab + j] : 0.f;
+        }
+      }
+      const long long off = drow * p.N + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (n + j >= p.N) { v[j] = 0.f; continue; }
+        float u = raw[j] * cs1[j] + cb1[j];
+        if (p.res) u += (float)p.res[off + j];
+        if (p.mask) u = ((float)p.mask[off + j] > 0.f) ? u : 0.f;
+        if (p.post_scale) u *= cs2[j];
+        if (p.relu) u = fmaxf(u, 0.f);
+        v[j] = u;
+        csum[j] += u;
+      }
+      if (vec && !p.out_f32) {
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off) = ov;
+      } else {
+        for (int j = 0; j < 8 && n + j < p.N; ++j) {
+          if (p.out_f32) reinterpret_cast<float*>(p.y)[off + j] = v[j];
+          else reinterpret_cast<bf16_t*>(p.y)[off + j] = (bf16_t)v[j];
+        }
+      }
+      if (p.zraw)
+        for (int j = 0; j < 8 && n + j < p.N; ++j) p.zraw[off + j] = (bf16_t)raw[j];
+    }
+  }
+  if (p.colsum) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sr[er][ec * 8 + j] = csum[j];
+    __syncthreads();
+    const int c = blockIdx.y * 256 + t;
+    if (c < p.N) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s2 += sr[r][t];
+      atomicAdd(p.colsum + c, s2);
+    }
+  }
+}
+
+// Split-K pays when the output is so small that whole tiles cannot fill the device (pyramid levels P6 / P7, the 16 x 16 stage
+// of the backbone): few tiles x many K-steps.  Returns the number of K slices (1 = direct launch).
+static int choose_ksplit(const ConvKParams& p) {
+  const int bn = p.N > 64 ? 128 : 64;
+  const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+  const int nk = (p.K + 63) / 64;
+  if (tiles > 32 || nk < 64) return 1;
+  long long ks = (256 + tiles - 1) / tiles;
+  if (ks > nk / 8) ks = nk / 8;
+  return ks >= 2 ? (int)ks : 1;
+}
+
+static int conv_params(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst, const float* pre_scale,
+                       const float* pre_shift, const void* res, const void* mask, const float* post_scale, void* zraw, float* colsum,
+                       ConvKParams& p) {
   AOD_CHECK_ARG(desc && src && w_packed && dst, "conv: null pointer");
-  ConvKParams p;
   memset(&p, 0, sizeof(p));
   int rc = fill_params(desc, p);
   if (rc) return rc;
   AOD_CHECK_ARG(!(desc->out_f32 && zraw), "conv: zraw needs a bf16 destination");
-  if (p.M == 0) return 0;
   p.x = (const bf16_t*)src; p.w = (const bf16_t*)w_packed; p.y = dst;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
+  p.ksplit = 1;
   long long xrows = 0;
   for (int i = 0; i < desc->nseg; ++i) {
     const aod_conv_seg_t& sg = desc->seg[i];
@@ -558,16 +671,40 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   p.x_bytes = xrows * p.C * 2;
   p.w_bytes = (long long)p.N * p.K * 2;
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.w_bytes < 0xe0000000ll, "conv: operand larger than 3.5 GiB (32-bit buffer offsets)");
+  return 0;
+}
+
+extern "C" size_t aod_conv2d_ws_bytes(const aod_conv_desc_t* desc) {
+  ConvKParams p;
+  memset(&p, 0, sizeof(p));
+  if (!desc || fill_params(desc, p) != 0 || p.M == 0) return 0;
+  const int ks = choose_ksplit(p);
+  return ks > 1 ? (size_t)ks * p.M * p.N * 4 : 0;
+}
+
+extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
+                             const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
+                             const float* post_scale, void* zraw, float* colsum, void* workspace, size_t workspace_bytes,
+                             aod_stream_t stream) {
+  ConvKParams p;
+  int rc = conv_params(desc, src, w_packed, dst, pre_scale, pre_shift, res, mask, post_scale, zraw, colsum, p);
+  if (rc) return rc;
+  if (p.M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  const int ks = workspace ? choose_ksplit(p) : 1;
+  if (ks > 1) {
+    const size_t need = (size_t)ks * p.M * p.N * 4;
+    AOD_CHECK_ARG(workspace_bytes >= need, "conv: split-K workspace of %zu bytes, need %zu (aod_conv2d_ws_bytes)", workspace_bytes, need);
+    p.ksplit = ks; p.ws = (float*)workspace;
+    if (p.N > 64) launch_conv<128, 128>(p, st); else launch_conv<128, 64>(p, st);
+    AOD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, st, p);
+    AOD_LAUNCH_CHECK();
+    return 0;
+  }
   // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups
   auto ntiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   const long long want = 512;
-  static const char* dbg = getenv("AOD_TILE_1X1");
-  if (dbg && p.R * p.S == 1 && p.K <= 1024) {
-    if (!strcmp(dbg, "64x64")) { launch_conv<64, 64>(p, st); AOD_LAUNCH_CHECK(); return 0; }
-    if (!strcmp(dbg, "64x128") && p.N > 64) { launch_conv<64, 128>(p, st); AOD_LAUNCH_CHECK(); return 0; }
-    if (!strcmp(dbg, "128x64")) { launch_conv<128, 64>(p, st); AOD_LAUNCH_CHECK(); return 0; }
-  }
   if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
   else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
   else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
@@ -575,6 +712,12 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
   else launch_conv<64, 64>(p, st);
   AOD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
+                          const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
+                          const float* post_scale, void* zraw, float* colsum, aod_stream_t stream) {
+  return aod_conv2d_ws(desc, src, w_packed, dst, pre_scale, pre_shift, res, mask, post_scale, zraw, colsum, nullptr, 0, stream);
 }
 
 // =====================================================================================
@@ -772,7 +915,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wm * 64 + i * 16 + lq * 4 + r;
         const int k = k0 + wn * 64 + j * 16 + lr;
+#ifdef AOD_WGRAD_NO_EPI      // ablation build (tools/dbg): how much of the kernel is the atomic epilogue
+        if (n < p.N && k < p.K && acc[i][j][r] == 12345.678f) p.dw[(long long)n * p.K + k] = 1.f;
+#else
         if (n < p.N && k < p.K) atomicAdd(p.dw + (long long)n * p.K + k, acc[i][j][r]);
+#endif
       }
 }
 

@@ -4,13 +4,14 @@ Activations are "row tensors": a flat [rows, C] bf16 buffer holding one or more 
 (`Seg` records).  A single-image-batch tensor [B, C, H, W] in torch.channels_last memory format
 is the same bytes as rows [B*H*W, C]."""
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _C
-from ._C import ConvDesc, ConvSeg, call, ptr, stream
+from ._C import ConvDesc, ConvSeg, call, lib, ptr, stream
 
 
 _ROW_TABLES = {}     # wgrad row tables, one per conv geometry (shared by every layer / iteration with that geometry)
@@ -90,6 +91,20 @@ def pack_weight_dgrad(w_oihw: torch.Tensor, opad: Optional[int] = None, scale: O
     return out
 
 
+SPLITK = os.environ.get('AOD_SPLITK', '1') != '0'          # debug switch: 0 = never hand a split-K workspace to the library
+
+
+def _splitk_ws(d, device):
+    """(workspace, bytes) for aod_conv2d_ws: a scratch tensor from torch's allocator when the library's heuristic wants split-K for this
+    descriptor (graph-safe: under capture it comes from the graph's pool), else (None, 0)."""
+    if not SPLITK:
+        return None, 0
+    n = lib.aod_conv2d_ws_bytes(C.byref(d))
+    if n == 0:
+        return None, 0
+    return torch.empty(n // 4, dtype=torch.float32, device=device), n
+
+
 def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, pre_scale=None, pre_shift=None,
                 res=None, mask=None, post_scale=None, relu=False, out_f32=False, save_z=False, out=None,
                 dst_segs=None, out_rows=None):
@@ -101,8 +116,9 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
         out = torch.empty(rows, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
     z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
-    _prof('fwd', d, lambda: call('aod_conv2d', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
-                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, stream()))
+    ws, wsb = _splitk_ws(d, x_rows.device)
+    _prof('fwd', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
+                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, ptr(ws), wsb, stream()))
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
@@ -115,8 +131,9 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     if out is None:
         out = torch.empty(rows, Cin, dtype=torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
-    _prof('dgrad', d, lambda: call('aod_conv2d', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
-                                   ptr(post_scale), None, ptr(colsum), stream()))
+    ws, wsb = _splitk_ws(d, dz_rows.device)
+    _prof('dgrad', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
+                                   ptr(post_scale), None, ptr(colsum), ptr(ws), wsb, stream()))
     return out
 
 

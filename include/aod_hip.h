@@ -67,6 +67,18 @@ int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packe
                const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
                const float* post_scale, void* zraw, float* colsum, aod_stream_t stream);
 
+/* Same operation with a caller-provided scratch buffer, which lets tiny-output / very-deep-reduction convolutions (the stride-2
+ * 3x3 on C5 that makes pyramid level P6, fpn.py:156-202: 1 024 output pixels, K = 18 432) run split-K: the K-steps of a tile are
+ * divided over several workgroups, each stores its fp32 partial tile into its own slab of `workspace` ([slices][M][N] fp32, need not
+ * be initialised) and a second small kernel adds the slabs IN ORDER and applies the epilogue above -- deterministic, no atomics.
+ * aod_conv2d_ws_bytes() is the size the launch heuristic wants for this descriptor (0: the direct kernel is used and workspace may
+ * be NULL).  aod_conv2d() == aod_conv2d_ws() with workspace NULL. */
+size_t aod_conv2d_ws_bytes(const aod_conv_desc_t* desc);
+int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst,
+                  const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
+                  const float* post_scale, void* zraw, float* colsum, void* workspace, size_t workspace_bytes,
+                  aod_stream_t stream);
+
 /* replaces: the weight-gradient half of autograd's conv backward (cuDNN wgrad) for the same
  * call sites.  dw_f32 is [N][R][S][C] fp32 and is ACCUMULATED into (caller zeroes it);
  * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */

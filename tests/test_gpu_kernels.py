@@ -118,6 +118,46 @@ def test_conv_pyramid_segments_share_weights(ho):
         assert close(ho.rows_to_nchw(y, s), ref, 1e-2, 1e-2)
 
 
+@pytest.mark.parametrize('N,out_f32', [(256, False), (180, True), (9, True), (72, False)])
+def test_conv_split_k_matches_the_direct_kernel(ho, N, out_f32):
+    """Small-output / deep-K convolutions run split-K (aod_conv2d_ws: fp32 partial sums in a workspace + a finalize pass).  Same
+    epilogue semantics as the direct kernel on a two-segment input: bias, residual, mask, ReLU, column sums, fp32 / bf16 / N tails."""
+    import ctypes as C
+    from aod_meh_hua_amd._C import call, lib, ptr, stream
+    B, Cin = 2, 512
+    sizes = [(6, 5), (3, 3)]
+    g = synth.gen(300 + N)
+    segs, r = [], 0
+    for h, w_ in sizes:
+        segs.append(ho.Seg(B, h, w_, r)); r += B * h * w_
+    x = torch.randn(r, Cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(N, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)).cuda()
+    wp = ho.pack_weight_fwd(w)
+    bias = torch.randn(N, generator=g).cuda()
+    res = None if out_f32 else torch.randn(r, N, generator=g).cuda().bfloat16()
+    mask = None if out_f32 else torch.randn(r, N, generator=g).cuda().bfloat16()
+    d = ho.make_desc(Cin, N, 3, 3, 1, 1, 1, segs, segs, False, True, out_f32)
+    need = lib.aod_conv2d_ws_bytes(C.byref(d))
+    assert need > 0 and need % (r * N * 4) == 0, 'the heuristic should pick split-K for 2 tiles x 72 K-steps'
+    outs = []
+    for use_ws in (False, True):
+        y = torch.zeros(r, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device='cuda')
+        cs = torch.zeros(N, device='cuda')
+        ws = torch.full((need // 4,), 7.0, device='cuda') if use_ws else None          # (dirty on purpose: it need not be initialised)
+        call('aod_conv2d_ws', C.byref(d), ptr(x), ptr(wp), ptr(y), None, ptr(bias), ptr(res), ptr(mask), None, None, ptr(cs),
+             ptr(ws), need if use_ws else 0, stream())
+        torch.cuda.synchronize()
+        outs.append((y.float().cpu(), cs.cpu()))
+    (y0, c0), (y1, c1) = outs
+    assert float(y0.abs().max()) > 0.5
+    assert torch.allclose(y1, y0, rtol=1e-2 if not out_f32 else 1e-5, atol=1e-2 if not out_f32 else 1e-5)
+    assert torch.allclose(c1, c0, rtol=1e-3, atol=2e-2 * (1 if out_f32 else 4))
+    # too small a workspace is an argument error, not a launch
+    ws = torch.zeros(16, device='cuda')
+    rc = lib.aod_conv2d_ws(C.byref(d), ptr(x), ptr(wp), ptr(y), None, None, None, None, None, None, None, ptr(ws), 64, stream())
+    assert rc == -1 and b'workspace' in lib.aod_last_error()
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_dgrad_and_wgrad(ho, case):
     B, C, H, W, N, R, stride, pad, dil = case
