@@ -230,9 +230,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int ec = t % NCH, er = t / NCH;
   float cs1[8], cb1[8], cs2[8];
   bf16x8 pres[E_IT], pmask[E_IT];
-  // interior tiles of the common configuration (bf16 destination, bias only, N % 8 == 0) take an epilogue without per-thread
+  // interior tiles of the common configuration (bf16 destination, N % 8 == 0, no post-scale / raw copy) take an epilogue without per-thread
   // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
-  const bool fast = !p.out_f32 && !p.zraw && !p.pre_scale && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
+  const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
   const long long drow_lin = one_seg ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
   const long long lin_off = (drow_lin + m0 + er) * p.N + n0 + ec * 8;     // element offset of this thread's first row segment
   const long long lin_step = (long long)(256 / NCH) * p.N;                // ... and the distance to its next one
@@ -243,10 +243,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         // bias through a buffer descriptor that is EMPTY when there is no bias: the range check then returns zeros and the load needs
         // no branch (a branch would make the compiler wait for the loaded values where the two paths merge, i.e. right here)
         const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_shift, 0, p.pre_shift ? p.N * 4 : 0, 0x00020000);
+        const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_scale, 0, p.pre_scale ? p.N * 4 : 0, 0x00020000);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4 + 16, 0, 0);
+        const u32x4 s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, n * 4, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, n * 4 + 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cb1[j] = __uint_as_float(b0[j]); cb1[4 + j] = __uint_as_float(b1[j]); }
+        for (int j = 0; j < 4; ++j) {
+          cb1[j] = __uint_as_float(b0[j]); cb1[4 + j] = __uint_as_float(b1[j]);
+          cs1[j] = __uint_as_float(s0[j]); cs1[4 + j] = __uint_as_float(s1[j]);       // (zeros without a scale vector: not used then)
+        }
       }
       if (!from_table) {
         if (p.res) {
@@ -384,7 +389,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = v0[j] + cb1[j]; v[4 + j] = v1[j] + cb1[4 + j]; }
+      for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+      if (p.pre_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= cs1[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += cb1[j];
       if (p.res) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)pres[it][j];
