@@ -648,16 +648,16 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
   }
 }
 
-// Split-K pays when the output is so small that whole tiles cannot fill the device (pyramid levels P6 / P7, the 16 x 16 stage
-// of the backbone): few tiles x many K-steps.  Returns the number of K slices (1 = direct launch).
+// Split-K pays when the output is so small that whole tiles cannot fill the device: few tiles x very many K-steps (pyramid level P6:
+// a stride-2 3x3 on the 2048-channel C5, 8 x 8 outputs per image).  The decision and the slice boundaries depend on the PER-IMAGE
+// geometry and on K only, never on the batch size: the fp32 summation order of an output element -- and so the score of an image --
+// must not change with how the pool is batched.  Returns the number of K slices (1 = direct launch).
 static int choose_ksplit(const ConvKParams& p) {
-  const int bn = p.N > 64 ? 128 : 64;
-  const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
   const int nk = (p.K + 63) / 64;
-  if (tiles > 32 || nk < 64) return 1;
-  long long ks = (256 + tiles - 1) / tiles;
-  if (ks > nk / 8) ks = nk / 8;
-  return ks >= 2 ? (int)ks : 1;
+  if (nk < 64) return 1;
+  for (int i = 0; i < p.nseg; ++i)
+    if (p.segB[i] > 0 && (long long)p.segOH[i] * p.segOW[i] > 64) return 1;
+  return nk / 16;                       // slices of ~16 K-steps
 }
 
 static int conv_params(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst, const float* pre_scale,
