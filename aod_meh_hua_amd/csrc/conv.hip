@@ -28,6 +28,8 @@ struct ConvKParams {
   int tiles_m, tiles_n;
   int ksplit;         // > 1: split-K launch -- K-steps are divided over ksplit workgroups per tile, each stores its fp32 partial tile
   float* ws;          // split-K workspace, fp32 [ksplit][M][N] in GEMM-row order; conv_splitk_finalize sums the slabs IN ORDER (deterministic)
+  int perm;           // dgrad of a stride-2 conv: GEMM rows run CLASS-MAJOR inside a segment (the four (y & 1, x & 1) classes of the
+                      // destination pixels one after the other), so a tile is one class and the filter taps that can never hit it are skipped
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
@@ -76,7 +78,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_swizzle(blockIdx.x, nwg * p.ksplit);
+  // class-major launches keep the round-robin block -> XCD assignment: the classes differ in work (1 / 2 / 2 / 4 taps of a 3x3, 1 / 0 / 0 / 0
+  // of a 1x1) and contiguous per-XCD tile ranges would hand whole classes to single XCDs
+  int wg;
+  if (!p.perm) wg = xcd_swizzle(blockIdx.x, nwg * p.ksplit);
+  else if ((nwg & 31) == 0) {
+    // ... but inside each quarter of the tile range (~ one class) every XCD still takes a contiguous chunk (neighbouring column tiles
+    // share their A rows in that XCD's L2), and the quarters are interleaved in launch order
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, q = j & 3, k = j >> 2, tq = nwg >> 2;
+    wg = q * tq + x * (tq >> 3) + k;
+  } else wg = blockIdx.x;
   const int tile = wg % nwg, kz = wg / nwg;        // kz: which slice of the K-steps (split-K launches)
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -114,11 +125,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
   const int sg_first = seg_of(m0);
   const bool one_seg = sg_first == seg_of(m_last);
-  struct Geo { unsigned mstart, OW, ohw, H, W, src0b, imgb; };
+  struct Geo { unsigned mstart, OW, OH, ohw, B, H, W, src0b, imgb; };
   auto load_geo = [&](int sg) {
     Geo g;
     g.mstart = sg ? (unsigned)p.seg_mend[sg - 1] : 0u;
-    g.OW = (unsigned)p.segOW[sg]; g.ohw = (unsigned)p.segOH[sg] * g.OW;
+    g.OW = (unsigned)p.segOW[sg]; g.OH = (unsigned)p.segOH[sg]; g.ohw = g.OH * g.OW; g.B = (unsigned)p.segB[sg];
     g.H = (unsigned)p.segH[sg]; g.W = (unsigned)p.segW[sg];
     // byte offsets fit 32 bits (x_bytes < 3.5 GiB is checked on the host), so the arithmetic may wrap on the way
     g.src0b = (unsigned)((unsigned long long)p.seg_src0[sg] * (unsigned)(p.C * 2));
@@ -126,6 +137,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     return g;
   };
   const Geo gu = load_geo(sg_first);          // workgroup-uniform: scalar loads, once
+  auto udiv = [&](unsigned n, unsigned d) { return p.bigrows ? n / d : udiv_small(n, d); };
+  // (image, y, x) of the destination pixel with index ml inside its segment; `cls` = its (y & 1) * 2 + (x & 1) class in a class-major
+  // launch (p.perm), where the segment's rows are ordered class 0 | class 1 | class 2 | class 3, each class image-major
+  auto rowpos = [&](unsigned ml, const Geo& g, unsigned& b, unsigned& oy, unsigned& ox, int& cls) {
+    if (!p.perm) {
+      b = udiv(ml, g.ohw);
+      const unsigned rem = ml - b * g.ohw;
+      oy = udiv(rem, g.OW); ox = rem - oy * g.OW; cls = 0;
+    } else {
+      const unsigned H0 = (g.OH + 1) >> 1, H1 = g.OH >> 1, W0 = (g.OW + 1) >> 1, W1 = g.OW >> 1;
+      const unsigned e0 = g.B * H0 * W0, e1 = e0 + g.B * H0 * W1, e2 = e1 + g.B * H1 * W0;
+      cls = (ml >= e0 ? 1 : 0) + (ml >= e1 ? 1 : 0) + (ml >= e2 ? 1 : 0);
+      const unsigned start = cls == 0 ? 0u : (cls == 1 ? e0 : (cls == 2 ? e1 : e2));
+      const unsigned Hc = (cls & 2) ? H1 : H0, Wc = (cls & 1) ? W1 : W0, hw = Hc * Wc;
+      const unsigned r = ml - start;
+      b = udiv(r, hw);
+      const unsigned rem = r - b * hw, yy = udiv(rem, Wc);
+      oy = 2 * yy + (unsigned)(cls >> 1); ox = 2 * (rem - yy * Wc) + (unsigned)(cls & 1);
+    }
+  };
+  const bool linear = one_seg && !p.perm;       // destination rows of the tile are consecutive: drow = m + const
   // destination row of every tile row, parked in LDS behind the staging / epilogue area (read by the general epilogue, and by the
   // fast one on tiles that straddle a segment boundary)
   constexpr int EPI_BYTES = BM * CP * 4;
@@ -133,8 +165,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   long long* s_drow = reinterpret_cast<long long*>(smem + DROW_OFF);
   if (t < BM) {
     const int m = m0 + t;
-    if (one_seg) s_drow[t] = p.seg_dst0[sg_first] + (long long)((unsigned)m - gu.mstart);
-    else { const int sg = m < p.M ? seg_of(m) : 0; s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0)); }
+    if (linear) s_drow[t] = p.seg_dst0[sg_first] + (long long)((unsigned)m - gu.mstart);
+    else if (!p.perm) { const int sg = m < p.M ? seg_of(m) : 0; s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0)); }
+    else {
+      const int sg = one_seg ? sg_first : (m < p.M ? seg_of(m) : 0);
+      const Geo g = one_seg ? gu : load_geo(sg);
+      unsigned b, oy, ox; int cls;
+      rowpos((unsigned)m - g.mstart, g, b, oy, ox, cls);
+      s_drow[t] = p.seg_dst0[sg] + (long long)(b * g.ohw + oy * g.OW + ox);
+    }
   }
   TSTAMP(10);
   // tap state of this lane's k-chunk
@@ -163,6 +202,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) woff[i] = wbase[i] == OOB ? OOB_BASE : wbase[i];
   const int steps_per_tap = fast_tap ? C8 / CPR : 1;
+  // taps that can reach this tile at all (class-major dgrad of a stride-2 conv: tap (r, s) only hits destination pixels with
+  // y = r * dil - pad and x = s * dil - pad modulo 2); the others are skipped whole -- 5 to 8 of the 9 taps of a 3x3, 3 of 4 tiles
+  // of a 1x1.  Rows are still checked one by one, so a tile that straddles two classes simply keeps every tap.
+  unsigned long long tapmask = ~0ull;
+  if (p.perm && fast_tap && one_seg) {
+    unsigned b_, y_, x_; int c_first, c_last;
+    rowpos((unsigned)m0 - gu.mstart, gu, b_, y_, x_, c_first);
+    rowpos((unsigned)m_last - gu.mstart, gu, b_, y_, x_, c_last);
+    if (c_first == c_last) {
+      tapmask = 0ull;
+      for (int r = 0; r < p.R; ++r)
+        for (int q = 0; q < p.S; ++q)
+          if ((((c_first >> 1) + p.pad - r * p.dil) & 1) == 0 && (((c_first & 1) + p.pad - q * p.dil) & 1) == 0) tapmask |= 1ull << (r * p.S + q);
+    }
+  }
+  const bool skipping = tapmask != ~0ull;
+  int kt_ld = kt_begin;                          // K-step the loaders fetch next
   int ksteps_in_tap = fast_tap ? kt_begin % steps_per_tap : 0;     // (a split-K slice may start inside a tap)
   bool new_tap = true;
 
@@ -191,19 +247,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
   };
-  auto load_b = [&](int kt, int buf) {
+  auto load_b = [&](int buf) {
     char* sb = smem + buf * STAGE + A_BYTES;
-    const bool kok = (kt * BK + kc * 8) < p.K;
+    const bool kok = (kt_ld * BK + kc * 8) < p.K;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const unsigned off = kok ? woff[i] : OOB_BASE;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
   };
+  auto skip_dead_taps = [&]() {      // (at a tap boundary) hop over the taps that cannot reach this tile
+    while (tr < p.R && !((tapmask >> (tr * p.S + ts)) & 1ull)) {
+      if (++ts == p.S) { ts = 0; ++tr; }
+      kt_ld += steps_per_tap;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) woff[i] += (unsigned)(p.C * 2);
+    }
+  };
   auto advance = [&]() {      // state of the next K-step
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) woff[i] += BK * 2;
     c8 += CPR;
+    ++kt_ld;
     if (fast_tap && ++ksteps_in_tap < steps_per_tap) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) aoff[i] += BK * 2;
@@ -211,9 +276,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       ksteps_in_tap = 0;
       while (c8 >= C8) { c8 -= C8; if (++ts == p.S) { ts = 0; ++tr; } }
       new_tap = true;
+      if (skipping) skip_dead_taps();
     }
   };
-  auto gload = [&](int kt, int buf) { load_a(buf); load_b(kt, buf); advance(); };
+  auto gload = [&](int buf) { load_a(buf); load_b(buf); advance(); };
+  if (skipping) skip_dead_taps();
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -233,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   // interior tiles of the common configuration (bf16 destination, N % 8 == 0, no post-scale / raw copy) take an epilogue without per-thread
   // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
   const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
-  const long long drow_lin = one_seg ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
+  const long long drow_lin = linear ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
   const long long lin_off = (drow_lin + m0 + er) * p.N + n0 + ec * 8;     // element offset of this thread's first row segment
   const long long lin_step = (long long)(256 / NCH) * p.N;                // ... and the distance to its next one
   auto prefetch_epilogue = [&](bool from_table) {
@@ -287,8 +354,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   };
   // first stage: the weight tile and the epilogue operands do not depend on the row decode -- they go out first and are in flight
   // while the rows are resolved
-  load_b(kt_begin, 0);
-  if (one_seg && p.ksplit == 1) prefetch_epilogue(false);
+  bool have = kt_ld < kt_end;                    // (a class without a reachable tap has no K-step at all: its dX is the epilogue of zero)
+  if (have) load_b(0);
+  if (linear && p.ksplit == 1) prefetch_epilogue(false);
   {
     // Row decode: lane j of a wave resolves the wave's row j & 31 ONCE (source block, top-left tap, image size); the 8 lanes that
     // gather the 8 k-chunks of a row then pick the record up with a lane shuffle (decoding per lane repeated the two divisions of a
@@ -297,11 +365,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const int m = m0 + 32 * (j >> 3) + 8 * uw + (j & 7);
     const int sg = one_seg ? sg_first : (m < p.M ? seg_of(m) : 0);
     const Geo gl = one_seg ? gu : load_geo(sg);
-    const unsigned ml = (unsigned)m - gl.mstart;
-    const unsigned b = p.bigrows ? ml / gl.ohw : udiv_small(ml, gl.ohw);
-    const unsigned rem = ml - b * gl.ohw;
-    const unsigned oy = p.bigrows ? rem / gl.OW : udiv_small(rem, gl.OW);
-    const unsigned ox = rem - oy * gl.OW;
+    unsigned b, oy, ox; int cls;
+    rowpos((unsigned)m - gl.mstart, gl, b, oy, ox, cls);
     const int d_hw = m < p.M ? (int)(gl.H | (gl.W << 16)) : 0;     // rows past M keep H = W = 0: every tap of theirs is out of the image
     const int d_base = (int)(gl.src0b + b * gl.imgb);
     const int d_y = p.transposed ? (int)oy + p.pad : (int)oy * p.stride - p.pad;
@@ -315,15 +380,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     }
   }
   TSTAMP(9);
-  load_a(0);
-  advance();
+  if (have) { load_a(0); advance(); }
   __syncthreads();
-  if (!one_seg && p.ksplit == 1) prefetch_epilogue(true);    // tile straddles a segment boundary: destination rows come from the LDS table
+  if (!linear && p.ksplit == 1) prefetch_epilogue(true);     // destination rows are not consecutive: they come from the LDS table
   TSTAMP(2);
   const int lr = lane & 15, lq = lane >> 4;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) gload(kt + 1, cur ^ 1);
+  for (int cur = 0; have; cur ^= 1) {
+    const bool more = kt_ld < kt_end;
+    if (more) gload(cur ^ 1);
+    have = more;
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -411,7 +476,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       bf16x8 ov;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { csum[j] += v[j]; ov[j] = (bf16_t)v[j]; }
-      *reinterpret_cast<bf16x8*>(one_seg ? yl + it * lin_step : yb + s_drow[row] * p.N) = ov;
+      *reinterpret_cast<bf16x8*>(linear ? yl + it * lin_step : yb + s_drow[row] * p.N) = ov;
     }
   } else
 #pragma unroll
@@ -672,6 +737,9 @@ static int conv_params(const aod_conv_desc_t* desc, const void* src, const void*
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
   p.ksplit = 1;
+  p.perm = (desc->transposed && desc->stride == 2 && desc->R * desc->S > 1 && desc->R * desc->S <= 64) ? 1 : 0;     // (no gain measured for 1x1)
+  static const char* dbg_perm = getenv("AOD_DGRAD_CLASSES");
+  if (dbg_perm && dbg_perm[0] == '0') p.perm = 0;
   long long xrows = 0;
   for (int i = 0; i < desc->nseg; ++i) {
     const aod_conv_seg_t& sg = desc->seg[i];
@@ -702,7 +770,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   if (rc) return rc;
   if (p.M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const int ks = workspace ? choose_ksplit(p) : 1;
+  const int ks = (workspace && !p.perm) ? choose_ksplit(p) : 1;
   if (ks > 1) {
     const size_t need = (size_t)ks * p.M * p.N * 4;
     AOD_CHECK_ARG(workspace_bytes >= need, "conv: split-K workspace of %zu bytes, need %zu (aod_conv2d_ws_bytes)", workspace_bytes, need);
