@@ -786,8 +786,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   const long long want = 512;
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
-  static const char* dbg_n = getenv("AOD_TILE_RAGGED");
-  const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128 && !(dbg_n && dbg_n[0] == '0');
+  const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
   if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
   else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
   else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
