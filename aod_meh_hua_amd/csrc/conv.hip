@@ -630,8 +630,9 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
   return 0;
 }
 
-// Split-K second pass: the epilogue of conv_igemm_kernel applied to the fp32 sums in the workspace.  A block takes 64 GEMM rows x 256
-// columns (thread -> one 8-column chunk, 8 rows), so column sums need one LDS reduction and 256 atomics per block.
+// Split-K second pass: the epilogue of conv_igemm_kernel applied to the fp32 sums in the workspace.  A block takes 8 GEMM rows x 256
+// columns (thread -> one 8-column chunk of one row; the outputs are tiny, the grid has to be wide), column sums need one LDS
+// reduction and 256 atomics per block.
 __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKParams p) {
   __shared__ float sr[8][256];
   const int t = threadIdx.x, ec = t & 31, er = t >> 5;
@@ -647,9 +648,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
   }
   const bool vec = (p.N & 7) == 0 && n + 8 <= p.N;
   if (n < p.N) {
-#pragma unroll 2
-    for (int k = 0; k < 8; ++k) {
-      const int m = blockIdx.x * 64 + er + 8 * k;
+    for (int k = 0; k < 1; ++k) {
+      const int m = blockIdx.x * 8 + er;
       if (m >= p.M) break;
       int sg = 0;
       if (p.nseg > 1) {
@@ -777,7 +777,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     p.ksplit = ks; p.ws = (float*)workspace;
     if (p.N > 64) launch_conv<128, 128>(p, st); else launch_conv<128, 64>(p, st);
     AOD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((p.M + 7) / 8, (p.N + 255) / 256), dim3(256), 0, st, p);
     AOD_LAUNCH_CHECK();
     return 0;
   }
@@ -1163,10 +1163,24 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
   const int pitch = run | 1;                   // odd LDS pitch: column reads (dgrad image) stay conflict-free
   float* tl = &tile[0][0][0];                  // linear [32][pitch]
   const int cvalid = it.I - c0 < PREP_T ? it.I - c0 : PREP_T;     // real input channels in this tile (may be <= 0)
-  for (int ol = 0; ol < PREP_T; ++ol) {
-    const int o = o0 + ol;
-    const float* src = it.w + ((long long)o * it.I + c0) * RS;
-    for (int idx = t; idx < run; idx += 256) tl[ol * pitch + idx] = (o < it.O && idx < cvalid * RS) ? src[idx] : 0.f;
+  {
+    // the whole 32 x run tile as ONE flat index space, four independent loads in flight per thread (a loop over the 32 output
+    // channels with one load each serialised 32 memory latencies)
+    const int total = PREP_T * run, lim = cvalid * RS;
+    const float* src0 = it.w + ((long long)o0 * it.I + c0) * RS;
+    const long long ostride = (long long)it.I * RS;
+    for (int base = t; base < total; base += 4 * 256) {
+      float v[4]; int ol[4], idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + u * 256;
+        ol[u] = e / run; idx[u] = e - ol[u] * run;
+        v[u] = (e < total && o0 + ol[u] < it.O && idx[u] < lim) ? src0[ol[u] * ostride + idx[u]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 256 < total) tl[ol[u] * pitch + idx[u]] = v[u];
+    }
   }
   __syncthreads();
   const int l32 = t & 31, g8 = t >> 5;      // 8 groups of 32 lanes
