@@ -158,6 +158,40 @@ def test_conv_split_k_matches_the_direct_kernel(ho, N, out_f32):
     assert rc == -1 and b'workspace' in lib.aod_last_error()
 
 
+@pytest.mark.parametrize('sizes', [[(17, 19)], [(16, 16), (9, 7)], [(5, 4), (3, 3), (2, 1)]])
+def test_conv_dgrad_stride2_class_major_with_fused_activation_backward(ho, sizes):
+    """dgrad of a 3x3 stride-2 conv runs class-major (rows grouped by the parity class of the destination pixel, dead taps skipped,
+    destination rows scattered): odd sizes, several segments, and the fused epilogue (residual gradient + ReLU mask + column sums)
+    against autograd on the same bf16 operands."""
+    B, C, N = 2, 128, 64
+    g = synth.gen(41 + len(sizes))
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9))
+    xs_, zs_, xr, zr = [], [], 0, 0
+    dz_rows, want, res_rows, mask_rows = [], [], [], []
+    for (H, W) in sizes:
+        x = bf(torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+        y = F.conv2d(x, w, None, 2, 1, 1)
+        dz = bf(torch.randn(y.shape, generator=g))
+        y.backward(dz)
+        res = bf(torch.randn(B, C, H, W, generator=g))
+        mask = bf(torch.randn(B, C, H, W, generator=g))
+        OH, OW = y.shape[-2:]
+        xs_.append(ho.Seg(B, H, W, xr)); zs_.append(ho.Seg(B, OH, OW, zr))
+        xr += B * H * W; zr += B * OH * OW
+        dz_rows.append(nhwc_rows(dz)); res_rows.append(nhwc_rows(res)); mask_rows.append(nhwc_rows(mask))
+        want.append(nhwc_rows((x.grad + res) * (mask > 0)))
+    dz_rows = torch.cat(dz_rows).cuda().bfloat16()
+    res_rows, mask_rows, want = torch.cat(res_rows).cuda().bfloat16(), torch.cat(mask_rows).cuda().bfloat16(), torch.cat(want)
+    wd = ho.pack_weight_dgrad(w.cuda(), N)
+    cs = torch.zeros(C, device='cuda')
+    dx = ho.conv2d_dgrad_rows(dz_rows, zs_, xs_, wd, C, 3, 3, 2, 1, 1, res=res_rows, mask=mask_rows, colsum=cs)
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert close(dx, want, 1e-2, 1e-2 * scale)
+    assert close(cs, dx.float().sum(0), 1e-3, 5e-2 * scale)           # column sums of the fp32 values behind what was stored (bf16)
+    assert close(cs, want.sum(0), 2e-2, 0.3 * scale)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_dgrad_and_wgrad(ho, case):
     B, C, H, W, N, R, stride, pad, dil = case
