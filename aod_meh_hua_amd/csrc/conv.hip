@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   };
   // first stage: the weight tile and the epilogue operands do not depend on the row decode -- they go out first and are in flight
   // while the rows are resolved
-  bool have = kt_ld < kt_end;                    // (a class without a reachable tap has no K-step at all: its dX is the epilogue of zero)
+  bool have = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;     // (kt_ld is the same in every lane; say so, or the loop control goes through EXEC)                    // (a class without a reachable tap has no K-step at all: its dX is the epilogue of zero)
   if (have) load_b(0);
   if (linear && p.ksplit == 1) prefetch_epilogue(false);
   {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   TSTAMP(2);
   const int lr = lane & 15, lq = lane >> 4;
   for (int cur = 0; have; cur ^= 1) {
-    const bool more = kt_ld < kt_end;
+    const bool more = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
     if (more) gload(cur ^ 1);
     have = more;
     const char* sa = smem + cur * STAGE;
