@@ -806,16 +806,18 @@ extern "C" int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const vo
 // =====================================================================================
 // wgrad
 // =====================================================================================
-// Row table: one 16-B record per GEMM row m (= destination pixel): where its receptive field starts.
+// Row table: one 32-B record per GEMM row m (= destination pixel): where its receptive field starts.
 // Depends only on the segment geometry / stride / pad, so it is built once per geometry and shared by every conv
-// (and every iteration) with that geometry -- the per-step im2col decode of wgrad becomes one 16-B load.
-struct RowRec {
+// (and every iteration) with that geometry -- the per-step im2col decode of wgrad becomes one 32-B record per pixel.
+struct RowRec {       // 32 B: two 16-B pieces, fetched by LDS-DMA (one wave-instruction = the records of 32 pixels)
   unsigned xrow;     // byte offset of the top-left tap pixel (b, y0, x0) in the source (wraps for y0/x0 < 0: only used when valid)
   unsigned zoff;     // byte offset of this pixel's row in the dZ buffer
   unsigned wc2;      // source row pitch in bytes: W * C * 2
   unsigned pad_;
   unsigned long long mask;   // bit (r*S + s) set <=> tap (r, s) lies inside the image for this pixel (R*S <= 64)
+  unsigned long long pad2_;
 };
+static_assert(sizeof(RowRec) == 32, "row record layout");
 
 __global__ void row_table_kernel(const ConvKParams p, RowRec* __restrict__ tab) {
   const int m = blockIdx.x * 256 + threadIdx.x;
@@ -839,7 +841,7 @@ __global__ void row_table_kernel(const ConvKParams p, RowRec* __restrict__ tab) 
       if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) mk |= 1ull << (tr * p.S + ts);
     }
   r.mask = mk;
-  r.pad_ = 0;
+  r.pad_ = 0; r.pad2_ = 0;
   tab[m] = r;
 }
 
@@ -870,7 +872,7 @@ struct WgradParams {
   int C, N, K, R, S, dil;
   int M;
   int tiles_n, tiles_k, splits, rows_per_split;
-  long long x_bytes, z_bytes;
+  long long x_bytes, z_bytes, tab_bytes;
 };
 
 // byte offset of (row, 16-B chunk) in a 256-B-pitch bf16 image that serves transposed reads
@@ -914,13 +916,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const unsigned long long tbit = kok ? (1ull << tap) : 0ull;
   const unsigned zcol = (unsigned)(zn * 2);
   constexpr unsigned OOB_BASE = 0xf0000000u;
-  RowRec rec[4];
-  auto tload = [&](int mbase) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mbase + 16 * i + 4 * uw + prow;
-      rec[i] = p.tab[min(m, p.M - 1)];
+  // Row records reach the lanes through LDS: waves 0 and 1 fetch the 64 records of a step with ONE LDS-DMA instruction each (two steps
+  // ahead, into a two-slot ring behind the operand stages), every lane then picks its four with ds_read.  Fetching them into VGPRs
+  // (global_load) beside the LDS-DMA operand loads made every K-step drain the whole vector-memory queue: 27 % of the kernel.
+  const auto rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.tab, 0, (int)p.tab_bytes, 0x00020000);
+  char* const stab = smem + 2 * STAGE;                        // [2][64] records
+  auto tdma = [&](int mbase, int slot) {
+    if (uw < 2) {
+      const int m = mbase + 32 * uw + (lane >> 1);
+      const unsigned off = (unsigned)min(m, p.M - 1) * 32u + (unsigned)(lane & 1) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (__attribute__((address_space(3))) void*)(stab + slot * 2048 + uw * 1024), 16, off, 0, 0, 0);
     }
+  };
+  RowRec rec[4];
+  auto rread = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rec[i] = *reinterpret_cast<const RowRec*>(stab + slot * 2048 + (16 * i + 4 * uw + prow) * 32);
   };
   auto gload = [&](int mbase, int buf) {
     char* sz = smem + buf * STAGE;
@@ -944,18 +955,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (me - ms + BKM - 1) / BKM;
-  tload(ms);
+  tdma(ms, 0);
+  if (nsteps > 1) tdma(ms + BKM, 1);
+  __syncthreads();                                            // records of steps 0 and 1 are resident
+  rread(0);
   gload(ms, 0);
-  if (nsteps > 1) tload(ms + BKM);
   __syncthreads();
   // transposed-read lane roles: group g = lane>>4 covers k rows 8g..8g+7 of a 32-row sub-step; lane 4q+pp -> row q, cols 4pp..4pp+3
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
   for (int stp = 0; stp < nsteps; ++stp) {
     const int cur = stp & 1;
     if (stp + 1 < nsteps) {
-      gload(ms + (stp + 1) * BKM, cur ^ 1);                 // uses rec[] fetched one step ago
-      if (stp + 2 < nsteps) tload(ms + (stp + 2) * BKM);
+      rread((stp + 1) & 1);                                 // landed before the previous barrier
+      gload(ms + (stp + 1) * BKM, cur ^ 1);
     }
+    // slot stp & 1 held this step's records; every wave read them one iteration ago (ahead of the barrier), so it can be refilled
+    if (stp + 2 < nsteps) tdma(ms + (stp + 2) * BKM, stp & 1);
     const char* sz = smem + cur * STAGE;
     const char* sx = sz + IMG;
 #pragma unroll
@@ -1030,6 +1045,7 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   }
   p.x_bytes = xrows * p.C * 2;
   p.z_bytes = zrows * p.N * 2;
+  p.tab_bytes = (long long)p.M * (long long)sizeof(RowRec);
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
   p.tiles_n = (p.N + 127) / 128;
   p.tiles_k = (p.K + 127) / 128;
@@ -1052,10 +1068,10 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   p.splits = splits; p.rows_per_split = rps;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 65536, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }

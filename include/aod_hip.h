@@ -86,7 +86,7 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
  * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */
 int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz, float* dw_f32,
                      const void* row_table, aod_stream_t stream);
-/* Row table of a forward descriptor (16 B per destination pixel: source block origin, top-left tap, extents,
+/* Row table of a forward descriptor (32 B per destination pixel: source block origin, top-left tap, extents,
  * dZ row).  Depends only on segment geometry / stride / pad / filter size: build once, reuse for every wgrad
  * launch with that geometry. */
 size_t aod_conv_row_table_bytes(const aod_conv_desc_t* desc);

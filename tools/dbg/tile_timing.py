@@ -8,8 +8,8 @@ if sys.argv[1] == 'build':
     os.makedirs(OUT, exist_ok=True)
     csrc = os.path.join(ROOT, 'aod_meh_hua_amd', 'csrc')
     srcs = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.cpp')))
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DAOD_TILE_TIMING', *(['-DAOD_WGRAD_NO_EPI'] if 'noepi' in sys.argv else []), '-shared', '-x', 'hip',
-                           '-o', os.path.join(OUT, 'libaodhip_noepi.so' if 'noepi' in sys.argv else 'libaodhip_dbg.so')] + srcs)
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DAOD_TILE_TIMING', *(['-DAOD_WGRAD_NO_EPI'] if 'noepi' in sys.argv else []), *(['-DAOD_WGRAD_NO_TLOAD'] if 'notload' in sys.argv else []), '-shared', '-x', 'hip',
+                           '-o', os.path.join(OUT, 'libaodhip_noepi.so' if 'noepi' in sys.argv else ('libaodhip_notload.so' if 'notload' in sys.argv else 'libaodhip_dbg.so'))] + srcs)
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
