@@ -91,9 +91,11 @@ class Lambda_L2Net(L_AnchorHead):
         assert type(self.loss_bbox).__name__ == 'L1Loss' and type(self.loss_cls).__name__ == 'EDL_Softmax_FocalLoss'
         sum_cls, sum_box, loss_noR = AF.RetinaLossFn.apply(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
                                                            float(self.loss_cls.gamma), float(self.loss_cls.alpha), self.cls_out_channels)
-        loss_cls = self.loss_cls.loss_weight * sum_cls / num_total_samples
-        loss_bbox = self.loss_bbox.loss_weight * sum_box / num_total_samples
-        return loss_cls, loss_bbox, self.loss_cls.loss_weight * loss_noR
+        wc, wb = self.loss_cls.loss_weight, self.loss_bbox.loss_weight
+        scaled = lambda w, t: t if w == 1.0 else w * t          # (1.0 * t == t exactly: no launch for the default weights)
+        loss_cls = scaled(wc, sum_cls) / num_total_samples
+        loss_bbox = scaled(wb, sum_box) / num_total_samples
+        return loss_cls, loss_bbox, scaled(wc, loss_noR)
 
     @force_fp32(apply_to=('L_score'))
     def loss_single_L(self, L_score, loss, label_weights, bbox_weights, **kwargs):

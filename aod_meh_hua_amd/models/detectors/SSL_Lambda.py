@@ -62,14 +62,16 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
     def _parse_losses(self, losses, **kwargs):
         """SSL_Lambda.py:126-154."""
         log_vars = OrderedDict()
+        # (.mean() of a 0-d tensor is the tensor itself, bit for bit; skipping it saves a reduce launch and its backward per level)
+        mean = lambda t: t if t.dim() == 0 else t.mean()
         for loss_name, loss_value in losses.items():
             if isinstance(loss_value, torch.Tensor):
-                log_vars[loss_name] = loss_value.mean()
+                log_vars[loss_name] = mean(loss_value)
             elif isinstance(loss_value, list):
                 loss_sum = None
                 for _loss in loss_value:
                     if torch.is_tensor(_loss):
-                        loss_sum = _loss.mean() if loss_sum is None else loss_sum + _loss.mean()
+                        loss_sum = mean(_loss) if loss_sum is None else loss_sum + mean(_loss)
                 log_vars[loss_name] = loss_sum if loss_sum is not None else torch.zeros((), device=kwargs.get('device'))
             else:
                 raise TypeError(f'{loss_name} is not a tensor or list of tensors')
