@@ -153,8 +153,16 @@ class L_AnchorHead(BaseModule):
         head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
         losses_cls, losses_bbox, losses_noR = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list,
                                                           bt_list, bw_list, list(range(len(cls_scores))),
-                                                          num_total_samples=num_total_samples, featmap_sizes=featmap_sizes, **kwargs)
+                                                          num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
+                                                          defer_avg=self._can_defer_avg, **kwargs)
+        if self._can_defer_avg:
+            # the per-level "sum / num_total_samples" of loss_single (L_anchor_head.py:266-288) for all levels at once: same quotients,
+            # 2 launches instead of 10 (and as many fewer in backward)
+            losses_cls = list((torch.stack(losses_cls) / num_total_samples).unbind(0))
+            losses_bbox = list((torch.stack(losses_bbox) / num_total_samples).unbind(0))
         return dict(loss_cls=losses_cls, loss_bbox=losses_bbox, loss_noR=losses_noR), head_out
+
+    _can_defer_avg = False      # set by heads whose loss_single understands defer_avg
 
     @force_fp32(apply_to=('L_scores'))
     def loss_L(self, L_scores, head_out, losses, **kwargs):

@@ -82,6 +82,8 @@ class Lambda_L2Net(L_AnchorHead):
         return self.forward_L([x])[0], 0
 
     # ------------------------------------------------------------------ losses
+    _can_defer_avg = True
+
     @force_fp32(apply_to=('cls_score', 'bbox_pred'))
     def loss_single(self, cls_score, bbox_pred, anchors, labels, label_weights, bbox_targets, bbox_weights, sIdx, num_total_samples, **kwargs):
         """Live branch of Lambda_L2.py:112-121 (Labeled and not Pseudo).  The Pseudo branch (:122-232) is never
@@ -93,6 +95,8 @@ class Lambda_L2Net(L_AnchorHead):
                                                            float(self.loss_cls.gamma), float(self.loss_cls.alpha), self.cls_out_channels)
         wc, wb = self.loss_cls.loss_weight, self.loss_bbox.loss_weight
         scaled = lambda w, t: t if w == 1.0 else w * t          # (1.0 * t == t exactly: no launch for the default weights)
+        if kwargs.get('defer_avg'):                               # loss() divides all levels by the sample count in one launch
+            return scaled(wc, sum_cls), scaled(wb, sum_box), scaled(wc, loss_noR)
         loss_cls = scaled(wc, sum_cls) / num_total_samples
         loss_bbox = scaled(wb, sum_box) / num_total_samples
         return loss_cls, loss_bbox, scaled(wc, loss_noR)
