@@ -10,15 +10,20 @@ constexpr int MAXC = 96;
 
 __device__ __forceinline__ float focal_pow(float b, float gamma) { return gamma == 2.f ? b * b : powf(b, gamma); }
 
-// per-row forward core: fills p[] (softmax) and returns row loss; lsum_w = sum_c l_c
-template <int MAXC_>
+// per-row forward core: fills p[] (softmax) and returns row loss.  CT is a compile-time bound of C: the loops are fully unrolled and
+// predicated (same order of operations), so x[] / p[] live in registers -- with a run-time trip count they were demoted to scratch
+// memory (784-1168 B per lane) and the kernels ran at an eighth of the HBM rate.
+template <int CT>
 __device__ __forceinline__ float edl_row_fwd(const float* x, int C, long long label, float gamma, float alpha, float* p) {
   float m = x[0];
-  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+  for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
   float S = 0.f;
-  for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); S += p[c]; }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { p[c] = expf(x[c] - m); S += p[c]; }
   float tot = 0.f;
-  for (int c = 0; c < C; ++c) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) {
     const float pr = p[c] / S;
     p[c] = pr;
     const float z = logf(pr / (1.f - pr + 1e-9f) + 1e-9f);
@@ -31,6 +36,7 @@ __device__ __forceinline__ float edl_row_fwd(const float* x, int C, long long la
   return tot;
 }
 
+template <int CT>
 __global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
                                                         const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
@@ -46,9 +52,10 @@ __global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict_
   float s_cls = 0.f, s_box = 0.f, s_nor = 0.f;
   if ((int)threadIdx.x < nr) {
     const long long r = r0 + threadIdx.x;
-    float x[MAXC], p[MAXC];
-    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
-    const float l = edl_row_fwd<MAXC>(x, C, labels[r], gamma, alpha, p);
+    float x[CT], p[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) x[c] = c < C ? srow[threadIdx.x * P + c] : 0.f;
+    const float l = edl_row_fwd<CT>(x, C, labels[r], gamma, alpha, p);
     loss_noR[r] = l;
     s_nor = l;
     s_cls = l * lw[r];
@@ -95,8 +102,12 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_fwd: bbox_pred needs targets and weights");
   if (nrows == 0) return 0;
   const long long nb = (nrows + LB - 1) / LB;
-  hipLaunchKernelGGL(edl_l1_fwd_kernel, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
-                     label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
+  if (C <= 24)
+    hipLaunchKernelGGL(edl_l1_fwd_kernel<24>, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+                       label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
+  else
+    hipLaunchKernelGGL(edl_l1_fwd_kernel<MAXC>, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+                       label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 3, sums3);
   AOD_LAUNCH_CHECK();
   return 0;
@@ -104,7 +115,7 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
 
 // backward.  Output element (row r, class c) lives at (r / A) * pitch + (r % A) * C + c so that the
 // gradient lands directly in the conv's [pixels, A*C (padded)] dZ layout, bf16 or fp32.
-template <bool OUT_BF16>
+template <bool OUT_BF16, int CT>
 __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
                                                         const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
@@ -122,16 +133,20 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
   __syncthreads();
   if ((int)threadIdx.x < nr) {
     const long long r = r0 + threadIdx.x;
-    float x[MAXC], p[MAXC], gp[MAXC];
-    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
+    float x[CT], p[CT], gp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) x[c] = c < C ? srow[threadIdx.x * P + c] : 0.f;
     float m = x[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+    for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
     float S = 0.f;
-    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); S += p[c]; }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < C) { p[c] = expf(x[c] - m); S += p[c]; }
     const long long label = labels[r];
     const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[r] : g_noR_s);
     float dot = 0.f;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < C) {
       const float pr = p[c] / S;
       p[c] = pr;
       const float om = 1.f - pr + 1e-9f;
@@ -146,12 +161,10 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
       gp[c] = g;
       dot += pr * g;
     }
-    const long long obase = (r / A) * pitch_cls + (r % A) * C;
-    for (int c = 0; c < C; ++c) {
-      const float gx = p[c] * (gp[c] - dot);
-      if (OUT_BF16) ((bf16_t*)grad_cls)[obase + c] = (bf16_t)gx;
-      else ((float*)grad_cls)[obase + c] = gx;
-    }
+    // the row's gradient goes back into its LDS row; the block then stores all rows with consecutive lanes on consecutive elements
+    // (one thread storing its own 20 values writes 4 B per lane at an 80-B lane stride)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < C) srow[threadIdx.x * P + c] = p[c] * (gp[c] - dot);
     if (bp && grad_bbox) {
       const float gb = g_bbox[0];
       const long long bb = (r / A) * pitch_box + (r % A) * 4;
@@ -163,6 +176,15 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
         else ((float*)grad_bbox)[bb + j] = gx;
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tot; i += LB) {
+    const int row = i / C, c = i - row * C;
+    const long long r = r0 + row;
+    const long long o = (r / A) * pitch_cls + (r % A) * C + c;
+    const float gx = srow[row * P + c];
+    if (OUT_BF16) ((bf16_t*)grad_cls)[o] = (bf16_t)gx;
+    else ((float*)grad_cls)[o] = gx;
   }
 }
 
@@ -176,14 +198,13 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && g_bbox && pitch_box >= A * 4), "edl_bwd: bbox args");
   if (nrows == 0) return 0;
   const long long nb = (nrows + LB - 1) / LB;
-  if (out_bf16)
-    hipLaunchKernelGGL((edl_l1_bwd_kernel<true>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,
-                       (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR,
-                       g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box);
-  else
-    hipLaunchKernelGGL((edl_l1_bwd_kernel<false>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,
-                       (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR,
-                       g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box);
+#define AOD_EDL_BWD(BF, CT_)                                                                                                              \
+  hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, CT_>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,       \
+                     (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR, \
+                     g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box)
+  if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 24); else AOD_EDL_BWD(true, MAXC); }
+  else { if (C <= 24) AOD_EDL_BWD(false, 24); else AOD_EDL_BWD(false, MAXC); }
+#undef AOD_EDL_BWD
   AOD_LAUNCH_CHECK();
   return 0;
 }
