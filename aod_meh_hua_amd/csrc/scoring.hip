@@ -14,29 +14,41 @@
 // alphas = softmax(x); S = sum(alphas) + 1e-20; scores = alphas / (S + 1e-9)   (Lambda_L2.py:269-273, gamma = 1)
 // has_bg (SSD, My_L_ssd_head.py:331-345): x holds C logits whose LAST column is background; scores = plain softmax over all C,
 // the two maxima are taken over the C-1 foreground columns.
+// CT: compile-time bound of C.  The loops are fully unrolled and predicated (same order of operations) so that x[] / s[] stay in registers;
+// with run-time trip counts the arrays were demoted to scratch memory (784 B per lane).
+template <int CT>
 __device__ __forceinline__ void row_scores_bg(const float* __restrict__ x, int C, float* s, float& max_alpha, float& max_score) {
   float m = x[0];
-  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+  for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
   float sum = 0.f;
-  for (int c = 0; c < C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { s[c] = expf(x[c] - m); sum += s[c]; }
   max_alpha = 0.f;
-  for (int c = 0; c < C; ++c) { s[c] = s[c] / sum; if (c < C - 1) max_alpha = fmaxf(max_alpha, s[c]); }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { s[c] = s[c] / sum; if (c < C - 1) max_alpha = fmaxf(max_alpha, s[c]); }
   max_score = max_alpha;
 }
+template <int CT>
 __device__ __forceinline__ void row_scores(const float* __restrict__ x, int C, float* s, float& max_alpha, float& max_score) {
   float m = x[0];
-  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+  for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
   float sum = 0.f;
-  for (int c = 0; c < C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { s[c] = expf(x[c] - m); sum += s[c]; }
   float S = 0.f;
   max_alpha = 0.f;
-  for (int c = 0; c < C; ++c) { s[c] = s[c] / sum; S += s[c]; max_alpha = fmaxf(max_alpha, s[c]); }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { s[c] = s[c] / sum; S += s[c]; max_alpha = fmaxf(max_alpha, s[c]); }
   const float den = (S + 1e-20f) + 1e-9f;
   max_score = 0.f;
-  for (int c = 0; c < C; ++c) { s[c] = s[c] / den; max_score = fmaxf(max_score, s[c]); }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) if (c < C) { s[c] = s[c] / den; max_score = fmaxf(max_score, s[c]); }
 }
 
 // ---------------------------------------------------------------- S1: row max of normalised scores + level gate
+template <int CT>
 __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __restrict__ cls, long long rows_per_img, int B, int C,
                                                              float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg, int has_bg) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
@@ -49,9 +61,10 @@ __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __rest
   __syncthreads();
   bool fg = false;
   if ((int)threadIdx.x < nr) {
-    float x[MAXC], s[MAXC], ma, ms;
-    for (int c = 0; c < C; ++c) x[c] = srow[threadIdx.x * P + c];
-    if (has_bg) row_scores_bg(x, C, s, ma, ms); else row_scores(x, C, s, ma, ms);
+    float x[CT], s[CT], ma, ms;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) x[c] = c < C ? srow[threadIdx.x * P + c] : 0.f;
+    if (has_bg) row_scores_bg<CT>(x, C, s, ma, ms); else row_scores<CT>(x, C, s, ma, ms);
     rowmax[(long long)b * rows_per_img + r0 + threadIdx.x] = ms;
     fg = ma > fg_thr;
   }
@@ -63,8 +76,12 @@ extern "C" int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img,
   if (B == 0 || rows_per_img == 0) return 0;
   AOD_CHECK_ARG(cls && rowmax && any_fg && C >= 1 && C <= MAXC, "softmax_rowmax: bad args");
   dim3 grid((unsigned)((rows_per_img + 255) / 256), B);
-  hipLaunchKernelGGL(softmax_rowmax_kernel, grid, dim3(256), (size_t)256 * (C | 1) * 4, (hipStream_t)stream, cls, (long long)rows_per_img, B, C,
-                     fg_thr, rowmax, any_fg, has_bg);
+  if (C <= 24)
+    hipLaunchKernelGGL(softmax_rowmax_kernel<24>, grid, dim3(256), (size_t)256 * (C | 1) * 4, (hipStream_t)stream, cls, (long long)rows_per_img, B, C,
+                       fg_thr, rowmax, any_fg, has_bg);
+  else
+    hipLaunchKernelGGL(softmax_rowmax_kernel<MAXC>, grid, dim3(256), (size_t)256 * (C | 1) * 4, (hipStream_t)stream, cls, (long long)rows_per_img, B, C,
+                       fg_thr, rowmax, any_fg, has_bg);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -251,27 +268,34 @@ struct GatherArgs {
   float* boxes; float* scores; float* lam; int* cand_anchor;
   long long n_total; long long cand0; long long anchor0; int normalize;
 };
+template <int CT>
 __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= p.k) return;
   const long long a = p.idx ? p.idx[(long long)b * p.idx_pitch + j] : j;
   const long long row = (long long)b * p.A + a;
-  float x[MAXC], s[MAXC], ma, ms;
-  for (int c = 0; c < p.C; ++c) x[c] = p.cls[row * p.C + c];
-  if (p.normalize == 2) row_scores_bg(x, p.C, s, ma, ms); else row_scores(x, p.C, s, ma, ms);
+  float x[CT], s[CT], ma, ms;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) x[c] = c < p.C ? p.cls[row * p.C + c] : 0.f;
+  if (p.normalize == 2) row_scores_bg<CT>(x, p.C, s, ma, ms); else row_scores<CT>(x, p.C, s, ma, ms);
   if (p.normalize == 0) {   // raw softmax: undo nothing, recompute without the (S + 1e-20 + 1e-9) division
     float m = x[0];
-    for (int c = 1; c < p.C; ++c) m = fmaxf(m, x[c]);
+#pragma unroll
+    for (int c = 1; c < CT; ++c) if (c < p.C) m = fmaxf(m, x[c]);
     float sum = 0.f;
-    for (int c = 0; c < p.C; ++c) { s[c] = expf(x[c] - m); sum += s[c]; }
-    for (int c = 0; c < p.C; ++c) s[c] = s[c] / sum;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < p.C) { s[c] = expf(x[c] - m); sum += s[c]; }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < p.C) s[c] = s[c] / sum;
   }
   const long long o = (long long)b * p.n_total + p.cand0 + j;
   if (p.normalize == 2) {
-    for (int c = 0; c < p.C; ++c) p.scores[o * p.C + c] = s[c];          // C columns, the last one is the background probability
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < p.C) p.scores[o * p.C + c] = s[c];          // C columns, the last one is the background probability
   } else {
-    for (int c = 0; c < p.C; ++c) p.scores[o * (p.C + 1) + c] = s[c];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < p.C) p.scores[o * (p.C + 1) + c] = s[c];
     p.scores[o * (p.C + 1) + p.C] = 0.f;
   }
   p.lam[o] = p.lam_map[row];
@@ -310,7 +334,8 @@ extern "C" int aod_gather_decode(const float* cls, const float* reg, const float
   for (int i = 0; i < 4; ++i) { p.means[i] = means4 ? means4[i] : 0.f; p.stds[i] = stds4 ? stds4[i] : 1.f; }
   p.max_ratio = fabsf(logf(wh_ratio_clip));
   p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.n_total = n_total; p.cand0 = cand0; p.anchor0 = anchor0; p.normalize = normalize;
-  hipLaunchKernelGGL(gather_decode_kernel, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
+  if (C <= 24) hipLaunchKernelGGL(gather_decode_kernel<24>, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gather_decode_kernel<MAXC>, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }
