@@ -81,6 +81,18 @@ def test_conv_forward(ho, case):
     assert close(got, ref, rtol=1e-2 if not out_f32 else 1e-4, atol=1e-2 if not out_f32 else 1e-4)
 
 
+def test_conv_segment_with_more_than_4m_rows(ho):
+    """Row decode: segments below 2^22 pixels use a float-reciprocal division (exact there); a larger one must take the integer path."""
+    B, C, H, W, N = 1, 8, 2048, 2056, 16
+    g = synth.gen(5)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9))
+    ref = F.conv2d(x, w, None, 1, 1, 1)
+    y, segs = ho.conv2d_rows(nhwc_rows(x).cuda().bfloat16(), [ho.Seg(B, H, W)], ho.pack_weight_fwd(w.cuda()), N, 3, 3, 1, 1, 1)
+    torch.cuda.synchronize()
+    assert close(rows_nchw(y, B, H, W), ref, 1e-2, 1e-2)
+
+
 def test_conv_epilogue_bn_res_relu_and_z(ho):
     B, C, H, W, N = 2, 128, 12, 12, 256
     g = synth.gen(7)
