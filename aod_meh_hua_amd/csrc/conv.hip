@@ -384,6 +384,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   __syncthreads();
   if (!linear && p.ksplit == 1) prefetch_epilogue(true);     // destination rows are not consecutive: they come from the LDS table
   TSTAMP(2);
+#ifdef AOD_TILE_TIMING
+  if (g_tile_stamps && threadIdx.x == 0) g_tile_stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();     // shader clock around the K loop
+#endif
   const int lr = lane & 15, lq = lane >> 4;
   for (int cur = 0; have; cur ^= 1) {
     const bool more = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
@@ -429,6 +432,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     return;
   }
   // ---- epilogue: accumulators -> LDS (fp32, [BM][CP]) -> row-major vector stores
+#ifdef AOD_TILE_TIMING
+  if (g_tile_stamps && threadIdx.x == 0) g_tile_stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
+#endif
   TSTAMP(3);
   float* sc = reinterpret_cast<float*>(smem);
 #pragma unroll

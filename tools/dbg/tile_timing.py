@@ -27,7 +27,7 @@ res = torch.randn(M, N, device='cuda').bfloat16() if use_res else None
 bias = torch.randn(N, device='cuda')
 out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
 f = lambda: ho.conv2d_rows(x, segs, wp, N, R, R, 1, R // 2, 1, relu=True, pre_shift=bias, res=res, out=out)
-for _ in range(3): f()
+for _ in range(int(os.environ.get('AOD_TT_WARM', '3'))): f()       # (thousands of launches: clock readings need the DVFS steady state)
 ntile = ((M + 127) // 128) * ((N + 127) // 128)
 st = torch.zeros(ntile * 16, dtype=torch.int64, device='cuda')
 lib.aod_dbg_set_tile_stamps.argtypes = [__import__('ctypes').c_void_p]
@@ -46,6 +46,11 @@ for k, nme in enumerate(names):
     print(f'  {nme:24s} mean {d.mean():6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}')
 it = s[:, 8:16].astype(np.float64) * 0.01
 print('  prologue stamps relative to kernel entry (mean us): 8 (args + tile index), 10 (drow table), 1 (lambdas set up), 9 (rows decoded):', [round(float((x - t[:, 0]).mean()), 2) for x in (it[:, 0], it[:, 2], t[:, 1], it[:, 1])])
+dclk = (s[:, 13] - s[:, 12]).astype(np.float64)
+dwall = (t[:, 3] - t[:, 2])
+ok = dwall > 1.0
+if ok.any():
+    print(f'  in-kernel shader clock over the K loop (median over workgroups): {np.median(dclk[ok] / dwall[ok]) / 1e3:.2f} GHz')
 tot = t[:, 6] - t[:, 0]
 print(f'  tile total               mean {tot.mean():6.2f}  p10 {np.percentile(tot, 10):6.2f}  p90 {np.percentile(tot, 90):6.2f}')
 hw = s[:, 7]
