@@ -278,10 +278,12 @@ def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g
     pitch_cls = pitch_cls or A * Cc
     pitch_box = pitch_box or A * 4
     dt = torch.bfloat16 if out_bf16 else torch.float32
+    # (the kernel writes every element of an unpadded row: only pad columns need the zero fill)
+    alloc = lambda pitch, width: (torch.empty if pitch == width else torch.zeros)(rows // A, pitch, dtype=dt, device=cls.device)
     if grad_cls is None:
-        grad_cls = torch.zeros(rows // A, pitch_cls, dtype=dt, device=cls.device)
+        grad_cls = alloc(pitch_cls, A * Cc)
     if grad_bbox is None and bbox_pred is not None:
-        grad_bbox = torch.zeros(rows // A, pitch_box, dtype=dt, device=cls.device)
+        grad_bbox = alloc(pitch_box, A * 4)
     call('aod_edl_focal_l1_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
          gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
          pitch_cls, pitch_box, stream())
@@ -301,7 +303,7 @@ def meh_loss_bwd(lam, loss_noR, bbox_w4, g, out_bf16=False, A=1, pitch=None, gra
     n = lam.numel()
     pitch = pitch or A
     if grad is None:
-        grad = torch.zeros(n // A, pitch, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=lam.device)
+        grad = (torch.empty if pitch == A else torch.zeros)(n // A, pitch, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=lam.device)
     call('aod_meh_loss_bwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), n, ptr(g), ptr(grad), int(out_bf16), A, pitch, stream())
     return grad
 
