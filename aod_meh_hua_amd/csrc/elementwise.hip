@@ -302,22 +302,44 @@ extern "C" int aod_sgd_multi(void* const* params, void* const* grads, void* cons
 
 // ---------------------------------------------------------------- pad + cast + column sums (prediction-conv gradients, N = 180 / 36 / 9)
 // dz[m][c] = g[m][c] * (a[m][c] > 0 if a given -- fused ReLU of retina_L, Lambda_L2.py:101), zero in the pad columns.
+// 256 threads = RP row lanes x TC column lanes (TC = Npad rounded up to a power of two, at most 256): narrow heads (N = 36, 9) keep
+// every lane busy, and each thread has four independent rows in flight.
 template <bool G_F32>
 __global__ __launch_bounds__(256) void pad_cast_colsum_kernel(const void* __restrict__ g_, const float* __restrict__ a, bf16_t* __restrict__ dz,
-                                                              float* __restrict__ colsum, long long M, int N, int Npad, int rows_per_block) {
+                                                              float* __restrict__ colsum, long long M, int N, int Npad, int rows_per_block, int TC) {
+  __shared__ float red[256];
+  const int RP = 256 / TC;
+  const int c0 = threadIdx.x % TC, rl = threadIdx.x / TC;
   const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < Npad; c += 256) {
+  for (int cb = 0; cb < Npad; cb += TC) {            // (one pass unless Npad > 256)
+    const int c = cb + c0;
     float s = 0.f;
-    for (long long m = r0; m < r1; ++m) {
+    auto one = [&](long long m) {
       float v = 0.f;
       if (c < N) {
         v = G_F32 ? ((const float*)g_)[m * N + c] : (float)((const bf16_t*)g_)[m * N + c];
         if (a && !(a[m * N + c] > 0.f)) v = 0.f;
       }
-      dz[m * Npad + c] = (bf16_t)v;
-      s += v;
+      return v;
+    };
+    if (c < Npad) {
+      long long m = r0 + rl;
+      for (; m + 3ll * RP < r1; m += 4ll * RP) {
+        const float v0 = one(m), v1 = one(m + RP), v2 = one(m + 2ll * RP), v3 = one(m + 3ll * RP);
+        dz[m * Npad + c] = (bf16_t)v0; dz[(m + RP) * Npad + c] = (bf16_t)v1;
+        dz[(m + 2ll * RP) * Npad + c] = (bf16_t)v2; dz[(m + 3ll * RP) * Npad + c] = (bf16_t)v3;
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; m < r1; m += RP) { const float v = one(m); dz[m * Npad + c] = (bf16_t)v; s += v; }
     }
-    if (c < N) atomicAdd(colsum + c, s);
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+      float tsum = 0.f;
+      for (int r = 0; r < RP; ++r) tsum += red[r * TC + c0];
+      atomicAdd(colsum + c, tsum);
+    }
   }
 }
 extern "C" int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, int Npad, int g_is_f32,
@@ -327,8 +349,10 @@ extern "C" int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, voi
   int rpb = (int)((M + 1023) / 1024);
   if (rpb < 16) rpb = 16;
   const int nb = (int)((M + rpb - 1) / rpb);
-  if (g_is_f32) hipLaunchKernelGGL((pad_cast_colsum_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb);
-  else hipLaunchKernelGGL((pad_cast_colsum_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb);
+  int tc = 8;
+  while (tc < Npad && tc < 256) tc <<= 1;
+  if (g_is_f32) hipLaunchKernelGGL((pad_cast_colsum_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc);
+  else hipLaunchKernelGGL((pad_cast_colsum_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc);
   AOD_LAUNCH_CHECK();
   return 0;
 }

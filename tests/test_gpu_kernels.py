@@ -244,6 +244,24 @@ def test_conv_dgrad_and_wgrad(ho, case):
     assert close(got, x.grad, 1e-2, 1e-2 * float(x.grad.abs().max()))
 
 
+@pytest.mark.parametrize('N', [9, 36, 180, 720])
+def test_pad_cast_colsum(ho, N):
+    """Prediction-conv gradient: fp32 [M, N] -> bf16 [M, Npad] (zero pad columns, optional fused ReLU mask) + fp32 column sums."""
+    M = 1237
+    g = synth.gen(60 + N)
+    x = torch.randn(M, N, generator=g)
+    a = torch.randn(M, N, generator=g)
+    npad = (N + 7) // 8 * 8
+    for relu_out in (None, a):
+        dz, cs = ho.pad_cast_colsum(x.cuda(), npad, relu_out.cuda() if relu_out is not None else None)
+        torch.cuda.synchronize()
+        want = x if relu_out is None else x * (a > 0)
+        assert dz.shape == (M, npad) and dz.dtype == torch.bfloat16
+        assert torch.equal(dz[:, :N].float().cpu(), want.to(torch.bfloat16).float())
+        assert float(dz[:, N:].float().abs().max()) == 0.0 if npad > N else True
+        assert close(cs[:N], want.sum(0), 1e-4, 1e-3)
+
+
 def test_elementwise_ops(ho):
     g = synth.gen(5)
     B, C, H, W = 2, 64, 13, 11
