@@ -720,14 +720,14 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
 }
 
 // Split-K pays when the output is so small that whole tiles cannot fill the device: few tiles x very many K-steps (pyramid level P6:
-// a stride-2 3x3 on the 2048-channel C5, 8 x 8 outputs per image).  The decision and the slice boundaries depend on the PER-IMAGE
+// a stride-2 3x3 on the 2048-channel C5, 8 x 8 outputs per image; the 3x3 convs of the 16 x 16 backbone stage, K = 4608).  The decision and the slice boundaries depend on the PER-IMAGE
 // geometry and on K only, never on the batch size: the fp32 summation order of an output element -- and so the score of an image --
 // must not change with how the pool is batched.  Returns the number of K slices (1 = direct launch).
 static int choose_ksplit(const ConvKParams& p) {
   const int nk = (p.K + 63) / 64;
   if (nk < 64) return 1;
   for (int i = 0; i < p.nseg; ++i)
-    if (p.segB[i] > 0 && (long long)p.segOH[i] * p.segOW[i] > 64) return 1;
+    if (p.segB[i] > 0 && (long long)p.segOH[i] * p.segOW[i] > 256) return 1;
   return nk / 16;                       // slices of ~16 K-steps
 }
 
