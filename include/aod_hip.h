@@ -67,10 +67,11 @@ int aod_conv2d(const aod_conv_desc_t* desc, const void* src, const void* w_packe
                const float* pre_scale, const float* pre_shift, const void* res, const void* mask,
                const float* post_scale, void* zraw, float* colsum, aod_stream_t stream);
 
-/* Same operation with a caller-provided scratch buffer, which lets tiny-output / very-deep-reduction convolutions (the stride-2
- * 3x3 on C5 that makes pyramid level P6, fpn.py:156-202: 1 024 output pixels, K = 18 432) run split-K: the K-steps of a tile are
- * divided over several workgroups, each stores its fp32 partial tile into its own slab of `workspace` ([slices][M][N] fp32, need not
- * be initialised) and a second small kernel adds the slabs IN ORDER and applies the epilogue above -- deterministic, no atomics.
+/* Same operation with a caller-provided scratch buffer, which lets small-output / deep-reduction convolutions (at most 16 x 16
+ * outputs per image and K >= 4096: the stride-2 3x3 on C5 that makes pyramid level P6, fpn.py:156-202 -- 1 024 output pixels,
+ * K = 18 432 -- and the 3x3 convs of the last backbone stage, resnet.py:262-301) run split-K: the K-steps of a tile are divided over
+ * several workgroups, each stores its fp32 partial tile into its own slab of `workspace` ([slices][M][N] fp32, need not be
+ * initialised) and a second small kernel adds the slabs IN ORDER and applies the epilogue above -- deterministic, no atomics.
  * Whether and how K is sliced depends on K and on the per-image output size only, not on the batch: the summation order of an output
  * element never changes with the batching of the pool.
  * aod_conv2d_ws_bytes() is the size the launch heuristic wants for this descriptor (0: the direct kernel is used and workspace may
