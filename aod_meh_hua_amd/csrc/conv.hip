@@ -60,15 +60,18 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
+// PLAIN: launches without residual / mask operands (their prefetch registers are what pushes the 8-wave form into spills)
+template <int BM, int BN, int NT, bool PLAIN>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 4 : 1, NT == 512 ? 4 : 8))) void conv_igemm_kernel(const ConvKParams p) {
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
-  constexpr int RPP = 256 / CPR;     // tile rows covered per pass of the 256 threads
+  constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
   constexpr int ROWB = BK * 2;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+  constexpr int WAVES_M = NT / 128;        // waves are laid out WAVES_M x 2
+  constexpr int WM = BM / WAVES_M, WN = BN / 2;  // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int CP = BN + 4;               // fp32 epilogue pitch
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   unsigned wbase[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + 32 * i + 8 * uw + prow;
+    const int n = n0 + RPP * i + 8 * uw + prow;
     wbase[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8 + (long long)kt_begin * BK) * 2) : OOB;
   }
 
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const unsigned off = aoff[i];     // (a plain local: a subscript of a template-sized array is type-dependent and the host pass rejects it as a builtin argument)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (RPP * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
   };
   auto load_b = [&](int buf) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const unsigned off = kok ? woff[i] : OOB_BASE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (32 * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (RPP * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
     }
   };
   auto skip_dead_taps = [&]() {      // (at a tap boundary) hop over the taps that cannot reach this tile
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   // together with the first operand tile and consumed after the main loop -- a load-use chain per store iteration would expose one
   // memory latency per 16 B and cap memory-bound layers at a third of the bandwidth
   constexpr int NCH = BN / 8;              // 8-column chunks per tile row
-  constexpr int E_IT = BM * NCH / 256;
+  constexpr int E_IT = BM * NCH / NT;
   const int ec = t % NCH, er = t / NCH;
   float cs1[8], cb1[8], cs2[8];
   bf16x8 pres[E_IT], pmask[E_IT];
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
   const long long drow_lin = linear ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
   const long long lin_off = (drow_lin + m0 + er) * p.N + n0 + ec * 8;     // element offset of this thread's first row segment
-  const long long lin_step = (long long)(256 / NCH) * p.N;                // ... and the distance to its next one
+  const long long lin_step = (long long)(NT / NCH) * p.N;                // ... and the distance to its next one
   auto prefetch_epilogue = [&](bool from_table) {
     const int n = n0 + ec * 8;
     if (fast) {
@@ -321,11 +324,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         }
       }
       if (!from_table) {
-        if (p.res) {
+        if (!PLAIN && p.res) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + lin_off + it * lin_step);
         }
-        if (p.mask) {
+        if (!PLAIN && p.mask) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + lin_off + it * lin_step);
         }
@@ -340,15 +343,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
       }
     }
-    if (p.res || p.mask) {
+    if (!PLAIN && (p.res || p.mask)) {
 #pragma unroll
       for (int it = 0; it < E_IT; ++it) {
-        const int row = er + it * (256 / NCH);
+        const int row = er + it * (NT / NCH);
         const bool ok = (m0 + row < p.M) && (n + 8 <= p.N);
         const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
         const long long off = ok ? drow * p.N + n : 0;
-        if (p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
-        if (p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
+        if (!PLAIN && p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
+        if (!PLAIN && p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
       }
     }
   };
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     // gather the 8 k-chunks of a row then pick the record up with a lane shuffle (decoding per lane repeated the two divisions of a
     // row 8 times, four rows per lane)
     const int j = lane & 31;
-    const int m = m0 + 32 * (j >> 3) + 8 * uw + (j & 7);
+    const int m = m0 + RPP * (j >> 3) + 8 * uw + (j & 7);
     const int sg = one_seg ? sg_first : (m < p.M ? seg_of(m) : 0);
     const Geo gl = one_seg ? gu : load_geo(sg);
     unsigned b, oy, ox; int cls;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     bf16_t* const yl = reinterpret_cast<bf16_t*>(p.y) + lin_off;
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
-      const int row = er + it * (256 / NCH);
+      const int row = er + it * (NT / NCH);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
       float v[8];
@@ -467,11 +470,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += cb1[j];
-      if (p.res) {
+      if (!PLAIN && p.res) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)pres[it][j];
       }
-      if (p.mask) {
+      if (!PLAIN && p.mask) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)pmask[it][j] > 0.f) ? v[j] : 0.f;
       }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   } else
 #pragma unroll
   for (int it = 0; it < E_IT; ++it) {
-    const int row = er + it * (256 / NCH);
+    const int row = er + it * (NT / NCH);
     const int m = m0 + row;
     const int n = n0 + ec * 8;
     if (m >= p.M || n >= p.N) continue;
@@ -504,12 +507,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       const long long off = drow * p.N + n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
-      if (p.res) {
+      if (!PLAIN && p.res) {
         const bf16x8 rv = pres[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
-      if (p.mask) {
+      if (!PLAIN && p.mask) {
         const bf16x8 mv = pmask[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     g_tile_stamps[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 #endif
   if (p.colsum) {
-    // column sums of this tile: per-thread partials -> LDS [256 / NCH][BN] -> one fp32 atomic per column
+    // column sums of this tile: per-thread partials -> LDS [NT / NCH][BN] -> one fp32 atomic per column
     __syncthreads();
     float* sr = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -579,13 +582,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     __syncthreads();
     if (t < BN && n0 + t < p.N) {
       float s = 0.f;
-      for (int r = 0; r < 256 / NCH; ++r) s += sr[r * BN + t];
+      for (int r = 0; r < NT / NCH; ++r) s += sr[r * BN + t];
       atomicAdd(p.colsum + n0 + t, s);
     }
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NT = 256>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
   ConvKParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
@@ -595,10 +598,10 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, NT == 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, NT == 512>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(NT), lds, st, q);
   return 0;
 }
 
@@ -793,6 +796,14 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
+  // deep plain forward convs (no residual / mask operands): the 128 x 128 tile on 8 waves -- four waves per SIMD hide more of the
+  // K loop's waits than two (-4 % on the head-tower shape); with the epilogue-operand registers the 8-wave form spills and loses
+  static const char* dbg_w8 = getenv("AOD_TILE_W8");
+  if (!(dbg_w8 && dbg_w8[0] == '0') && !p.transposed && !p.res && !p.mask && p.N >= 128 && p.K >= 1024 && ntiles(128, 128) >= want) {
+    launch_conv<128, 128, 512>(p, st);
+    AOD_LAUNCH_CHECK();
+    return 0;
+  }
   if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
   else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
   else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
