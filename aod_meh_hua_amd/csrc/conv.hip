@@ -60,8 +60,9 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-// PLAIN: launches without residual / mask operands (their prefetch registers are what pushes the 8-wave form into spills)
-template <int BM, int BN, int NT, bool PLAIN>
+// OPS: which optional epilogue operands the instance supports -- 0 none, 1 ReLU mask only, 2 residual and mask (their prefetch registers
+// are what pushes the 8-wave form into spills, so it exists without them)
+template <int BM, int BN, int NT, int OPS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 4 : 1, NT == 512 ? 4 : 8))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   constexpr int BK = 64;
@@ -324,11 +325,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
         }
       }
       if (!from_table) {
-        if (!PLAIN && p.res) {
+        if (OPS > 1 && p.res) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + lin_off + it * lin_step);
         }
-        if (!PLAIN && p.mask) {
+        if (OPS > 0 && p.mask) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + lin_off + it * lin_step);
         }
@@ -343,15 +344,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
         cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
       }
     }
-    if (!PLAIN && (p.res || p.mask)) {
+    if (OPS > 0 && (p.res || p.mask)) {
 #pragma unroll
       for (int it = 0; it < E_IT; ++it) {
         const int row = er + it * (NT / NCH);
         const bool ok = (m0 + row < p.M) && (n + 8 <= p.N);
         const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
         const long long off = ok ? drow * p.N + n : 0;
-        if (!PLAIN && p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
-        if (!PLAIN && p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
+        if (OPS > 1 && p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
+        if (OPS > 0 && p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
       }
     }
   };
@@ -470,11 +471,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += cb1[j];
-      if (!PLAIN && p.res) {
+      if (OPS > 1 && p.res) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)pres[it][j];
       }
-      if (!PLAIN && p.mask) {
+      if (OPS > 0 && p.mask) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)pmask[it][j] > 0.f) ? v[j] : 0.f;
       }
@@ -507,12 +508,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       const long long off = drow * p.N + n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
-      if (!PLAIN && p.res) {
+      if (OPS > 1 && p.res) {
         const bf16x8 rv = pres[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
-      if (!PLAIN && p.mask) {
+      if (OPS > 0 && p.mask) {
         const bf16x8 mv = pmask[it];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
   }
 }
 
-template <int BM, int BN, int NT = 256>
+template <int BM, int BN, int NT = 256, int OPS = 2>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
   ConvKParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
@@ -598,10 +599,10 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, NT == 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, NT == 512>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(NT), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(NT), lds, st, q);
   return 0;
 }
 
@@ -796,11 +797,12 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
-  // deep plain forward convs (no residual / mask operands): the 128 x 128 tile on 8 waves -- four waves per SIMD hide more of the
-  // K loop's waits than two (-4 % on the head-tower shape); with the epilogue-operand registers the 8-wave form spills and loses
+  // deep convs without a residual operand (forward and dgrad of the head towers, the 3x3 of the backbone): the 128 x 128 tile on 8
+  // waves -- four waves per SIMD hide more of the K loop's waits than two (-4 % on the head-tower shape); with the residual's prefetch
+  // registers as well the 8-wave form spills and loses
   static const char* dbg_w8 = getenv("AOD_TILE_W8");
-  if (!(dbg_w8 && dbg_w8[0] == '0') && !p.transposed && !p.res && !p.mask && p.N >= 128 && p.K >= 1024 && ntiles(128, 128) >= want) {
-    launch_conv<128, 128, 512>(p, st);
+  if (!(dbg_w8 && dbg_w8[0] == '0') && !p.res && p.N >= 128 && p.K >= 1024 && ntiles(128, 128) >= want) {
+    if (!p.mask) launch_conv<128, 128, 512, 0>(p, st); else launch_conv<128, 128, 512, 1>(p, st);
     AOD_LAUNCH_CHECK();
     return 0;
   }
