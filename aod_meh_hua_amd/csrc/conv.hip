@@ -903,14 +903,21 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 // Both LDS images keep the global row-major form ([pixel][128 columns], 256-B rows) and are filled by LDS-DMA:
 // one wave-instruction = 4 pixel rows x 16 chunks, the conflict-avoiding XOR applied on the SOURCE chunk index,
 // which is the same for the 4 rows a lane serves -> every lane owns ONE fixed (tap, channel-chunk) column.
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+// NW waves per workgroup (4 or 8): the 128 x 128 dW tile is split 2 x 2 (64 x 64 per wave) or 2 x 4 (64 x 32 per wave); the 8-wave form
+// puts four waves on a SIMD instead of two.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int RPW = 4 * NW;          // pixel rows covered per pass of all waves
+  constexpr int PASSES = 64 / RPW;
+  constexpr int WNC = NW / 2;          // waves along the (tap, channel) axis
+  constexpr int NJ = 8 / WNC;          // 16-column groups per wave along that axis
   constexpr int BKM = 64;
   constexpr int IMG = BKM * 256;
   constexpr int STAGE = 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = uw >> 1, wn = uw & 1;
+  const int wm = uw / WNC, wn = uw % WNC;
   int bid = blockIdx.x;
   const int split = bid % p.splits; bid /= p.splits;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
   const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group
-  const int ch = (lane & 15) ^ ((prow << 2) | uw);             // source chunk of this lane (fixed)
+  const int ch = (lane & 15) ^ ((prow << 2) | (uw & 3));       // source chunk of this lane (fixed)
   const int zn = n0 + ch * 8;
   const bool zok = zn < p.N;
   const int kk = k0 + ch * 8;
@@ -947,31 +954,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (__attribute__((address_space(3))) void*)(stab + slot * 2048 + uw * 1024), 16, off, 0, 0, 0);
     }
   };
-  RowRec rec[4];
+  RowRec rec[PASSES];
   auto rread = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rec[i] = *reinterpret_cast<const RowRec*>(stab + slot * 2048 + (16 * i + 4 * uw + prow) * 32);
+    for (int i = 0; i < PASSES; ++i) rec[i] = *reinterpret_cast<const RowRec*>(stab + slot * 2048 + (RPW * i + 4 * uw + prow) * 32);
   };
   auto gload = [&](int mbase, int buf) {
     char* sz = smem + buf * STAGE;
     char* sx = sz + IMG;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mbase + 16 * i + 4 * uw + prow;
+    for (int i = 0; i < PASSES; ++i) {
+      const int m = mbase + RPW * i + 4 * uw + prow;
       const bool mok = m < me;
       const RowRec r = rec[i];
       const unsigned zoff = (mok && zok) ? r.zoff + zcol : OOB_BASE;
       const unsigned xoff = (mok && (r.mask & tbit)) ? r.xrow + (unsigned)dy * r.wc2 + cdx : OOB_BASE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + (16 * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + (16 * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + (RPW * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + (RPW * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (me - ms + BKM - 1) / BKM;
   tdma(ms, 0);
@@ -994,7 +1001,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const char* sx = sz + IMG;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
       const int r0 = ks * 32 + 8 * g + q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1006,8 +1013,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = wn * 64 + j * 16 + pp * 4;
+      for (int j = 0; j < NJ; ++j) {
+        const int col = wn * (16 * NJ) + j * 16 + pp * 4;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -1027,11 +1034,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wm * 64 + i * 16 + lq * 4 + r;
-        const int k = k0 + wn * 64 + j * 16 + lr;
+        const int k = k0 + wn * (16 * NJ) + j * 16 + lr;
 #ifdef AOD_WGRAD_NO_EPI      // ablation build (tools/dbg): how much of the kernel is the atomic epilogue
         if (n < p.N && k < p.K && acc[i][j][r] == 12345.678f) p.dw[(long long)n * p.K + k] = 1.f;
 #else
@@ -1087,10 +1094,13 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   p.splits = splits; p.rows_per_split = rps;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
+  static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
+  if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL(conv_wgrad_kernel<8>, dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<4>, dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }
