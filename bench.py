@@ -249,8 +249,11 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01n_pmc_hbm_traffic_per_launch.json')))
-            key = 'conv_wgrad_kernel' if kind == 'wgrad' else 'void conv_igemm_kernel<128, 128>'
-            traffic = round((pm[key]['read_MB_per_launch'] + pm[key]['write_MB_per_launch']) * 1e6)
+            # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants of the 128 x 128 tile)
+            pref = 'void conv_wgrad_kernel' if kind == 'wgrad' else 'void conv_igemm_kernel<128, 128'
+            ks = [k for k in pm if k.startswith(pref)]
+            nl = sum(pm[k]['launches'] for k in ks)
+            traffic = round(sum((pm[k]['read_MB_per_launch'] + pm[k]['write_MB_per_launch']) * pm[k]['launches'] for k in ks) / nl * 1e6)
         except Exception:      # noqa: BLE001
             pass
         roof = dict(bound='mfma', kernel={'fwd': 'conv_igemm_kernel (forward)', 'dgrad': 'conv_igemm_kernel (dgrad)', 'wgrad': 'conv_wgrad_kernel'}[kind],
