@@ -2,10 +2,10 @@
 // (mmdet/models/dense_heads/Lambda_L2.py:343-349, 489-537, 597-619; torch._sample_dirichlet) as three launches:
 //   H1  one block per image : objects (det score > 0.3), (candidate, object) pairs with IoU > 0.5 and
 //       max-score > 0.3 in the reference's nonzero() order, per-level pair ranges and mean(lambda).
-//   H2  one WAVEFRONT per pair: lanes = Monte-Carlo samples (8 rounds x 64 >= 500); every lane draws the
-//       20 gamma variates of one Dirichlet sample (Philox4x32-10 counter RNG -> Box-Muller -> Marsaglia-Tsang),
-//       normalises, accumulates sample entropy and the running mean of p; wave shuffles reduce to
-//       (aleatoric, epistemic) of the pair.  ALU/transcendental bound: ~100 B in, 8 B out, 10^4 variates per pair.
+//   H2  one 256-thread workgroup per pair: lanes = Monte-Carlo samples (LPP = 1) or quarter samples (LPP = 4, up to 96 Dirichlet
+//       columns); every lane draws the gamma variates of its classes (Philox4x32-10 counter RNG -> Box-Muller pair -> two
+//       Marsaglia-Tsang candidates per block), normalises, accumulates sample entropy and the running sum of p; shuffles + LDS reduce
+//       to (aleatoric, epistemic) of the pair.  Vector-ALU bound: ~100 B in, 8 B out, 10^4 variates per pair.
 //   H3  one block per image : deterministic (pair-order) means per (object, level, class) bin, then
 //       class -> scale -> object aggregation (Sum / Avg / Max each) -> one float per image.
 // The RNG stream is keyed by (seed, image id, anchor id, object id, sample, class, attempt): results do not
@@ -32,7 +32,7 @@ struct HuaArgs {
                     //    lambda mean over ALL anchors of the (image, level); dets / num_det / boxes are not read
   float* unc; float* pair_out; int max_pairs; int* pair_count;
   // workspace
-  int* pair_cand; int* pair_obj; float* pair_epi; float* pair_ale; int* lvl_pair_start; float* lam_mean; int* nobj;
+  int* pair_cand; int* pair_obj; int* pair_cls; float* pair_epi; float* pair_ale; int* lvl_pair_start; float* lam_mean; int* nobj;
 };
 
 __device__ __forceinline__ int level_of(const HuaArgs& p, int cand) {
@@ -60,17 +60,33 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
   const float* sc = p.scores + (long long)b * p.n * (p.C + 1);
   const float* dt = p.dets + (long long)b * p.max_num * 5;
   if (t == 0 && p.scale_mode) { s_no = 1; p.nobj[b] = 1; }
-  if (t == 0 && !p.scale_mode) {
-    int no = 0;
+  if (!p.scale_mode) {
+    // objects = detections with score > thr, in detection order: thread j takes detection j, ordered compaction by ballot + wave offsets
+    // (max_num <= HMAXO = 256: the first four waves)
     const int nd = min(p.num_det[b], p.max_num);
-    for (int j = 0; j < nd; ++j)
-      if (dt[j * 5 + 4] > p.obj_score_thr) {
-        for (int u = 0; u < 4; ++u) obox[no][u] = dt[j * 5 + u];
-        obox[no][4] = (obox[no][2] - obox[no][0]) * (obox[no][3] - obox[no][1]);
-        ++no;
+    float d5[5];
+    bool keep = false;
+    if (t < nd) {
+      for (int u = 0; u < 5; ++u) d5[u] = dt[t * 5 + u];
+      keep = d5[4] > p.obj_score_thr;
+    }
+    if (t < HMAXO) {
+      const unsigned long long m = __ballot(keep);
+      if ((t & 63) == 0) s_warp[t >> 6] = __popcll(m);
+      const int within = __popcll(m & ((1ull << (t & 63)) - 1ull));
+      __syncthreads();
+      int off = 0;
+      for (int k = 0; k < (t >> 6); ++k) off += s_warp[k];
+      if (keep) {
+        const int o = off + within;
+        for (int u = 0; u < 4; ++u) obox[o][u] = d5[u];
+        obox[o][4] = (d5[2] - d5[0]) * (d5[3] - d5[1]);
       }
-    s_no = no;
-    p.nobj[b] = no;
+      if (t == 0) { const int no = s_warp[0] + s_warp[1] + s_warp[2] + s_warp[3]; s_no = no; p.nobj[b] = no; }
+    } else {
+      __syncthreads();
+    }
+    __syncthreads();      // (s_warp is reused by the pair scan below)
   }
   if (t <= p.L) s_lvl[t] = 0;
   __syncthreads();
@@ -130,19 +146,22 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
     for (int l = 0; l <= p.L; ++l) { acc += s_lvl[l]; p.lvl_pair_start[b * (HMAXL + 1) + l] = min(acc, p.max_pairs); }
   }
   __syncthreads();
-  if (t < p.L) {
-    // mean(lambda) over the pairs of (image, level) in pair order (Lambda_L2.py:513-515)
-    int s = 0, e = 0, acc = 0;
-    for (int l = 0; l <= t; ++l) { s = acc; acc += s_lvl[l + 1]; e = acc; }
-    s = min(s, p.max_pairs); e = min(e, p.max_pairs);
-    float sum = 0.f;
-    if (p.scale_mode) {      // l_scores.mean() over every anchor of the level (:551-553)
-      const int c0 = p.level_start[t], c1 = p.level_start[t + 1];
-      for (int k = c0; k < c1; ++k) sum += p.lam[(long long)b * p.n + k];
-      p.lam_mean[b * HMAXL + t] = c1 > c0 ? sum / (float)(c1 - c0) : 0.f;
-    } else {
-      for (int k = s; k < e; ++k) sum += p.lam[(long long)b * p.n + pc[k]];
-      p.lam_mean[b * HMAXL + t] = e > s ? sum / (float)(e - s) : 0.f;
+  {
+    // mean(lambda) over the pairs of (image, level) (Lambda_L2.py:513-515): one wave per level, lanes stride over the pairs
+    const int wv = t >> 6, ln = t & 63;
+    if (wv < p.L) {
+      int s = 0, e = 0, acc = 0;
+      for (int l = 0; l <= wv; ++l) { s = acc; acc += s_lvl[l + 1]; e = acc; }
+      s = min(s, p.max_pairs); e = min(e, p.max_pairs);
+      float sum = 0.f;
+      if (p.scale_mode) {      // l_scores.mean() over every anchor of the level (:551-553)
+        s = p.level_start[wv]; e = p.level_start[wv + 1];
+        for (int k = s + ln; k < e; k += 64) sum += p.lam[(long long)b * p.n + k];
+      } else {
+        for (int k = s + ln; k < e; k += 64) sum += p.lam[(long long)b * p.n + pc[k]];
+      }
+      sum = wave_sum(sum);
+      if (ln == 0) p.lam_mean[b * HMAXL + wv] = e > s ? sum / (float)(e - s) : 0.f;
     }
   }
 }
@@ -162,84 +181,168 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 }
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-08f; }
 
-__device__ __forceinline__ float gamma_philox(float alpha, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-  const bool boost = alpha < 1.f;
-  const float a = boost ? alpha + 1.f : alpha;
-  const float d = a - (1.0f / 3.0f);
-  const float c = 1.f / sqrtf(9.f * d);
-  float out = 0.f, ub = 1.f;
-  for (unsigned t = 0; t < 64u; ++t) {
+// hardware transcendentals (v_log_f32 = log2, v_exp_f32 = exp2, v_sin/v_cos take REVOLUTIONS, v_rcp / v_sqrt): the sampler is bound by
+// vector-ALU issue, and the libm forms (range reduction, denormal fix-ups) tripled its instruction count.  Arguments here are normal
+// floats in (0, 1] or O(1); the numpy restatement (oracle/hua.py) uses exact float32 functions and agrees to ~1e-6 per variate.
+#define LN2_F 0.693147180559945309f
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * LN2_F; }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// One Gamma(alpha, 1) variate: Marsaglia-Tsang (2000) on a = alpha (+1 when alpha < 1), d = a - 1/3, cc = 1/sqrt(9d).
+// Attempt t draws ONE Philox block at counter (2t, c1, c2, c3): words -> (u_a, u_b) give the Box-Muller pair
+// x1 = r cos(2 pi u_b), x2 = r sin(2 pi u_b); (x1, u_c) is the first candidate and (x2, u_d) the second.  Trying two candidates per
+// block matters on a 64-lane wavefront: with one candidate (acceptance ~95.5 %) some lane rejects in 95 % of the rounds and the whole
+// wave pays a second Philox block; with two, a third-round is needed in ~12 % of the rounds.
+__device__ __forceinline__ float gamma_mt(float d, float cc, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  float out = 0.f;
+  for (unsigned t = 0; t < 32u; ++t) {
     unsigned r[4];
-    philox4x32_10(t, c1, c2, c3, k0, k1, r);
-    const float ua = u01(r[0]), ubx = u01(r[1]), uc = u01(r[2]);
-    if (t == 0) ub = u01(r[3]);
-    const float x = sqrtf(-2.f * logf(ua)) * cosf(6.283185307179586f * ubx);
-    const float v = 1.f + c * x;
-    const float v3 = v * v * v;
-    if (v > 0.f && logf(uc) < 0.5f * x * x + d - d * v3 + d * logf(v3)) { out = d * v3; break; }
+    philox4x32_10(2u * t, c1, c2, c3, k0, k1, r);
+    const float ua = u01(r[0]), ub = u01(r[1]);
+    const float rad = __builtin_amdgcn_sqrtf(-2.f * fast_ln(ua));
+    const float x1 = rad * __builtin_amdgcn_cosf(ub), x2 = rad * __builtin_amdgcn_sinf(ub);
+    const float v1 = 1.f + cc * x1, v2 = 1.f + cc * x2;
+    const float w1 = v1 * v1 * v1, w2 = v2 * v2 * v2;
+    const bool ok1 = v1 > 0.f && fast_ln(u01(r[2])) < 0.5f * x1 * x1 + d - d * w1 + d * fast_ln(w1);
+    const bool ok2 = v2 > 0.f && fast_ln(u01(r[3])) < 0.5f * x2 * x2 + d - d * w2 + d * fast_ln(w2);
+    if (ok1) { out = d * w1; break; }
+    if (ok2) { out = d * w2; break; }
   }
-  if (boost) out = out * expf(logf(ub) / alpha);
   return out;
 }
 
-// CT > 0: class count known at compile time (20 for VOC) -> alpha / g / sum_p live in registers
-template <int CT>
+template <int LPP>
+__device__ __forceinline__ float part_sum(float v) {     // over the LPP lanes that share one Monte-Carlo sample
+  if (LPP >= 2) v += __shfl_xor(v, 1, 64);
+  if (LPP >= 4) v += __shfl_xor(v, 2, 64);
+  return v;
+}
+template <int LPP>
+__device__ __forceinline__ float slot_sum(float v) {     // over the 64 / LPP lanes that hold the same class part
+#pragma unroll
+  for (int o = 32; o >= LPP; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One 256-thread workgroup per pair (grid-stride over the pairs of image blockIdx.y); the four waves split the Monte-Carlo samples.
+// A lane owns ONE sample (LPP = 1: C <= 24 Dirichlet columns -- VOC's 20 / SSD's 21) or a quarter of one (LPP = 4: COCO's 80 / 81 columns,
+// the lane's classes are [part * cpl, (part + 1) * cpl)): per-class state (d, cc, 1/alpha, running sum of p) stays in registers for any class
+// count up to 96; the sums over a sample's classes cross LPP lanes by shuffle, the sums over samples cross the wave once per pair.
+// EXACT: every lane owns exactly CPL classes (nd == CPL * LPP): no predication in the class loops.
+template <int CPL, int LPP, bool EXACT>
 __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
-  constexpr int CA = CT ? CT : HMAXC;
-  const int C = CT ? CT : p.nd;
+  constexpr int SPR = 64 / LPP;                      // samples per wave round
+  constexpr bool ALIGNED = LPP == 1 || (CPL % 4) == 0;
+  __shared__ float s_red[4][HMAXC + 2];
+  __shared__ float s_tot[2];
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int part = lane % LPP, slot = lane / LPP;
+  const int nd = p.nd;
+  const int cpl = EXACT ? CPL : (nd + LPP - 1) / LPP;
+  const int c0 = part * cpl;
+  const int n = EXACT ? CPL : max(min(cpl, nd - c0), 0);
   const int np = min(p.pair_count[b], p.max_pairs);
-  for (int pi = blockIdx.x * 4 + wave; pi < np; pi += gridDim.x * 4) {
-  const int cand = p.pair_cand[(long long)b * p.max_pairs + pi], obj = p.pair_obj[(long long)b * p.max_pairs + pi];
-  const int lvl = level_of(p, cand);
-  const float lamv = p.lam[(long long)b * p.n + cand];
-  const float lam_hat = p.lam_mean[b * HMAXL + lvl] / (lamv + 1e-7f) * 25.f;
-  const float* sc = p.scores + ((long long)b * p.n + cand) * (p.C + 1);
-  const unsigned c2 = (unsigned)p.cand_anchor[(long long)b * p.n + cand];
-  const unsigned c3 = (unsigned)p.image_ids[b];
-  float sum_p[CA];
-  float alpha[CA];
+  for (int pi = blockIdx.x; pi < np; pi += gridDim.x) {
+    const int cand = p.pair_cand[(long long)b * p.max_pairs + pi], obj = p.pair_obj[(long long)b * p.max_pairs + pi];
+    const int lvl = level_of(p, cand);
+    const float lamv = p.lam[(long long)b * p.n + cand];
+    const float lam_hat = p.lam_mean[b * HMAXL + lvl] / (lamv + 1e-7f) * 25.f;
+    const float* sc = p.scores + ((long long)b * p.n + cand) * (p.C + 1);
+    const unsigned c2 = (unsigned)p.cand_anchor[(long long)b * p.n + cand];
+    const unsigned c3 = (unsigned)p.image_ids[b];
+    float dd[CPL], cc[CPL], binv[CPL], sum_p[CPL];
+    float best = -1.f;
+    int am = 0;
 #pragma unroll
-  for (int c = 0; c < C; ++c) { alpha[c] = sc[c] * lam_hat; sum_p[c] = 0.f; }
-  float sum_ent = 0.f;
-  for (int s0 = 0; s0 < p.num_samples; s0 += 64) {
-    const int s = s0 + lane;
-    if (s < p.num_samples) {
-      float g[CA];
-      float tot = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const unsigned c1 = ((unsigned)obj << 20) | ((unsigned)s << 7) | (unsigned)c;
-        g[c] = fmaxf(gamma_philox(alpha[c], c1, c2, c3, p.seed_lo, p.seed_hi), FLT_MIN_F);
-        tot += g[c];
-      }
-      float ent = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float pr = fminf(fmaxf(g[c] / tot, FLT_MIN_F), ONE_MINUS_EPS);
-        ent -= pr * logf(pr);
-        sum_p[c] += pr;
-      }
-      sum_ent += ent;
+    for (int c = 0; c < CPL; ++c) {
+      const bool on = EXACT || c < n;
+      const float sv = on ? sc[c0 + c] : 0.f;
+      if (on && sv > best) { best = sv; am = c0 + c; }            // first maximum (torch.argmax), within this lane's part
+      const float alpha = sv * lam_hat;
+      const bool boost = alpha < 1.f;
+      const float a = boost ? alpha + 1.f : alpha;
+      dd[c] = a - (1.0f / 3.0f);
+      cc[c] = __builtin_amdgcn_rsqf(9.f * dd[c]);
+      binv[c] = boost ? fast_rcp(alpha) : 0.f;                     // u^(1/alpha) = exp2(log2(u) * binv); 0 -> factor 1 (no boost)
+      sum_p[c] = 0.f;
     }
-  }
-  const float inv = 1.f / (float)p.num_samples;
-  float total = 0.f;
+    if (LPP > 1) {                                                 // argmax over the parts: larger value, ties -> lower class index
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float avg = wave_sum(sum_p[c]) * inv;
-    total -= avg * logf(avg);
-  }
-  const float ale = wave_sum(sum_ent) * inv;
-  if (lane == 0) {
-    p.pair_epi[(long long)b * p.max_pairs + pi] = total - ale;
-    p.pair_ale[(long long)b * p.max_pairs + pi] = ale;
-    if (p.pair_out) {
-      float* o = p.pair_out + ((long long)b * p.max_pairs + pi) * 4;
-      o[0] = (float)cand; o[1] = (float)obj; o[2] = ale; o[3] = total - ale;
+      for (int o = 1; o < LPP; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (ob > best || (ob == best && oa < am)) { best = ob; am = oa; }
+      }
     }
-  }
+    if (threadIdx.x == 0) p.pair_cls[(long long)b * p.max_pairs + pi] = am;
+    float sum_ent = 0.f;
+    for (int r = wave; r * SPR < p.num_samples; r += 4) {
+      const int s = r * SPR + slot;
+      if (s < p.num_samples) {                                     // uniform over the LPP lanes of a sample
+        float g[CPL];
+        float tot = 0.f;
+        const unsigned cs = ((unsigned)obj << 20) | ((unsigned)s << 7);
+        unsigned rb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          if (EXACT || c < n) {
+            const unsigned gc = (unsigned)(c0 + c);
+            // boost uniforms: one Philox block per group of four classes, counter word 0 = 1 (the candidates use even words)
+            if (ALIGNED ? (c & 3) == 0 : (c == 0 || (gc & 3u) == 0u)) philox4x32_10(1u, cs | (gc >> 2), c2, c3, p.seed_lo, p.seed_hi, rb);
+            float gv = gamma_mt(dd[c], cc[c], cs | gc, c2, c3, p.seed_lo, p.seed_hi);
+            gv *= fast_exp2(fast_log2(u01(rb[gc & 3u])) * binv[c]);
+            g[c] = fmaxf(gv, FLT_MIN_F);
+            tot += g[c];
+          }
+        }
+        tot = part_sum<LPP>(tot);
+        const float inv = fast_rcp(tot);
+        float ent = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          if (EXACT || c < n) {
+            const float pr = fminf(fmaxf(g[c] * inv, FLT_MIN_F), ONE_MINUS_EPS);
+            ent -= pr * fast_log2(pr);
+            sum_p[c] += pr;
+          }
+        }
+        sum_ent += ent;
+      }
+    }
+    // sums over this wave's samples -> LDS (lanes 0 .. LPP-1 hold the totals of their class part)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const float v = slot_sum<LPP>(sum_p[c]);
+      if (slot == 0 && (EXACT || c < n)) s_red[wave][c0 + c] = v;
+    }
+    const float we = wave_sum(sum_ent);
+    if (lane == 0) s_red[wave][HMAXC] = we;
+    __syncthreads();
+    const float invn = 1.f / (float)p.num_samples;
+    float term = 0.f;
+    if ((int)threadIdx.x < nd) {
+      const float avg = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]) * invn;
+      term = -avg * logf(avg);
+    }
+    if (threadIdx.x < 128) {
+      term = wave_sum(term);
+      if (lane == 0) s_tot[wave] = term;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float total = s_tot[0] + s_tot[1];
+      const float ale = (s_red[0][HMAXC] + s_red[1][HMAXC] + s_red[2][HMAXC] + s_red[3][HMAXC]) * LN2_F * invn;
+      p.pair_epi[(long long)b * p.max_pairs + pi] = total - ale;
+      p.pair_ale[(long long)b * p.max_pairs + pi] = ale;
+      if (p.pair_out) {
+        float* o = p.pair_out + ((long long)b * p.max_pairs + pi) * 4;
+        o[0] = (float)cand; o[1] = (float)obj; o[2] = ale; o[3] = total - ale;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -249,61 +352,79 @@ __device__ __forceinline__ float agg_fold(int mode, float acc, float v, int cnt)
 }
 __device__ __forceinline__ float agg_final(int mode, float acc, int cnt) { return mode == 1 ? acc / (float)cnt : acc; }
 
+// H3: one block per image.  Per level the pairs (object, argmax class, epistemic) are staged in LDS; a thread per (object, class) bin
+// takes the mean over its pairs IN PAIR ORDER (deterministic), a thread per object then folds the classes in class order, the levels in
+// level order, and thread 0 the objects in object order (Lambda_L2.py:526-536, 597-619).
+constexpr int HRED_STAGE = 2048;
 __global__ __launch_bounds__(1024) void hua_reduce_kernel(const HuaArgs p) {
-  __shared__ float s_val[HMAXO][HMAXL];
-  __shared__ int s_has[HMAXO][HMAXL];
-  __shared__ float s_obj[HMAXO];
-  __shared__ int s_objhas[HMAXO];
+  extern __shared__ float s_bin[];                 // [no][nd] bin means of the current level, NaN = empty
+  __shared__ int s_po[HRED_STAGE], s_pcl[HRED_STAGE];
+  __shared__ float s_pe[HRED_STAGE];
+  __shared__ float s_lvl[HMAXO];                   // running fold over levels per object
+  __shared__ int s_lvln[HMAXO];
   __shared__ unsigned long long s_cls[2];
   const int b = blockIdx.x, t = threadIdx.x;
-  const int no = p.nobj[b];
+  const int no = p.nobj[b], nd = p.nd;
   if (t < 2) s_cls[t] = 0ull;
-  __syncthreads();
-  const int* pc = p.pair_cand + (long long)b * p.max_pairs;
+  for (int o = t; o < no; o += 1024) { s_lvl[o] = 0.f; s_lvln[o] = 0; }
   const int* po = p.pair_obj + (long long)b * p.max_pairs;
+  const int* pcl = p.pair_cls + (long long)b * p.max_pairs;
   const float* pe = p.pair_epi + (long long)b * p.max_pairs;
-  const float* sc = p.scores + (long long)b * p.n * (p.C + 1);
-  for (int u = t; u < no * p.L; u += 1024) {
-    const int o = u / p.L, l = u - o * p.L;
+  __syncthreads();
+  for (int l = 0; l < p.L; ++l) {
     const int s = p.lvl_pair_start[b * (HMAXL + 1) + l], e = p.lvl_pair_start[b * (HMAXL + 1) + l + 1];
-    float sum[HMAXC];
-    int cnt[HMAXC];
-    for (int c = 0; c < p.nd; ++c) { sum[c] = 0.f; cnt[c] = 0; }
-    for (int k = s; k < e; ++k)
-      if (po[k] == o) {
-        const float* r = sc + (long long)pc[k] * (p.C + 1);
-        int am = 0;
-        float mv = r[0];
-        for (int c = 1; c < p.nd; ++c) if (r[c] > mv) { mv = r[c]; am = c; }   // first max (torch.argmax on CPU)
-        sum[am] += pe[k];
-        ++cnt[am];
+    if (e <= s) continue;                          // (block-uniform)
+    const int nb = no * nd;
+    // running (sum, count) per bin in registers across the staged chunks of this level
+    float bs[(HMAXO * HMAXC + 1023) / 1024];
+    int bc[(HMAXO * HMAXC + 1023) / 1024];
+#pragma unroll
+    for (int u = 0; u < (HMAXO * HMAXC + 1023) / 1024; ++u) { bs[u] = 0.f; bc[u] = 0; }
+    for (int k0 = s; k0 < e; k0 += HRED_STAGE) {
+      const int nk = min(HRED_STAGE, e - k0);
+      for (int k = t; k < nk; k += 1024) { s_po[k] = po[k0 + k]; s_pcl[k] = pcl[k0 + k]; s_pe[k] = pe[k0 + k]; }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < (HMAXO * HMAXC + 1023) / 1024; ++u) {
+        const int bin = u * 1024 + t;
+        if (bin < nb) {
+          const int o = bin / nd, c = bin - o * nd;
+          for (int k = 0; k < nk; ++k)
+            if (s_po[k] == o && s_pcl[k] == c) { bs[u] += s_pe[k]; ++bc[u]; }
+        }
       }
-    float acc = 0.f;
-    int n = 0;
-    for (int c = 0; c < p.nd; ++c)
-      if (cnt[c]) {
-        acc = agg_fold(p.agg_class, acc, sum[c] / (float)cnt[c], n);
-        ++n;
-        atomicOr(&s_cls[c >> 6], 1ull << (c & 63));
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < (HMAXO * HMAXC + 1023) / 1024; ++u) {
+      const int bin = u * 1024 + t;
+      if (bin < nb) s_bin[bin] = bc[u] ? bs[u] / (float)bc[u] : __int_as_float(0x7fc00000);
+    }
+    __syncthreads();
+    for (int o = t; o < no; o += 1024) {
+      float acc = 0.f;
+      int n = 0;
+      for (int c = 0; c < nd; ++c) {
+        const float v = s_bin[o * nd + c];
+        if (v == v) {
+          acc = agg_fold(p.agg_class, acc, v, n);
+          ++n;
+          atomicOr(&s_cls[c >> 6], 1ull << (c & 63));
+        }
       }
-    s_val[o][l] = n ? agg_final(p.agg_class, acc, n) : 0.f;
-    s_has[o][l] = n;
+      if (n) {
+        const float lv = agg_final(p.agg_class, acc, n);
+        s_lvl[o] = agg_fold(p.agg_scale, s_lvl[o], lv, s_lvln[o]);
+        ++s_lvln[o];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int o = t; o < no; o += 1024) {
-    float acc = 0.f;
-    int n = 0;
-    for (int l = 0; l < p.L; ++l)
-      if (s_has[o][l]) { acc = agg_fold(p.agg_scale, acc, s_val[o][l], n); ++n; }
-    s_obj[o] = n ? agg_final(p.agg_scale, acc, n) : 0.f;
-    s_objhas[o] = n;
-  }
-  __syncthreads();
   if (t == 0) {
     float acc = 0.f;
     int n = 0;
     for (int o = 0; o < no; ++o)
-      if (s_objhas[o]) { acc = agg_fold(p.agg_obj, acc, s_obj[o], n); ++n; }
+      if (s_lvln[o]) { acc = agg_fold(p.agg_obj, acc, agg_final(p.agg_scale, s_lvl[o], s_lvln[o]), n); ++n; }
     float v = n ? agg_final(p.agg_obj, acc, n) : 0.f;
     if (p.clsW) v *= (float)(__popcll(s_cls[0]) + __popcll(s_cls[1]));
     p.unc[b] = v;
@@ -311,7 +432,7 @@ __global__ __launch_bounds__(1024) void hua_reduce_kernel(const HuaArgs p) {
 }
 
 extern "C" size_t aod_hua_ws_bytes(int B, int max_pairs) {
-  return (size_t)B * ((size_t)max_pairs * 16 + (HMAXL + 1) * 4 + HMAXL * 4 + 4) + 64;
+  return (size_t)B * ((size_t)max_pairs * 20 + (HMAXL + 1) * 4 + HMAXL * 4 + 4) + 64;
 }
 
 extern "C" int aod_hua_score(const float* boxes, const float* scores, const float* lam, const int32_t* cand_anchor, const float* dets,
@@ -337,6 +458,7 @@ extern "C" int aod_hua_score(const float* boxes, const float* scores, const floa
   char* w = (char*)ws;
   p.pair_cand = (int*)w; w += (size_t)B * max_pairs * 4;
   p.pair_obj = (int*)w; w += (size_t)B * max_pairs * 4;
+  p.pair_cls = (int*)w; w += (size_t)B * max_pairs * 4;
   p.pair_epi = (float*)w; w += (size_t)B * max_pairs * 4;
   p.pair_ale = (float*)w; w += (size_t)B * max_pairs * 4;
   p.lvl_pair_start = (int*)w; w += (size_t)B * (HMAXL + 1) * 4;
@@ -344,11 +466,15 @@ extern "C" int aod_hua_score(const float* boxes, const float* scores, const floa
   p.nobj = (int*)w;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(hua_pairs_kernel, dim3(B), dim3(1024), 0, st, p);
-  const int gx = (max_pairs + 3) / 4 < 256 ? (max_pairs + 3) / 4 : 256;
-  if (p.nd == 20) hipLaunchKernelGGL((hua_sample_kernel<20>), dim3(gx, B), dim3(256), 0, st, p);
-  else if (p.nd == 21) hipLaunchKernelGGL((hua_sample_kernel<21>), dim3(gx, B), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((hua_sample_kernel<0>), dim3(gx, B), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(hua_reduce_kernel, dim3(B), dim3(1024), 0, st, p);
+  const int gx = max_pairs < 512 ? max_pairs : 512;
+#define AOD_HUA_SAMPLE(CPL_, LPP_, EX_) hipLaunchKernelGGL((hua_sample_kernel<CPL_, LPP_, EX_>), dim3(gx, B), dim3(256), 0, st, p)
+  if (p.nd == 20) AOD_HUA_SAMPLE(20, 1, true);
+  else if (p.nd == 21) AOD_HUA_SAMPLE(21, 1, true);
+  else if (p.nd == 80) AOD_HUA_SAMPLE(20, 4, true);
+  else if (p.nd <= 24) AOD_HUA_SAMPLE(24, 1, false);
+  else AOD_HUA_SAMPLE(24, 4, false);
+#undef AOD_HUA_SAMPLE
+  hipLaunchKernelGGL(hua_reduce_kernel, dim3(B), dim3(1024), (size_t)max_num * p.nd * 4, st, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -10,59 +10,85 @@ constexpr int MAXC = 96;
 
 __device__ __forceinline__ float focal_pow(float b, float gamma) { return gamma == 2.f ? b * b : powf(b, gamma); }
 
-// per-row forward core: fills p[] (softmax) and returns row loss.  CT is a compile-time bound of C: the loops are fully unrolled and
-// predicated (same order of operations), so x[] / p[] live in registers -- with a run-time trip count they were demoted to scratch
-// memory (784-1168 B per lane) and the kernels ran at an eighth of the HBM rate.
-template <int CT>
-__device__ __forceinline__ float edl_row_fwd(const float* x, int C, long long label, float gamma, float alpha, float* p) {
-  float m = x[0];
+// Row layout in the kernels below: LPR lanes share one anchor row, lane part j owns the classes [j*cpl, (j+1)*cpl) with
+// cpl = ceil(C / LPR) <= CT.  CT is a compile-time bound: the loops are fully unrolled and predicated, so x[] / p[] / gp[] live in
+// registers -- with a run-time trip count (or a 96-wide bound for the 80/81-class heads) they were demoted to scratch memory
+// (400-1168 B per lane) and the kernels ran at an eighth of the HBM rate.  LPR = 1 (C <= 24: VOC's 20/21 classes, one lane per row, the
+// reference's sequential op order) or 4 (C <= 96: COCO's 80/81; row maxima / sums are combined over the 4 lanes by two shuffles).
+template <int LPR>
+__device__ __forceinline__ float grp_max(float v) {
+  if (LPR >= 2) v = fmaxf(v, __shfl_xor(v, 1, 64));
+  if (LPR >= 4) v = fmaxf(v, __shfl_xor(v, 2, 64));
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+  if (LPR >= 2) v += __shfl_xor(v, 1, 64);
+  if (LPR >= 4) v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// per-row forward core: fills p[] (softmax) and returns the row loss (identical in the LPR lanes of the row)
+template <int CT, int LPR>
+__device__ __forceinline__ float edl_row_fwd(const float* x, int n, int c0, long long label, float gamma, float alpha, float* p) {
+  float m = -INFINITY;
 #pragma unroll
-  for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
+  for (int c = 0; c < CT; ++c) if (c < n) m = fmaxf(m, x[c]);
+  m = grp_max<LPR>(m);
   float S = 0.f;
 #pragma unroll
-  for (int c = 0; c < CT; ++c) if (c < C) { p[c] = expf(x[c] - m); S += p[c]; }
+  for (int c = 0; c < CT; ++c) if (c < n) { p[c] = expf(x[c] - m); S += p[c]; }
+  S = grp_sum<LPR>(S);
   float tot = 0.f;
 #pragma unroll
-  for (int c = 0; c < CT; ++c) if (c < C) {
+  for (int c = 0; c < CT; ++c) if (c < n) {
     const float pr = p[c] / S;
     p[c] = pr;
     const float z = logf(pr / (1.f - pr + 1e-9f) + 1e-9f);
     const float q = 1.f / (1.f + expf(-z));
     float l;
-    if (label == c) l = -alpha * focal_pow(1.f - q, gamma) * logf(fmaxf(q, FLT_MIN_F));
+    if (label == c0 + c) l = -alpha * focal_pow(1.f - q, gamma) * logf(fmaxf(q, FLT_MIN_F));
     else l = -(1.f - alpha) * focal_pow(q, gamma) * logf(fmaxf(1.f - q, FLT_MIN_F));
     tot += l;
   }
-  return tot;
+  return grp_sum<LPR>(tot);
 }
 
-template <int CT>
+template <int CT, int LPR>
 __global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
                                                         const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
                                                         float gamma, float alpha, float* __restrict__ loss_noR, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
+  constexpr int RB = LB / LPR;   // rows per block
   const int P = C | 1;  // odd pitch -> conflict-free row reads
-  const long long r0 = (long long)blockIdx.x * LB;
-  const int nr = (int)min((long long)LB, nrows - r0);
+  const long long r0 = (long long)blockIdx.x * RB;
+  const int nr = (int)min((long long)RB, nrows - r0);
   const float* src = cls + r0 * C;
   const int tot = nr * C;
   for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
   __syncthreads();
   float s_cls = 0.f, s_box = 0.f, s_nor = 0.f;
-  if ((int)threadIdx.x < nr) {
-    const long long r = r0 + threadIdx.x;
+  const int lrow = threadIdx.x / LPR, part = threadIdx.x % LPR;
+  const bool live = lrow < nr;
+  const int row = live ? lrow : nr - 1;          // every lane takes part in the row shuffles
+  const int cpl = (C + LPR - 1) / LPR, c0 = part * cpl;
+  const int n = min(cpl, C - c0);
+  {
+    const long long r = r0 + row;
     float x[CT], p[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) x[c] = c < C ? srow[threadIdx.x * P + c] : 0.f;
-    const float l = edl_row_fwd<CT>(x, C, labels[r], gamma, alpha, p);
-    loss_noR[r] = l;
-    s_nor = l;
-    s_cls = l * lw[r];
-    if (bp) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(bp + r * 4), b = *reinterpret_cast<const f32x4*>(bt + r * 4),
-                  w = *reinterpret_cast<const f32x4*>(bw + r * 4);
-      for (int j = 0; j < 4; ++j) s_box += fabsf(a[j] - b[j]) * w[j];
+    for (int c = 0; c < CT; ++c) x[c] = c < n ? srow[row * P + c0 + c] : 0.f;
+    const float l = edl_row_fwd<CT, LPR>(x, n, c0, labels[r], gamma, alpha, p);
+    if (live && part == 0) {
+      loss_noR[r] = l;
+      s_nor = l;
+      s_cls = l * lw[r];
+      if (bp) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(bp + r * 4), b = *reinterpret_cast<const f32x4*>(bt + r * 4),
+                    w = *reinterpret_cast<const f32x4*>(bw + r * 4);
+        for (int j = 0; j < 4; ++j) s_box += fabsf(a[j] - b[j]) * w[j];
+      }
     }
   }
   // block reduction (fixed order -> deterministic)
@@ -91,7 +117,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-extern "C" size_t aod_loss_partials_len(int64_t nrows) { return (size_t)((nrows + LB - 1) / LB) * 3; }
+static inline int edl_lpr(int C) { return C <= 24 ? 1 : 4; }
+static inline long long edl_blocks(int64_t nrows, int C) { const int rb = LB / edl_lpr(C); return (nrows + rb - 1) / rb; }
+
+// (sized for the LPR = 4 form: 64 rows per block)
+extern "C" size_t aod_loss_partials_len(int64_t nrows) { return (size_t)((nrows + LB / 4 - 1) / (LB / 4)) * 3; }
 
 extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
                                     const float* bbox_tgt, const float* bbox_w, int64_t nrows, int C, float gamma, float alpha,
@@ -100,13 +130,12 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(cls && labels && label_w && loss_noR && sums3 && partials, "edl_fwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC, "edl_fwd: C=%d out of range", C);
   AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_fwd: bbox_pred needs targets and weights");
-  if (nrows == 0) return 0;
-  const long long nb = (nrows + LB - 1) / LB;
+  const long long nb = edl_blocks(nrows, C);
   if (C <= 24)
-    hipLaunchKernelGGL(edl_l1_fwd_kernel<24>, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+    hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 1>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
                        label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
   else
-    hipLaunchKernelGGL(edl_l1_fwd_kernel<MAXC>, dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+    hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 4>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / 4) * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
                        label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 3, sums3);
   AOD_LAUNCH_CHECK();
@@ -115,7 +144,7 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
 
 // backward.  Output element (row r, class c) lives at (r / A) * pitch + (r % A) * C + c so that the
 // gradient lands directly in the conv's [pixels, A*C (padded)] dZ layout, bf16 or fp32.
-template <bool OUT_BF16, int CT>
+template <bool OUT_BF16, int CT, int LPR>
 __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
                                                         const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
@@ -124,29 +153,37 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
                                                         void* __restrict__ grad_cls, void* __restrict__ grad_bbox, int A, int pitch_cls,
                                                         int pitch_box) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
+  constexpr int RB = LB / LPR;
   const int P = C | 1;
-  const long long r0 = (long long)blockIdx.x * LB;
-  const int nr = (int)min((long long)LB, nrows - r0);
+  const long long r0 = (long long)blockIdx.x * RB;
+  const int nr = (int)min((long long)RB, nrows - r0);
   const float* src = cls + r0 * C;
   const int tot = nr * C;
   for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
   __syncthreads();
-  if ((int)threadIdx.x < nr) {
-    const long long r = r0 + threadIdx.x;
+  const int lrow = threadIdx.x / LPR, part = threadIdx.x % LPR;
+  const bool live = lrow < nr;
+  const int row = live ? lrow : nr - 1;
+  const int cpl = (C + LPR - 1) / LPR, c0 = part * cpl;
+  const int n = min(cpl, C - c0);
+  {
+    const long long r = r0 + row;
     float x[CT], p[CT], gp[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) x[c] = c < C ? srow[threadIdx.x * P + c] : 0.f;
-    float m = x[0];
+    for (int c = 0; c < CT; ++c) x[c] = c < n ? srow[row * P + c0 + c] : 0.f;
+    float m = -INFINITY;
 #pragma unroll
-    for (int c = 1; c < CT; ++c) if (c < C) m = fmaxf(m, x[c]);
+    for (int c = 0; c < CT; ++c) if (c < n) m = fmaxf(m, x[c]);
+    m = grp_max<LPR>(m);
     float S = 0.f;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) if (c < C) { p[c] = expf(x[c] - m); S += p[c]; }
+    for (int c = 0; c < CT; ++c) if (c < n) { p[c] = expf(x[c] - m); S += p[c]; }
+    S = grp_sum<LPR>(S);
     const long long label = labels[r];
     const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[r] : g_noR_s);
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) if (c < C) {
+    for (int c = 0; c < CT; ++c) if (c < n) {
       const float pr = p[c] / S;
       p[c] = pr;
       const float om = 1.f - pr + 1e-9f;
@@ -154,18 +191,21 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
       const float z = logf(u + 1e-9f);
       const float q = 1.f / (1.f + expf(-z));
       float gz;   // d l / d z  (mmcv sigmoid_focal_loss backward)
-      if (label == c) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * logf(fmaxf(q, FLT_MIN_F)));
+      if (label == c0 + c) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * logf(fmaxf(q, FLT_MIN_F)));
       else gz = -(1.f - alpha) * focal_pow(q, gamma) * (gamma * (1.f - q) * logf(fmaxf(1.f - q, FLT_MIN_F)) - q);
       // dz/dp = (1+eps) / ((1-p+eps)^2 (u+eps))
       const float g = coef * gz * (1.f + 1e-9f) / (om * om * (u + 1e-9f));
       gp[c] = g;
       dot += pr * g;
     }
+    dot = grp_sum<LPR>(dot);
     // the row's gradient goes back into its LDS row; the block then stores all rows with consecutive lanes on consecutive elements
     // (one thread storing its own 20 values writes 4 B per lane at an 80-B lane stride)
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < CT; ++c) if (c < C) srow[threadIdx.x * P + c] = p[c] * (gp[c] - dot);
-    if (bp && grad_bbox) {
+      for (int c = 0; c < CT; ++c) if (c < n) srow[row * P + c0 + c] = p[c] * (gp[c] - dot);
+    }
+    if (live && part == 0 && bp && grad_bbox) {
       const float gb = g_bbox[0];
       const long long bb = (r / A) * pitch_box + (r % A) * 4;
       for (int j = 0; j < 4; ++j) {
@@ -196,14 +236,13 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(cls && labels && label_w && g_cls && grad_cls, "edl_bwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_bwd: bad C/A/pitch");
   AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && g_bbox && pitch_box >= A * 4), "edl_bwd: bbox args");
-  if (nrows == 0) return 0;
-  const long long nb = (nrows + LB - 1) / LB;
-#define AOD_EDL_BWD(BF, CT_)                                                                                                              \
-  hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, CT_>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls,       \
+  const long long nb = edl_blocks(nrows, C);
+#define AOD_EDL_BWD(BF, LPR_)                                                                                                              \
+  hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, 24, LPR_>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / LPR_) * (C | 1) * 4, (hipStream_t)stream, cls, \
                      (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR, \
                      g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box)
-  if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 24); else AOD_EDL_BWD(true, MAXC); }
-  else { if (C <= 24) AOD_EDL_BWD(false, 24); else AOD_EDL_BWD(false, MAXC); }
+  if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
+  else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
 #undef AOD_EDL_BWD
   AOD_LAUNCH_CHECK();
   return 0;

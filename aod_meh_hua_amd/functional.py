@@ -190,7 +190,7 @@ class ConvFn(Function):
         out_rows = as_rows(meta['out']) if meta.get('out') is not None else None      # caller-provided destination (pyramid slice)
         # the pre-BN activations z are NOT kept: the BN weight gradient comes from <w, dW> (see backward)
         r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
-                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], out=out_rows)
+                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], out=out_rows, alg=(I, O))
         y_rows, y_segs = r[0], r[1]
         ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
         ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
@@ -259,7 +259,7 @@ class ConvFn(Function):
                 gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
         x_segs = ctx.x_segs
         if need_w or need_bn:
-            dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'])
+            dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'], alg=(I, O))
             if need_bn:
                 gw, ggamma = ho.unpack_wgrad(dw, O, I, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
                 gbeta = s1
@@ -280,7 +280,7 @@ class ConvFn(Function):
             if res_g is not None and not fuse:
                 raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')
             dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
-                                      res=res_g, mask=x_rows if fuse else None, colsum=s1_in)
+                                      res=res_g, mask=x_rows if fuse else None, colsum=s1_in, alg=(I, O))
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None

@@ -21,7 +21,9 @@ _ROW_TABLES = {}     # wgrad row tables, one per conv geometry (shared by every 
 PROFILE = None
 
 
-def _prof(kind, desc, fn):
+def _prof(kind, desc, fn, alg=None):
+    """alg = (Cin, Cout) of the layer as the reference defines it: channel pads (stem 3 -> 8, prediction convs 180 -> 184 ...) are
+    excluded from the algorithmic FLOPs."""
     if PROFILE is None:
         return fn()
     # algorithmic FLOPs = 2 * (forward output pixels) * Cout * R*S*Cin, for dgrad too (dZ pixels = seg.H*seg.W)
@@ -29,7 +31,8 @@ def _prof(kind, desc, fn):
         m = sum(desc.seg[i].B * desc.seg[i].H * desc.seg[i].W for i in range(desc.nseg))
     else:
         m = sum(desc.seg[i].B * desc.seg[i].OH * desc.seg[i].OW for i in range(desc.nseg))
-    flops = 2.0 * m * desc.N * desc.R * desc.S * desc.C
+    cn = alg[0] * alg[1] if alg is not None else desc.N * desc.C
+    flops = 2.0 * m * desc.R * desc.S * cn
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
@@ -107,7 +110,7 @@ def _splitk_ws(d, device):
 
 def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, pre_scale=None, pre_shift=None,
                 res=None, mask=None, post_scale=None, relu=False, out_f32=False, save_z=False, out=None,
-                dst_segs=None, out_rows=None):
+                dst_segs=None, out_rows=None, alg=None):
     """Forward conv on row tensors.  Returns (y_rows, dst_segs[, z_rows])."""
     Cin = x_rows.shape[1]
     dst_segs = dst_segs or out_segs(src_segs, R, S, stride, pad, dil)
@@ -118,12 +121,12 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
     ws, wsb = _splitk_ws(d, x_rows.device)
     _prof('fwd', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
-                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, ptr(ws), wsb, stream()))
+                                 ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, ptr(ws), wsb, stream()), alg)
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
 def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,
-                      post_scale=None, out=None, x_rows_total=None, colsum=None):
+                      post_scale=None, out=None, x_rows_total=None, colsum=None, alg=None):
     """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad].
     res / mask / colsum: fused activation backward of the producer of x (see aod_conv2d)."""
     Npad = dz_rows.shape[1]
@@ -133,11 +136,11 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
     ws, wsb = _splitk_ws(d, dz_rows.device)
     _prof('dgrad', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
-                                   ptr(post_scale), None, ptr(colsum), ptr(ws), wsb, stream()))
+                                   ptr(post_scale), None, ptr(colsum), ptr(ws), wsb, stream()), alg)
     return out
 
 
-def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None):
+def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None, alg=None):
     """dW[Npad][R][S][C] fp32 (accumulated into `dw` if given)."""
     Cin, Npad = x_rows.shape[1], dz_rows.shape[1]
     if dw is None:
@@ -151,7 +154,7 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
         tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=x_rows.device)
         call('aod_conv_row_table', C.byref(d), ptr(tab), stream())
         _ROW_TABLES[key] = tab
-    _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), ptr(tab), stream()))
+    _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), ptr(tab), stream()), alg)
     return dw
 
 

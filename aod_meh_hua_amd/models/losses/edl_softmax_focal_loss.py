@@ -18,7 +18,7 @@ class _EDLFocalFn(Function):
         rows, C = pred.shape
         # elementwise loss [rows, C] is only needed by reduction='none' callers: recover it from the row kernel
         # by evaluating with one-hot weights is wasteful, so expose the row sum (what the hot path uses).
-        loss_row, sums = ho.edl_focal_l1_fwd(pred.contiguous(), target.contiguous(), torch.ones(rows, device=pred.device))
+        loss_row, sums = ho.edl_focal_l1_fwd(pred.contiguous(), target.contiguous(), torch.ones(rows, device=pred.device), gamma=gamma, alpha=alpha)
         ctx.save_for_backward(pred, target)
         ctx.cfg = (gamma, alpha)
         return loss_row

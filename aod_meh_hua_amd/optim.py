@@ -32,7 +32,9 @@ class FusedSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        touched = []
+        if self._lr_dev and not torch.cuda.is_current_stream_capturing():
+            self.device_lr()          # eager step between graph replays: the schedule may have changed group['lr'] since the last upload
+        touched, keep = [], []        # keep: contiguous gradient copies must outlive the launch that reads their raw pointers
         for gi, group in enumerate(self.param_groups):
             self._gi = gi
             ps, gs, ms, ns, first = [], [], [], [], None
@@ -41,6 +43,7 @@ class FusedSGD(torch.optim.Optimizer):
                     continue
                 assert p.dtype == torch.float32 and p.is_contiguous()
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(g)
                 st = self.state[p]
                 is_first = 'momentum_buffer' not in st
                 if is_first:

@@ -68,10 +68,63 @@ def build_model(device, seed=20):
     torch.manual_seed(seed)
     model = build_detector(cfg.model)
     model.init_weights()
-    with torch.no_grad():                     # "trained-like" head so that HUA is non-degenerate
-        model.bbox_head.retina_cls.weight.mul_(30.0)
+    with torch.no_grad():
         model.bbox_head.retina_L.bias.fill_(0.1)
     return model.to(device), cfg
+
+
+def calibrate_head(model, img, target_frac=0.005, fg_thr=0.3):
+    """"Trained-like" classification head: random-init weights give max-softmax ~ 0.05 everywhere, so every image would score 0
+    and the HUA sampler would idle.  Scale retina_cls (weight and bias: the logits scale exactly) by the factor k at which `target_frac` of
+    all anchors of this batch exceed the foreground threshold 0.3 (Lambda_L2.py:349,497-502).  Set-up only (torch ops, not timed)."""
+    from aod_meh_hua_amd.scoring import nhwc_view
+    head = model.bbox_head
+    model.eval()
+    with torch.no_grad():
+        cls, _ = head.forward(model.extract_feat(img))
+        x = torch.cat([nhwc_view(c.float(), head.cls_out_channels) for c in cls], 1)
+        frac = lambda k: float((torch.softmax(x * k, -1).amax(-1) > fg_thr).float().mean())
+        lo, hi = 1.0, 2.0
+        while frac(hi) < target_frac and hi < 1e6:
+            lo, hi = hi, hi * 2
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if frac(mid) < target_frac else (lo, mid)
+        head.retina_cls.weight.mul_(hi)
+        head.retina_cls.bias.mul_(hi)
+    return hi, frac(hi)
+
+
+def hua_stats(model, pool, score_kw, dev, reps=20):
+    """Pairs / objects per image of the scoring batch and the duration of aod_hua_score (HIP events on the launch stream; its three
+    launches pairs -> sample -> reduce) -- SURVEY 8d asks for P-bar, O-bar and variates/s beside the number."""
+    from aod_meh_hua_amd import scoring
+    head = model.bbox_head
+    model.eval()
+    with torch.no_grad():
+        feats = model.extract_feat(pool['img'])
+        outs = head.forward(feats)
+        Ls = head.forward_L(feats)
+        kw = {k: v for k, v in score_kw.items() if k not in ('return_loss', 'rescale')}
+        _, unc, it = head.get_bboxes(*outs, pool['img_metas'], rescale=True, with_nms=True, L_scores=Ls, _return_internals=True, **kw)
+        B = unc.shape[0]
+        ids = torch.arange(B, device=dev, dtype=torch.int64)
+        args = (it['cand'], it['dets'], it['num'], ids, head.test_cfg.max_per_img)
+        _, pc, _ = scoring.hua_score(*args, want_pairs=True)
+        nobj = (it['dets'][..., 4] > 0.3).sum(1)
+        scoring.hua_score(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            scoring.hua_score(*args)
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    pairs = int(pc.sum())
+    nd = head.cls_out_channels
+    return dict(pairs_per_img=round(pairs / B, 1), objects_per_img=round(float(nobj.float().mean()), 1),
+                nonzero_scores=int((unc > 0).sum()), hua_us_per_batch=round(us, 1), us_per_pair=round(us / max(pairs, 1), 4),
+                gamma_variates_per_s=round(pairs * 500 * nd / (us * 1e-6), 0) if pairs else 0.0)
 
 
 def make_optimizers(model, cfg):
@@ -111,6 +164,13 @@ def main():
     B, H = args.batch, args.size
     data = synth_batch(B, H, H, dev, seed=20 + rank)
     pool = synth_batch(B, H, H, dev, seed=1020 + rank)
+    # The pool is scored with a FROZEN copy of the model whose classification head is "trained-like" (SURVEY 8d C3): the training phase
+    # of the bench fits random labels, which flattens any synthetic confidence within a few SGD steps, and random-init confidence is
+    # ~0.05 everywhere -- either way every image would score 0 and the HUA sampler would idle.  Same architecture, same kernels.
+    import copy
+    pool_model = copy.deepcopy(model)
+    cal_k, cal_frac = calibrate_head(pool_model, pool['img'])
+    broadcast_model(pool_model)               # every rank scores with rank 0's calibrated head
     score_kw = dict(return_loss=False, rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS',
                     uPool2='objectSum_scaleMax_classSum', scaleUnc=False, showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
     do_train, do_score = 'train' in args.mode, 'score' in args.mode
@@ -124,7 +184,7 @@ def main():
     from aod_meh_hua_amd.graphs import GraphedScore, GraphedTrainStep
     use_graph = not args.no_graph
     gstep = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync if world > 1 else None, Labeled=True, Pseudo=False)
-    gscore = GraphedScore(model, **{k: v for k, v in score_kw.items() if k != 'return_loss'}) if have_scoring else None
+    gscore = GraphedScore(pool_model, **{k: v for k, v in score_kw.items() if k != 'return_loss'}) if have_scoring else None
     data_dev = dict(data, gt_bboxes=[b.to(dev) for b in data['gt_bboxes']], gt_labels=[l.to(dev) for l in data['gt_labels']])
 
     state = dict(graph_ok=use_graph)
@@ -155,10 +215,10 @@ def main():
             gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
             opt_L.step()
         if do_score:
-            model.eval()
+            pool_model.eval()
             with torch.no_grad():
                 ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                _, unc = model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **score_kw)
+                _, unc = pool_model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **score_kw)
                 unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
                 if world > 1:
                     gather_scores(unc, B * world)
@@ -261,6 +321,12 @@ def main():
                     traffic=traffic, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
                     all={k: dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in agg.items()})
 
+    hua = None
+    if do_score:
+        hua = hua_stats(pool_model, pool, score_kw, dev)          # every rank (same launches); rank 0 reports its own batch
+        hua.update(head_scale=round(cal_k, 3), fg_anchor_frac_at_calibration=round(cal_frac, 5))
+        assert hua['pairs_per_img'] > 0, 'degenerate HUA phase: no (candidate, object) pair in the scoring batch'
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, do_train, do_score and have_scoring)
@@ -275,7 +341,7 @@ def main():
                                 global_batch=B * world, image_size=H, num_classes=20, anchors_per_image=49104 if H == 512 else None,
                                 parallelism=f'dp{world}', phases=args.mode if (do_score or not have_scoring) else 'train',
                                 launch='hip-graph replay' if use_graph else 'eager'),
-                    phase_rates=phase, roofline=roof, cpu_baseline=cpu)
+                    phase_rates=phase, hua=hua, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -6,9 +6,9 @@ Three samplers for the stochastic part of `ComputeObjUnc` (Lambda_L2.py:489-537)
   * sampler='torch'   -- torch.distributions.Dirichlet, exactly what the reference calls
                          (statistical parity with the golden MC-500 values);
   * sampler='philox'  -- numpy restatement of the build's counter-based sampler
-                         (Philox4x32-10 -> Box-Muller -> Marsaglia-Tsang gamma), the SAME
-                         algorithm as aod_meh_hua_amd/csrc/hua.hip, stream keyed by
-                         (seed, image id, anchor id, object id, sample, class, attempt) so
+                         (Philox4x32-10 -> Box-Muller pair -> two Marsaglia-Tsang candidates per
+                         block), the SAME algorithm as aod_meh_hua_amd/csrc/hua.hip, stream keyed
+                         by (seed, image id, anchor id, object id, sample, class, attempt) so
                          the HIP kernel is checked value-for-value, not only statistically;
   * closed form       -- epi_inf = H(a/S) - psi(S+1) + sum (a_k/S) psi(a_k+1)  (MC limit).
 """
@@ -48,12 +48,16 @@ def _u01(x):
     return ((x >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
 
 
-def philox_gamma(alpha, c1, c2, c3, seed, max_attempts=64):
+def philox_gamma(alpha, c1, c2, c3, seed, max_attempts=32):
     """Gamma(alpha, 1) variates, float32, Marsaglia-Tsang (2000) with the alpha<1 boost
-    gamma(alpha) = gamma(alpha+1) * u^(1/alpha).  One Philox call per attempt `t` at counter
-    (t, c1, c2, c3): words -> (u_a, u_b) Box-Muller normal, u_c accept test, u_d boost (t=0 only).
+    gamma(alpha) = gamma(alpha+1) * u^(1/alpha) -- the stream of aod_meh_hua_amd/csrc/hua.hip (gamma_mt):
+    attempt t draws ONE Philox block at counter (2t, c1, c2, c3): words (u_a, u_b) -> Box-Muller pair
+    x1 = r cos(2 pi u_b), x2 = r sin(2 pi u_b); candidate 1 = (x1, u_c), candidate 2 = (x2, u_d), first accepted wins.
+    The boost uniform of class c = c1 & 127 is word (c & 3) of the Philox block at counter (1, (c1 & ~127) | (c >> 2), c2, c3):
+    one block serves four classes of a sample.
     """
     alpha = np.asarray(alpha, dtype=np.float32)
+    c1 = np.broadcast_to(np.asarray(c1, dtype=np.uint32), alpha.shape)
     k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     boost = alpha < 1
     a = np.where(boost, alpha + np.float32(1), alpha).astype(np.float32)
@@ -61,22 +65,26 @@ def philox_gamma(alpha, c1, c2, c3, seed, max_attempts=64):
     c = (np.float32(1.0) / np.sqrt(np.float32(9.0) * d)).astype(np.float32)
     out = np.zeros(alpha.shape, dtype=np.float32)
     done = np.zeros(alpha.shape, dtype=bool)
-    ub = np.ones(alpha.shape, dtype=np.float32)
+    two_pi = np.float32(2.0 * np.pi)
     for t in range(max_attempts):
-        r0, r1, r2, r3 = philox4x32(np.uint32(t), c1, c2, c3, k0, k1)
-        u_a, u_b, u_c = _u01(r0), _u01(r1), _u01(r2)
-        if t == 0:
-            ub = _u01(r3)
-        x = (np.sqrt(np.float32(-2.0) * np.log(u_a)) * np.cos(np.float32(2.0 * np.pi) * u_b)).astype(np.float32)
-        v = (np.float32(1.0) + c * x).astype(np.float32)
-        v3 = (v * v * v).astype(np.float32)
-        with np.errstate(invalid='ignore', divide='ignore'):
-            ok = (v > 0) & (np.log(u_c) < np.float32(0.5) * x * x + d - d * v3 + d * np.log(v3))
-        newly = ok & ~done
-        out = np.where(newly, (d * v3).astype(np.float32), out)
-        done |= ok
+        r0, r1, r2, r3 = philox4x32(np.uint32(2 * t), c1, c2, c3, k0, k1)
+        u_a, u_b = _u01(r0), _u01(r1)
+        rad = np.sqrt(np.float32(-2.0) * np.log(u_a)).astype(np.float32)
+        for x, u_acc in (((rad * np.cos(two_pi * u_b)).astype(np.float32), _u01(r2)),
+                         ((rad * np.sin(two_pi * u_b)).astype(np.float32), _u01(r3))):
+            v = (np.float32(1.0) + c * x).astype(np.float32)
+            v3 = (v * v * v).astype(np.float32)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                ok = (v > 0) & (np.log(u_acc) < np.float32(0.5) * x * x + d - d * v3 + d * np.log(v3))
+            newly = ok & ~done
+            out = np.where(newly, (d * v3).astype(np.float32), out)
+            done |= ok
         if done.all():
             break
+    cls = c1 & np.uint32(127)
+    rb = philox4x32(np.uint32(1), (c1 & ~np.uint32(127)) | (cls >> np.uint32(2)), c2, c3, k0, k1)
+    w = (cls & np.uint32(3)).astype(np.int64)
+    ub = _u01(np.choose(w, rb))
     with np.errstate(divide='ignore', over='ignore', under='ignore'):
         boosted = (out * np.exp(np.log(ub) / alpha)).astype(np.float32)
     return np.where(boost, boosted, out).astype(np.float32)

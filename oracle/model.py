@@ -59,13 +59,14 @@ def state_dict_spec(depth=50, num_classes=20, num_anchors=9):
     return spec
 
 
-def seeded_state_dict(depth=50, num_classes=20, cls_bias=0.0):
+def seeded_state_dict(depth=50, num_classes=20, cls_bias=0.0, bn3_gamma=0.3):
     """The fixed weight recipe shared by golden generation and the build (the real
     R50 checkpoint is 156 MB, so both sides REGENERATE it): tensor idx in state_dict order ->
     torch.Generator().manual_seed(20+idx); conv weights Kaiming-normal (std sqrt(2/fan_in)) except
     the three `retina_*` prediction convs N(0, 0.01) (the reference's head init std,
     Lambda_L2.py:28-29); conv biases 0 (+cls_bias on retina_cls); BN beta=0, mean=0, var=1,
-    gamma=1 except bn3 -> 0.3 and downsample.1 -> 0.7 so the residual sum keeps O(1) variance."""
+    gamma=1 except bn3 -> bn3_gamma (0.3; the 23-block layer3 of R101 needs ~0.12) and downsample.1 -> 0.7 so the residual sum
+    keeps O(1) variance."""
     sd = OrderedDict()
     for idx, (k, shp) in enumerate(state_dict_spec(depth, num_classes)):
         g = torch.Generator().manual_seed(20 + idx)
@@ -77,7 +78,7 @@ def seeded_state_dict(depth=50, num_classes=20, cls_bias=0.0):
         elif k.endswith('running_var'):
             sd[k] = torch.ones(shp)
         elif k.endswith('.weight'):            # BN gamma
-            sd[k] = torch.full(shp, 0.3 if '.bn3.' in k else (0.7 if 'downsample.1' in k else 1.0))
+            sd[k] = torch.full(shp, bn3_gamma if '.bn3.' in k else (0.7 if 'downsample.1' in k else 1.0))
         else:
             sd[k] = torch.zeros(shp)
     sd['bbox_head.retina_cls.bias'] += cls_bias

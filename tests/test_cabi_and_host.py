@@ -42,7 +42,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     lib.aod_last_error.restype = ctypes.c_char_p
     assert b'multiple of 8' in lib.aod_last_error()
     lib.aod_loss_partials_len.restype = ctypes.c_size_t
-    assert lib.aod_loss_partials_len(ctypes.c_int64(1000)) == 12
+    assert lib.aod_loss_partials_len(ctypes.c_int64(1000)) == 48      # 3 per block of 64 rows (the 4-lanes-per-row form for > 24 classes)
 
 
 def test_product_refuses_cpu_tensors():

@@ -1,0 +1,237 @@
+"""GPU, BASELINE.json configs[4]: RetinaNet-R101-FPN + MEH/HUA with 80 classes at COCO resolutions (800 x 1344 and a non-square
+608 x 1024).  The reference has no MEH config for COCO / R101: this is Config_RetinaNet.py with depth=101, num_classes=80,
+and it is the only place the > 24-class forms of the row kernels (4 lanes per anchor row in the loss, `<96>` softmax / gather, the
+quarter-sample HUA sampler) and the 23-block layer3 run.  Checked against the fp32 oracle on the same seeded weights and inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detect as odetect
+from oracle import geometry as ogeo
+from oracle import hua as ohua
+from oracle import losses as olosses
+from oracle import model as omodel
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NC = 80
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.fixture(scope='module')
+def built():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    cfg.model.backbone.pop('init_cfg')
+    cfg.model.backbone.depth = 101
+    cfg.model.bbox_head.num_classes = NC
+    cfg.model.bbox_head.loss_cls.num_classes = NC
+    model = build_detector(cfg.model)
+    sd = omodel.seeded_state_dict(depth=101, num_classes=NC, bn3_gamma=0.12)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().train(), sd
+
+
+def _oracle_step(sd0, img, gtb, gtl):
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not any(s in k for s in ('running', 'backbone.conv1.', 'backbone.bn1.', 'layer1.')):
+            v.requires_grad_(True)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    o = omodel.train_step(sd, img, gtb, gtl, depth=101, num_classes=NC)
+    o['loss'].backward()
+    g1 = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+    for v in sd.values():
+        v.grad = None
+    oL = omodel.train_step_L(sd, o['feats'], o['loss_noR'], o['targets'])
+    oL['loss'].backward()
+    gL = {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}
+    return o, oL, g1, gL
+
+
+NAMES = ['backbone.layer2.0.conv1.weight', 'backbone.layer3.0.downsample.0.weight', 'backbone.layer3.11.conv2.weight',
+         'backbone.layer3.22.bn3.weight', 'backbone.layer4.2.conv3.weight', 'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.4.conv.weight',
+         'bbox_head.cls_convs.0.conv.weight', 'bbox_head.cls_convs.3.conv.bias', 'bbox_head.reg_convs.1.conv.weight',
+         'bbox_head.retina_cls.weight', 'bbox_head.retina_cls.bias', 'bbox_head.retina_reg.weight']
+NAMES_L = ['bbox_head.L_convs.0.conv.weight', 'bbox_head.L_convs.3.conv.bias', 'bbox_head.retina_L.weight', 'bbox_head.retina_L.bias']
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 800, 1344), (2, 608, 1024)])
+def test_r101_80class_train_step_vs_oracle(built, B, H, W):
+    model, sd0 = built
+    model.load_state_dict(sd0, strict=True)
+    img = synth.images(B, H, W, seed=31)
+    gtb, gtl = synth.random_gts(B, H, W, seed=32, gmin=3, gmax=6, num_classes=NC)
+    o, oL, g1, gL = _oracle_step(sd0, img, gtb, gtl)
+    data = dict(img=img.cuda(), img_metas=synth.metas(B, H, W), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    torch.cuda.synchronize()
+    A = sum(c.shape[-2] * c.shape[-1] * 9 for c in head_out[1])
+    assert A == sum(t.shape[1] for t in o['targets']['labels'])
+    assert int(head_out[8]) == o['targets']['num_total_pos']                                  # int-exact assignment at 134 k anchors / image
+    lab = torch.cat([l.reshape(B, -1) for l in head_out[4]], 1).cpu()
+    assert torch.equal(lab, torch.cat(o['targets']['labels'], 1))
+    assert int(lab.max()) == NC and int(lab.min()) >= 0
+    got = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
+    exp = [float(sum(o['loss_cls'])), float(sum(o['loss_bbox'])), float(sum(x.mean() for x in o['loss_noR']))]
+    assert np.allclose(got, exp, rtol=2e-2), (got, exp)
+    assert np.allclose(float(out['loss']), float(o['loss']), rtol=2e-2)
+    for l in range(5):                                                                        # per-anchor loss rows, every level
+        a, b = prev[l].cpu().numpy(), o['loss_noR'][l].detach().numpy()
+        assert np.abs(a - b).max() <= 3e-2 * np.abs(b).max() + 1e-6, l
+    model.zero_grad()
+    out['loss'].backward()
+    pd = dict(model.named_parameters())
+    for k in NAMES:
+        a, b = pd[k].grad.float().cpu().flatten(), g1[k].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.99, (k, cos)
+        assert abs(float(a.norm() / b.norm()) - 1) < 6e-2, (k, float(a.norm()), float(b.norm()))
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    model.zero_grad()
+    lossL['loss'].backward()
+    torch.cuda.synchronize()
+    assert np.allclose(float(lossL['loss']), float(oL['loss']), rtol=3e-2), (float(lossL['loss']), float(oL['loss']))
+    for k in NAMES_L:
+        a, b = pd[k].grad.float().cpu().flatten(), gL[k].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.99, (k, cos)
+
+
+def test_80class_loss_kernels_vs_oracle():
+    """aod_edl_focal_l1_fwd / bwd with C = 80 and C = 81 (4 lanes per row, ragged last lane) against the oracle's autograd, incl.
+    saturated rows and the padded bf16 dZ layout."""
+    from aod_meh_hua_amd import hipops as ho
+    for C, N, A in ((80, 4099, 1), (81, 1536, 3), (33, 777, 1), (96, 512, 2)):
+        li = synth.loss_inputs(N=N, C=C, seed=21 + C)
+        li['logits'][0] = 0.0
+        li['logits'][1, :] = -60.0
+        li['logits'][1, C - 1] = 60.0                                     # saturated row
+        li['labels'][1] = C - 1
+        x = li['logits'].clone().requires_grad_(True)
+        bp = li['bbox_pred'].clone().requires_grad_(True)
+        n = li['num_total_samples']
+        lc, lb, lnr = olosses.loss_single(x, bp, li['labels'], li['label_weights'], li['bbox_targets'], li['bbox_weights'], n)
+        (lc + lb + lnr.mean()).backward()
+        dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in li.items()}
+        noR, sums = ho.edl_focal_l1_fwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'])
+        torch.cuda.synchronize()
+        assert np.allclose(noR.cpu().numpy(), lnr.detach().numpy(), rtol=3e-5, atol=1e-6), C
+        s = sums.cpu().numpy()
+        assert np.allclose(s[0] / n, float(lc), rtol=2e-5) and np.allclose(s[1] / n, float(lb), rtol=2e-5) and np.allclose(s[2] / N, float(lnr.mean()), rtol=2e-5)
+        one = torch.full((1,), 1.0 / n, device='cuda')
+        gc, gb = ho.edl_focal_l1_bwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'],
+                                     one, one, None, 1.0 / N)
+        assert np.allclose(gc.cpu().numpy(), x.grad.numpy(), rtol=1e-3, atol=3e-7), (C, float((gc.cpu() - x.grad).abs().max()))
+        assert np.array_equal(gb.cpu().numpy(), bp.grad.numpy())
+        if A > 1:                                                         # padded bf16 dZ rows: [N / A pixels, pitch]
+            pitch = (A * C + 7) // 8 * 8 + 8
+            g2, _ = ho.edl_focal_l1_bwd(dev['logits'], dev['labels'], dev['label_weights'], dev['bbox_pred'], dev['bbox_targets'], dev['bbox_weights'],
+                                        one, one, None, 1.0 / N, out_bf16=True, A=A, pitch_cls=pitch, pitch_box=A * 4)
+            ref = x.grad.view(N // A, A * C)
+            assert torch.allclose(g2[:, :A * C].float().cpu(), ref, rtol=1e-2, atol=1e-6) and bool((g2[:, A * C:] == 0).all())
+
+
+@pytest.fixture(scope='module')
+def coco_scoring():
+    """Planted-logit head outputs with 80 classes on a 320 x 448 pyramid (level 0: 20 160 anchors > nms_pre) -> HIP scoring pass + oracle."""
+    from aod_meh_hua_amd import scoring
+    from aod_meh_hua_amd.core.anchor import AnchorGenerator
+    from aod_meh_hua_amd.core.bbox import DeltaXYWHBBoxCoder
+
+    class Head:
+        last_activation, cls_out_channels, num_anchors = 'relu', NC, 9
+        bbox_coder = DeltaXYWHBBoxCoder()
+    B, H, W = 2, 320, 448
+    cls_p, reg_p, L_p = synth.planted_heads(B, H, W, C=NC, seed=44, n_plant=4)
+    mt = synth.metas(B, H, W, scale=0.8)
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    sizes = [tuple(c.shape[-2:]) for c in cls_p]
+    anchors = ag.grid_anchors(sizes, 'cuda')
+    cfg = Cfg(nms_pre=1000, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+    ids = torch.tensor([7, 1234567], device='cuda')
+    det, unc, it = scoring.score_batch(Head(), [c.cuda() for c in cls_p], [r.cuda() for r in reg_p], anchors, [m['img_shape'] for m in mt],
+                                       [m['scale_factor'] for m in mt], cfg, rescale=True, with_nms=True, isUnc='Epistemic', uPool='Entropy_NMS',
+                                       uPool2='objectSum_scaleMax_classSum', isEval=False, L_scores=[l.cuda() for l in L_p],
+                                       _return_internals=True, image_ids=ids)
+    torch.cuda.synchronize()
+    o = omodel.score_images(None, torch.zeros(B, 3, H, W), [m['img_shape'] for m in mt], [m['scale_factor'] for m in mt], sampler='philox',
+                            seed=20, heads=(cls_p, reg_p, L_p), image_ids=[7, 1234567], num_classes=NC)
+    return dict(unc=unc, it=it, o=o, scoring=scoring, sizes=sizes, ids=ids)
+
+
+def test_80class_scoring_indices_exact_vs_oracle(coco_scoring):
+    it, o = coco_scoring['it'], coco_scoring['o']
+    cand = it['cand']
+    A = [h * w * 9 for h, w in coco_scoring['sizes']]
+    ks = [min(a, 1000) for a in A]
+    assert cand.level_start == [0] + list(np.cumsum(ks))
+    for l in range(5):
+        if cand.topk_idx[l] is not None:
+            assert np.array_equal(cand.topk_idx[l].cpu().numpy(), o['pre']['idx'][l].numpy()), l      # exact top-k order
+    assert np.allclose(cand.boxes.cpu().numpy(), o['pre']['cat_boxes'].numpy(), rtol=1e-5, atol=1e-4)
+    assert np.allclose(cand.scores.cpu().numpy(), o['pre']['cat_scores'].numpy(), rtol=1e-5, atol=1e-8)
+    for b in range(2):
+        d, lab, keep = o['dets'][b]
+        n = int(it['num'][b])
+        assert n == len(keep) and n > 5
+        assert np.array_equal(it['keep'][b, :n].cpu().numpy(), keep.numpy())
+        assert np.array_equal(it['labels'][b, :n].cpu().numpy(), lab.numpy())
+        assert int(lab.max()) > 24                                           # classes beyond the 24-wide kernels really occur
+
+
+def test_80class_hua_pairs_values_and_scores_vs_philox_oracle(coco_scoring):
+    sc, it, o = coco_scoring['scoring'], coco_scoring['it'], coco_scoring['o']
+    cand = it['cand']
+    unc, pc, pout = sc.hua_score(cand, it['dets'], it['num'], coco_scoring['ids'], 100, want_pairs=True, seed=20)
+    torch.cuda.synchronize()
+    pc, pout = pc.cpu().tolist(), pout.cpu().numpy()
+    lvl_off = np.array(cand.level_start)
+    for b in range(2):
+        exp = sorted([p for p in o['pairs'] if p['image'] == b], key=lambda p: p['level'])
+        ec = np.concatenate([p['cand'].numpy() + lvl_off[p['level']] for p in exp])
+        eo = np.concatenate([p['obj'].numpy() for p in exp])
+        ee = np.concatenate([p['epi'].numpy() for p in exp])
+        assert pc[b] == len(ec) and pc[b] > 20
+        got = pout[b, :pc[b]]
+        assert np.array_equal(got[:, 0].astype(np.int64), ec) and np.array_equal(got[:, 1].astype(np.int64), eo)
+        err = np.abs(got[:, 3] - ee)
+        assert np.median(err) < 5e-5 and (err < 5e-3).all(), (np.median(err), err.max())
+    assert np.allclose(unc.cpu().numpy(), np.array(o['unc']), rtol=2e-3), (unc, o['unc'])
+    assert torch.equal(coco_scoring['unc'], unc)
+
+
+def test_hua_sampler_81_columns_ragged_quarter_samples():
+    """dirichlet_cols = C + 1 = 81 (SSD-style background column at COCO width): cpl = 21, the last quarter-lane owns 18 columns."""
+    from aod_meh_hua_amd import scoring
+    B, n, C = 2, 64, 80
+    gen = torch.Generator().manual_seed(5)
+    sc = torch.rand(B, n, C + 1, generator=gen) ** 8
+    hot = torch.randint(0, C + 1, (B, n), generator=gen)
+    sc[torch.arange(B)[:, None], torch.arange(n)[None], hot] += 2.0
+    sc = sc / sc.sum(-1, keepdim=True)
+    lam = torch.rand(B, n, generator=gen) * 0.3 + 0.01
+    anchor = torch.arange(n, dtype=torch.int32)[None].repeat(B, 1) * 3 + 11
+    cand = scoring.Candidates(torch.zeros(B, n, 4).cuda(), sc.cuda().contiguous(), lam.cuda(), anchor.cuda(), [0, n], torch.ones(1, B, dtype=torch.int32).cuda(), [None])
+    ids = torch.tensor([3, 99], device='cuda')
+    unc, pc, pout = scoring.hua_score(cand, None, None, ids, 1, (0, 0, 0), want_pairs=True, seed=20, scale_mode=True, dirichlet_cols=C + 1, num_samples=200)
+    torch.cuda.synchronize()
+    pc, pout = pc.cpu().tolist(), pout.cpu().numpy()
+    for b in range(B):
+        fg = (sc[b].max(-1)[0] > 0.3).nonzero()[:, 0]
+        assert pc[b] == len(fg) > 30
+        lhat = lam[b].mean() / (lam[b][fg] + 1e-7) * 25
+        alpha = (sc[b][fg] * lhat[:, None]).numpy()
+        ale, epi = ohua.philox_dirichlet_stats(alpha, int(ids[b]), anchor[b][fg].numpy(), np.zeros(len(fg), np.int64), 20, num_samples=200)
+        got = pout[b, :pc[b]]
+        assert np.array_equal(got[:, 0].astype(np.int64), fg.numpy())
+        err = np.abs(got[:, 3] - epi)
+        assert np.median(err) < 5e-5 and (err < 5e-3).all(), (np.median(err), err.max())
+        assert np.allclose(got[:, 2], ale, rtol=1e-3, atol=1e-4)
