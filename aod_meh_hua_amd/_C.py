@@ -74,6 +74,7 @@ _SIGS = {
     'aod_l2norm_bwd': (C.c_int, [P, P, P, P, P, I64, I32, F32, P]),
     'aod_ssd_loss_fwd': (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P, P]),
     'aod_ssd_loss_bwd': (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, P, P, P, P, P, P]),
+    'aod_synth_normal_images': (C.c_int, [P, I32, I64, U64, P, P]),
     'aod_sgd_multi': (C.c_int, [P, P, P, P, I32, F32, P, F32, F32, I32, F32, P]),
 }
 for _n, (_r, _a) in _SIGS.items():

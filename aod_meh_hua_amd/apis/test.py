@@ -64,13 +64,25 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
     gscore = None
     if plain and os.environ.get('AOD_HIP_GRAPH', '1') != '0' and next(model.parameters()).is_cuda:
         from ..graphs import GraphedScore
-        gscore = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
+        # one captured graph per (model, options): a pool is scored once per AL cycle with a freshly built model, but callers that score
+        # several pools with one model (bench, tests) must not pay the capture again
+        cache = model.__dict__.setdefault('_aod_gscore_cache', {})
+        key = tuple(sorted((k, str(v)) for k, v in kwargs.items()))
+        gscore = cache.get(key)
+        if gscore is None:
+            gscore = cache[key] = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
+    dev = next(model.parameters()).device
+    device_side = hasattr(dataset, 'device_batch')       # images produced on the device (datasets.DevicePhiloxPool): no host collate / H2D
+    all_ids = torch.arange(lo, max(hi, lo), dtype=torch.int64).to(dev) if device_side else None
     for s in range(lo, hi, bs):
         idxs = list(range(s, min(s + bs, hi)))
-        data = collate([dataset[i] for i in idxs])
-        data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
-        dev = next(model.parameters()).device
-        image_ids = torch.tensor(idxs, dtype=torch.int64).to(dev, non_blocking=True)
+        if device_side:
+            image_ids = all_ids[s - lo:s - lo + len(idxs)]
+            data = dataset.device_batch(idxs, dev, image_ids=image_ids)
+        else:
+            data = collate([dataset[i] for i in idxs])
+            data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
+            image_ids = torch.tensor(idxs, dtype=torch.int64).to(dev, non_blocking=True)
         out = None
         if gscore is not None and isinstance(data['img'], (list, tuple)) and len(data['img']) == 1:
             out = gscore.maybe(data['img'][0], data['img_metas'][0], image_ids)

@@ -43,3 +43,20 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Philox4x32-10 (Salmon et al. 2011), the counter-based RNG of the HUA sampler and of the synthetic pool images; restated in numpy in
+// oracle/hua.py (known-answer test: tests/test_oracle_golden.py::test_philox_known_answer)
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* r) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
+    const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-08f; }
+

@@ -356,3 +356,34 @@ extern "C" int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, voi
   AOD_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- synthetic pool images (bench harness)
+// img[b] ~ N(0, 1) elementwise, generated ON the device from Philox4x32-10 keyed by (seed, global image id, element / 4): a pool image is a
+// pure function of its id, so any sharding of the pool over ranks / batches scores the same images.  One Philox block -> two Box-Muller
+// pairs -> four consecutive elements (16-B store).
+__global__ __launch_bounds__(256) void synth_normal_kernel(float* __restrict__ dst, long long per_img4, unsigned k0, unsigned k1,
+                                                           const long long* __restrict__ ids) {
+  const int b = blockIdx.y;
+  const unsigned id_lo = (unsigned)ids[b], id_hi = (unsigned)((unsigned long long)ids[b] >> 32);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_img4; i += (long long)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), id_lo, id_hi, k0, k1, r);
+    const float ra = __builtin_amdgcn_sqrtf(-2.f * 0.693147180559945309f * __builtin_amdgcn_logf(u01(r[0])));
+    const float rb = __builtin_amdgcn_sqrtf(-2.f * 0.693147180559945309f * __builtin_amdgcn_logf(u01(r[2])));
+    f32x4 v;
+    v[0] = ra * __builtin_amdgcn_cosf(u01(r[1])); v[1] = ra * __builtin_amdgcn_sinf(u01(r[1]));
+    v[2] = rb * __builtin_amdgcn_cosf(u01(r[3])); v[3] = rb * __builtin_amdgcn_sinf(u01(r[3]));
+    *reinterpret_cast<f32x4*>(dst + ((long long)b * per_img4 + i) * 4) = v;
+  }
+}
+
+extern "C" int aod_synth_normal_images(float* dst, int B, int64_t elems_per_image, uint64_t seed, const int64_t* image_ids, aod_stream_t stream) {
+  if (B == 0) return 0;
+  AOD_CHECK_ARG(dst && image_ids && B > 0 && elems_per_image > 0 && elems_per_image % 4 == 0, "synth_normal_images: elems_per_image must be a positive multiple of 4");
+  const long long n4 = elems_per_image / 4;
+  const int gx = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(synth_normal_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, dst, n4, (unsigned)(seed & 0xffffffffull),
+                     (unsigned)(seed >> 32), (const long long*)image_ids);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

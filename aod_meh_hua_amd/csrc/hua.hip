@@ -167,20 +167,6 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 + samplers (mirrors oracle/hua.py)
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* r) {
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
-    const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
-    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
-}
-__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-08f; }
-
 // hardware transcendentals (v_log_f32 = log2, v_exp_f32 = exp2, v_sin/v_cos take REVOLUTIONS, v_rcp / v_sqrt): the sampler is bound by
 // vector-ALU issue, and the libm forms (range reduction, denormal fix-ups) tripled its instruction count.  Arguments here are normal
 // floats in (0, 1] or O(1); the numpy restatement (oracle/hua.py) uses exact float32 functions and agrees to ~1e-6 per variate.
@@ -234,7 +220,7 @@ __device__ __forceinline__ float slot_sum(float v) {     // over the 64 / LPP la
 template <int CPL, int LPP, bool EXACT>
 __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
   constexpr int SPR = 64 / LPP;                      // samples per wave round
-  constexpr bool ALIGNED = LPP == 1 || (CPL % 4) == 0;
+  constexpr bool ALIGNED = LPP == 1 || (EXACT && (CPL % 4) == 0);      // a lane's first class is a multiple of four
   __shared__ float s_red[4][HMAXC + 2];
   __shared__ float s_tot[2];
   const int b = blockIdx.y;

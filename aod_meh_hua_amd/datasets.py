@@ -62,6 +62,47 @@ class SyntheticVOCDataset(Dataset):
 
 
 @DATASETS.register_module()
+class DevicePhiloxPool(Dataset):
+    """Unlabeled pool whose images are generated ON the device ('pool of 10 000 synthetic 512^2 images generated on-device
+    from Philox(seed=20, image_id)'): image i is a pure function of (seed, i), so any sharding over ranks / batches scores the same pool.
+    `device_batch(idxs, device)` is the hook apis/test.py single_gpu_uncertainty uses instead of host collate + H2D copy; `__getitem__`
+    gives the same image on the host for small cross-checks."""
+    CLASSES = VOC_CLASSES
+
+    def __init__(self, num_images=10000, size=(512, 512), seed=20, **kw):
+        self.num_images, self.size, self.seed = int(num_images), tuple(size), int(seed)
+        self.flag = np.zeros(self.num_images, dtype=np.uint8)
+        self._buf = {}
+
+    def __len__(self):
+        return self.num_images
+
+    def _meta(self, idx):
+        H, W = self.size
+        return dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3), scale_factor=np.ones(4, np.float32), flip=False,
+                    flip_direction=None, filename=f'philox_{idx}', ori_filename=f'philox_{idx}', image_id=idx)
+
+    def device_batch(self, idxs, device, image_ids=None):
+        """-> dict(img=[tensor [B,3,H,W] on device], img_metas=[list of dicts]).  The image tensor is a per-batch-size static buffer (it is
+        copied into the scoring graph's input buffer by the caller), filled by one kernel launch."""
+        from . import _C
+        H, W = self.size
+        B = len(idxs)
+        key = (B, str(device))
+        if key not in self._buf:
+            self._buf[key] = torch.empty(B, 3, H, W, device=device)
+        img = self._buf[key]
+        ids = image_ids if image_ids is not None else torch.tensor(list(idxs), dtype=torch.int64).to(device, non_blocking=True)
+        _C.call('aod_synth_normal_images', _C.ptr(img), B, 3 * H * W, self.seed, _C.ptr(ids), _C.stream())
+        return dict(img=[img], img_metas=[[self._meta(int(i)) for i in idxs]])
+
+    def __getitem__(self, i):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        d = self.device_batch([int(i)], dev)
+        return dict(img=d['img'][0][0].cpu(), img_metas=d['img_metas'][0][0])
+
+
+@DATASETS.register_module()
 class RepeatDataset(Dataset):
     """mmdet/datasets/dataset_wrappers.py:128-170."""
 

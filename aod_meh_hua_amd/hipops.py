@@ -41,6 +41,20 @@ def _prof(kind, desc, fn, alg=None):
     return r
 
 
+BYTES_PROFILE = None     # bench.py: (kernel name, algorithmic bytes, start_event, end_event) for the HBM-bound row kernels
+
+
+def prof_bytes(name, nbytes, fn):
+    if BYTES_PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    BYTES_PROFILE.append((name, float(nbytes), e0, e1))
+    return r
+
+
 @dataclass(frozen=True)
 class Seg:
     B: int
@@ -270,8 +284,10 @@ def edl_focal_l1_fwd(cls, labels, label_w, bbox_pred=None, bbox_tgt=None, bbox_w
     if sums is None:
         sums = zeros_f32(3, cls.device)
     part = torch.empty(max(int(_C.lib.aod_loss_partials_len(rows)), 1), dtype=torch.float32, device=cls.device)
-    call('aod_edl_focal_l1_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
-         gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream())
+    # algorithmic bytes per anchor row: logits + label (int64) + label weight + 3 box vectors in, loss_noR out
+    prof_bytes('edl_l1_fwd', rows * (Cc * 4 + 8 + 4 + (48 if bbox_pred is not None else 0) + 4),
+               lambda: call('aod_edl_focal_l1_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
+                            gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream()))
     return loss_noR, sums
 
 
@@ -287,9 +303,11 @@ def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g
         grad_cls = alloc(pitch_cls, A * Cc)
     if grad_bbox is None and bbox_pred is not None:
         grad_bbox = alloc(pitch_box, A * 4)
-    call('aod_edl_focal_l1_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
-         gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
-         pitch_cls, pitch_box, stream())
+    esz = 2 if out_bf16 else 4
+    prof_bytes('edl_l1_bwd', rows * (Cc * 4 + 8 + 4 + (4 if g_noR is not None else 0) + Cc * esz + ((48 + 4 * esz) if bbox_pred is not None else 0)),
+               lambda: call('aod_edl_focal_l1_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
+                            gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
+                            pitch_cls, pitch_box, stream()))
     return grad_cls, grad_bbox
 
 

@@ -67,9 +67,12 @@ class FusedSGD(torch.optim.Optimizer):
             return
         arr = C.c_void_p * n
         ent = self._lr_dev.get(self._gi)
-        call('aod_sgd_multi', arr(*ps), arr(*gs), arr(*ms), (C.c_int64 * n)(*ns), n, float(group['lr']),
-             C.c_void_p(ent[0].data_ptr()) if ent is not None else None, float(group['momentum']),
-             float(group['weight_decay']), int(bool(first)), float(self.grad_scale), stream())
+        from .hipops import prof_bytes
+        # algorithmic bytes: p, g, m read + p, m written = 20 B per parameter (16 on the first step: no momentum read)
+        prof_bytes('sgd_multi', sum(ns) * (16 if first else 20),
+                   lambda: call('aod_sgd_multi', arr(*ps), arr(*gs), arr(*ms), (C.c_int64 * n)(*ns), n, float(group['lr']),
+                                C.c_void_p(ent[0].data_ptr()) if ent is not None else None, float(group['momentum']),
+                                float(group['weight_decay']), int(bool(first)), float(self.grad_scale), stream()))
 
 
 def build_optimizer(model, cfg):

@@ -92,7 +92,9 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     level_start, idxs, rowmaxes = [0], [], []
     for l in range(L):
         rowmax = torch.empty(B, A[l], device=dev)
-        call('aod_softmax_rowmax', ptr(cls[l]), B, A[l], C_, fg_thr, ptr(rowmax), ptr(any_fg[l]), int(has_bg), stream())
+        from .hipops import prof_bytes
+        prof_bytes('softmax_rowmax', B * A[l] * (C_ * 4 + 4),
+                   lambda: call('aod_softmax_rowmax', ptr(cls[l]), B, A[l], C_, fg_thr, ptr(rowmax), ptr(any_fg[l]), int(has_bg), stream()))
         idx = None
         if ks[l] < A[l]:
             idx = torch.empty(B, ks[l], dtype=torch.int32, device=dev)

@@ -254,6 +254,12 @@ int aod_ssd_loss_bwd(const float* cls, const int64_t* labels, const float* label
                      const float* bbox_w, const float* ce, const uint32_t* sel4, int B, int A, int C1, int num_classes, float beta,
                      const float* g_cls, const float* g_box, const float* g_noR, float* grad_cls, float* grad_box, aod_stream_t stream);
 
+/* ------------------------------------------------------------------ synthetic pool (bench harness; nothing to replace in the reference:
+ * its pool is VOC images from disk, tools/train_RetinaNet.py:221-225).  dst [B, elems_per_image] fp32 ~ N(0,1), a pure function of
+ * (seed, image_ids[b], element index): Philox4x32-10 keyed like the HUA sampler, so a sharded pool scores the same
+ * images for any world size.  elems_per_image % 4 == 0. */
+int aod_synth_normal_images(float* dst, int B, int64_t elems_per_image, uint64_t seed, const int64_t* image_ids, aod_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer (K16)
  * torch.optim.SGD semantics (apis/train_Lambda.py:54,59-61): d = g*grad_scale + wd*p; buf = first ? d : mom*buf + d;
  * p -= lr*buf, over HOST arrays of device pointers (params/grads/momentum buffers, fp32) and element counts.

@@ -23,13 +23,14 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     alphas = softmax; scores = alphas / (sum(alphas) + 1e-20 + 1e-9); per-level top-k of
     row max; gather; decode (clip to img_shape); cat; /scale_factor; append bg column."""
     B = mlvl_cls[0].shape[0]
-    out = dict(boxes=[], scores=[], alphas=[], lam=[], idx=[], level_any_fg=[])
+    out = dict(boxes=[], scores=[], alphas=[], lam=[], idx=[], level_any_fg=[], rowmax=[])
     for cls, reg, lam, anchors in zip(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors):
         alphas = cls.softmax(dim=2)
         S = alphas.sum(dim=2, keepdim=True) + 1e-20
         scores = alphas / (S + 1e-9)
         # Lambda_L2.py:497-501 level gate uses the un-normalised softmax max over ALL anchors
         out['level_any_fg'].append((alphas.max(dim=2)[0] > 0.3).any(dim=1))
+        out['rowmax'].append(scores.max(-1)[0])            # every anchor of the level, before top-k
         A = cls.shape[1]
         anc = anchors[None].expand(B, A, 4)
         idx = torch.arange(A)[None].expand(B, A)
