@@ -260,11 +260,21 @@ class ConvFn(Function):
         x_segs = ctx.x_segs
         if need_w or need_bn:
             dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'], alg=(I, O))
+            # data parallelism (parallel.GradSync.attach): the weight gradient is unpacked straight into this parameter's slice of the
+            # flat all-reduce buffer; autograd installs the returned slice as .grad, so the all-reduce runs in place.  A second use of the
+            # same weight inside one backward pass gets a fresh tensor (autograd then adds it into the slice).
+            dst = getattr(w, '_aod_grad_view', None) if need_w else None
+            if dst is not None and (w.__dict__.get('_aod_view_busy') or dst.device != dw.device
+                                    or (w.grad is not None and w.grad.data_ptr() == dst.data_ptr())):
+                dst = None          # (.grad already IS the slice and was not reset to None: autograd will add into it)
+            if dst is not None:
+                w._aod_view_busy = True
+                dst = dst.detach()  # a tensor object of its own on the same memory: autograd installs it as .grad without a copy
             if need_bn:
-                gw, ggamma = ho.unpack_wgrad(dw, O, I, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
+                gw, ggamma = ho.unpack_wgrad(dw, O, I, grad_oihw=dst, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
                 gbeta = s1
             else:
-                gw = ho.unpack_wgrad(dw, O, I, scale=scale if ctx.has_bn else None)
+                gw = ho.unpack_wgrad(dw, O, I, grad_oihw=dst, scale=scale if ctx.has_bn else None)
             if not need_w:
                 gw = None
         gxs = [None] * ctx.nx

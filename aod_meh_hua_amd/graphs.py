@@ -47,11 +47,21 @@ def _plain(data, dev):
 
 
 class GraphedTrainStep:
+    """Capture-once / replay of run_iter.  Captured graphs are cached per input signature (a few shapes alternate with aspect-ratio
+    grouped VOC batches).  Building a graph needs eager warm-up iterations (allocator pools, row tables, parameter-preparation
+    registration): parameters, momentum buffers and BN buffers are snapshotted before and restored after, so the batch that triggers a
+    capture is applied exactly ONCE (by the first replay), like every other batch.  Under data parallelism the capture-or-eager decision
+    is collective (every rank must issue the same sequence of all-reduces), gradients live in the static slices of GradSync's flat buffer
+    and the all-reduces run eagerly between the captured segments."""
+    MAX_GRAPHS = 4
+
     def __init__(self, model, optimizer, optimizer_L, grad_sync=None, gmax=64, warmup=2, **step_kwargs):
         self.model, self.module = model, _unwrap(model)
         self.opt, self.opt_L, self.sync = optimizer, optimizer_L, grad_sync
         self.gmax, self.warmup, self.kw = gmax, warmup, step_kwargs
-        self.sig, self.graphs, self.static = None, None, None
+        self.cache = {}                   # signature -> dict(graphs, static, live, live_L, keep, src, src_L), insertion order = LRU
+        self.cur = None
+        self.last_sig = None              # signature of the previous call to maybe()
         self.dev = next(self.module.parameters()).device
 
     # ------------------------------------------------------------------ input staging
@@ -59,7 +69,7 @@ class GraphedTrainStep:
         return (tuple(d['img'].shape), tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in d['img_metas']))
 
     def _load(self, d):
-        st = self.static
+        st = self.cur['static']
         st['img'].copy_(d['img'], non_blocking=True)
         B, G = st['gts'].shape[:2]
         # fresh pinned staging every call: the copies below are asynchronous, and torch's caching host allocator only recycles a pinned
@@ -78,27 +88,27 @@ class GraphedTrainStep:
 
     def _alloc(self, d):
         B, dev, G = d['img'].shape[0], self.dev, self.gmax
-        self.static = dict(img=torch.empty(tuple(d['img'].shape), dtype=torch.float32, device=dev),
-                           gts=torch.zeros(B, G, 4, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
-                           labs=torch.zeros(B, G, dtype=torch.long, device=dev), metas=[dict(m) for m in d['img_metas']])
+        return dict(img=torch.empty(tuple(d['img'].shape), dtype=torch.float32, device=dev),
+                    gts=torch.zeros(B, G, 4, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
+                    labs=torch.zeros(B, G, dtype=torch.long, device=dev), metas=[dict(m) for m in d['img_metas']])
 
-    # ------------------------------------------------------------------ the three segments of run_iter
+    # ------------------------------------------------------------------ the four segments of run_iter
     def _seg_a(self):
-        st = self.static
+        st = self.cur['static']
         data = dict(img=st['img'], img_metas=st['metas'], gt_bboxes=PackedGT((st['gts'], st['counts'], st['labs'])), gt_labels=None)
         out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
         self.opt.zero_grad()
         out['loss'].backward()
-        self.live = (out, head_out, feat_out, prev)
+        self.cur['live'] = (out, head_out, feat_out, prev)
 
     def _seg_b(self):
         # the MEH step only reads detached features / losses and its own parameters, so the main update (segment C) may follow it:
         # with data parallelism the main gradients' all-reduce then runs under this whole segment
-        out, head_out, feat_out, prev = self.live
+        out, head_out, feat_out, prev = self.cur['live']
         loss_L = self.module.train_step_L(prev, head_out, feat_out, **self.kw)
         self.opt_L.zero_grad()
         loss_L['loss'].backward()
-        self.live_L = loss_L
+        self.cur['live_L'] = loss_L
 
     def _seg_c(self):
         self.opt.step()
@@ -109,29 +119,71 @@ class GraphedTrainStep:
     def _params(self, opt):
         return [p for g in opt.param_groups for p in g['params']]
 
-    def _between(self, i):
-        """Eager communication between segment i and i+1 (data parallelism only)."""
+    def _between(self, i, capturing=False):
+        """Communication between segment i and i+1 (data parallelism only).  While CAPTURING nothing is sent: only the hand-over the
+        later segments' captured pointers depend on happens (.grad -> the slices of the flat buffer the reduced values arrive in)."""
         if self.sync is None:
             return
+        cur = self.cur
+        if capturing:
+            if i == 0:
+                cur['src'] = [p.grad for p in self._params(self.opt)]           # what segment A's captured kernels write
+            elif i == 1:
+                cur['src_L'] = [p.grad for p in self._params(self.opt_L)]
+                for opt in (self.opt, self.opt_L):                              # segments C / D read the reduced slices
+                    ent = self.sync.attach(self._params(opt))
+                    for p, v in zip(ent['params'], ent['views']):
+                        if p.grad is not None:
+                            p.grad = v
+            return
         if i == 0:
-            self.pending = self.sync.start(self._params(self.opt))         # overlaps segment B
+            self.inflight = self.sync.start(self._params(self.opt), sources=cur.get('src'))         # overlaps segment B
         elif i == 1:
-            self.pending.wait()
+            self.inflight.wait()
         elif i == 2:
-            self.sync.all_reduce_grads(self._params(self.opt_L))
+            self.sync.start(self._params(self.opt_L), sources=cur.get('src_L')).wait()
 
     def _run_eager(self):
         for i, f in enumerate((self._seg_a, self._seg_b, self._seg_c, self._seg_d)):
             f()
             self._between(i)
 
+    # ------------------------------------------------------------------ state snapshot around warm-up
+    def _snapshot(self):
+        ps = self._params(self.opt) + self._params(self.opt_L)
+        snap = dict(p=[p.detach().clone() for p in ps], m=[], b=[b.detach().clone() for b in self.module.buffers()])
+        for opt in (self.opt, self.opt_L):
+            for p in self._params(opt):
+                mb = opt.state.get(p, {}).get('momentum_buffer')
+                snap['m'].append(None if mb is None else mb.detach().clone())
+        return snap
+
+    def _restore(self, snap):
+        ps = self._params(self.opt) + self._params(self.opt_L)
+        with torch.no_grad():
+            torch._foreach_copy_(ps, snap['p'])
+            for b, v in zip(self.module.buffers(), snap['b']):
+                b.copy_(v)
+            i = 0
+            for opt in (self.opt, self.opt_L):
+                for p in self._params(opt):
+                    mb = opt.state.get(p, {}).get('momentum_buffer')
+                    if mb is not None:
+                        # a buffer that did not exist before warm-up restarts from zero: buf = m * 0 + d == the first-step rule buf = d
+                        mb.zero_() if snap['m'][i] is None else mb.copy_(snap['m'][i])
+                    i += 1
+        torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+
     def _build(self, d):
         from .parallel import is_dist
-        self.live = self.live_L = None
-        self._alloc(d)
+        dist_mode = self.sync is not None and is_dist()
+        if dist_mode:                      # gradients must land in the flat buffer's slices from the first captured backward on
+            self.sync.attach(self._params(self.opt)), self.sync.attach(self._params(self.opt_L))
+        self.cur = dict(static=self._alloc(d), live=None, live_L=None)
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
         self.module.train()
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -144,52 +196,69 @@ class GraphedTrainStep:
         # itself must not contain the refresh, or its position would depend on which layers happened to be stale at capture time
         AF.PREP.refresh_if_stale()
         segs = [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
-        self.graphs = []
-        if self.sync is None or not is_dist():
+        graphs = []
+        if not dist_mode:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):      # other threads (RCCL watchdog) may touch the runtime
                 for f in segs:
                     f()
-            self.graphs.append(g)
+            graphs.append(g)
         else:
             pool = torch.cuda.graph_pool_handle()
-            for f in segs:
+            for i, f in enumerate(segs):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                     f()
-                self.graphs.append(g)
+                graphs.append(g)
+                self._between(i, capturing=True)
         ho.reset_zero_arena()
-        self._keep = _pin_caches()
-        self.touched = self._params(self.opt) + self._params(self.opt_L)
+        self._restore(snap)                       # warm-up iterations were real updates: undo them, the first replay applies this batch
+        AF.PREP.refresh_if_stale()
+        self.cur.update(graphs=graphs, keep=_pin_caches(), touched=self._params(self.opt) + self._params(self.opt_L))
+        return self.cur
 
     # ------------------------------------------------------------------ call
+    def _agree(self, want):
+        """Data parallelism: replay / capture only when EVERY rank wants to (ranks see different batch shapes with keep-ratio VOC data;
+        a rank that captured while its peers ran eagerly would issue a different number of all-reduces)."""
+        from .parallel import is_dist
+        if self.sync is None or not is_dist():
+            return want
+        import torch.distributed as dist
+        t = torch.tensor([int(want)], device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t))
+
     def maybe(self, data_batch):
-        """Replay when this input shape was also the previous call's shape (capture on its second consecutive appearance); otherwise
-        return None and let the caller run the iteration eagerly (multi-scale data would re-capture on every batch)."""
+        """Replay when this input shape is cached, capture when it was also the previous call's shape (second consecutive appearance);
+        otherwise return None and let the caller run the iteration eagerly (multi-scale data would re-capture on every batch)."""
         d = _plain(data_batch, self.dev)
         sig = self._signature(d)
-        if sig != self.sig and sig != getattr(self, 'pending', None):
-            self.pending = sig
+        want = sig in self.cache or sig == self.last_sig
+        self.last_sig = sig
+        if not self._agree(want):
             return None
         return self(data_batch)
 
     def __call__(self, data_batch):
         d = _plain(data_batch, self.dev)
         sig = self._signature(d)
-        if sig != self.sig:
-            self.graphs = None
-            self._build(d)
-            self.sig = sig
+        ent = self.cache.pop(sig, None)
+        if ent is None:
+            if len(self.cache) >= self.MAX_GRAPHS:
+                self.cache.pop(next(iter(self.cache)))          # least recently used
+            ent = self._build(d)
+        self.cache[sig] = self.cur = ent
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
         AF.PREP.refresh_if_stale()
-        for i, g in enumerate(self.graphs):
+        for i, g in enumerate(ent['graphs']):
             g.replay()
-            if len(self.graphs) > 1:
+            if len(ent['graphs']) > 1:
                 self._between(i)
-        tp = [p for p in self.touched if p.grad is not None]
+        tp = [p for p in ent['touched'] if p.grad is not None]
         torch._C._autograd._unsafe_set_version_counter(tp, [p._version + 1 for p in tp])
-        out, loss_L = self.live[0], self.live_L
+        out, loss_L = ent['live'][0], ent['live_L']
         log_vars = type(out['log_vars'])((k, v.clone()) for k, v in out['log_vars'].items())     # static tensors: hand out copies
         log_vars.update((k, v.clone()) for k, v in loss_L['log_vars'].items())
         return dict(loss=out['loss'].detach().clone(), log_vars=log_vars, num_samples=out['num_samples'])

@@ -3,9 +3,9 @@ in the CPU tests).  The reference has no working multi-GPU training path (it wra
 apis/train_Lambda.py:53, and scores the pool with dist=False, tools/train_RetinaNet.py:224-225); SURVEY 8(e)
 defines what is built here:
 
-  * GradSync      -- mean of per-rank gradients: parameters' grads are packed into a few large flat fp32
-                     buckets (sized for xGMI's per-link-bound rings: few, large collectives), all-reduced,
-                     and unpacked; called once after each of the two backward passes of run_iter.
+  * GradSync      -- mean of per-rank gradients: each optimizer's gradients live in ONE persistent flat fp32
+                     buffer (parameters' .grad are slices of it), all-reduced in place in a few large buckets
+                     (sized for xGMI's per-link-bound rings); called once after each of the two backward passes.
   * shard_range   -- contiguous block of the unlabeled pool for this rank, [r*ceil(N/W), (r+1)*ceil(N/W)).
   * gather_scores -- all-gather of the per-rank fp32 score blocks (+ trim of the padding).
   * broadcast_model -- rank-0 weights to everybody after each cycle's re-init (tools/train_RetinaNet.py:156-157).
@@ -27,48 +27,103 @@ def get_dist_info():
 
 
 class _PendingSync:
-    """In-flight bucketed all-reduce: wait() finishes the collectives and scatters the averaged buckets back into the gradients."""
+    """In-flight bucketed all-reduce of one flat gradient buffer: wait() finishes the collectives, turns the sums into means and makes
+    every parameter's .grad the averaged slice of the flat buffer (a re-pointing, not a copy)."""
 
-    def __init__(self, buckets, world):
-        self.buckets, self.world = buckets, world
+    def __init__(self, ent, works, world, avg_done):
+        self.ent, self.works, self.world, self.avg_done = ent, works, world, avg_done
 
     def wait(self):
-        for grads, flat, work in self.buckets:
-            if work is not None:
-                work.wait()
-            flat.div_(self.world)
-            parts = [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)]
-            if hasattr(torch, '_foreach_copy_'):
-                torch._foreach_copy_(grads, parts)          # one batched launch instead of one copy per parameter
-            else:
-                for g, v in zip(grads, parts):
-                    g.copy_(v)
-        self.buckets = []
+        if self.ent is None:
+            return
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if not self.avg_done and self.world > 1:
+            self.ent['flat'].mul_(1.0 / self.world)
+        for p, v in zip(self.ent['params'], self.ent['views']):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+        self.ent = None
 
 
 class GradSync:
+    """Mean of per-rank gradients over RCCL.  Each parameter list (one per optimizer) owns ONE persistent flat fp32 buffer; every
+    parameter's gradient is a slice of it (`p._aod_grad_view`).  The conv backward writes weight gradients straight into the slice
+    (functional.ConvFn), so for 99.8 % of the bytes .grad IS the slice and the all-reduce runs in place: no torch.cat, no copy back
+    (round 1 moved ~3 x 146 MB per iteration for that).  The few small vectors autograd hands over in their own tensors (BN gamma / beta,
+    biases: ~60 K floats) are copied into their slices by one batched launch.  The buffer is reduced in a few large buckets -- xGMI rings
+    are per-link bound -- issued in REVERSE parameter order: the order in which a backward pass finishes them (`bucket_ready` hooks use
+    that to start a bucket's all-reduce while the rest of the backward is still running)."""
+
+    ALIGN = 64          # elements: every slice starts on a 256-B boundary (vector stores of the unpack kernel)
+
     def __init__(self, bucket_mb=64):
         self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self._ents = {}
 
-    def start(self, params):
-        """Launch the bucketed all-reduce of the parameters' gradients WITHOUT waiting (RCCL runs it on its own stream; xGMI rings are
-        per-link bound, so a few large buckets).  Returns a handle whose wait() must be called before the gradients are read.  The
-        runner overlaps the main network's all-reduce with the whole MEH forward/backward (disjoint parameters)."""
+    def attach(self, params):
+        params = [p for p in params if p.requires_grad]
+        key = tuple(id(p) for p in params)
+        ent = self._ents.get(key)
+        if ent is not None and all(r() is p for r, p in zip(ent['refs'], params)):
+            return ent
+        import weakref
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        flat = torch.zeros(max(n, 1), dtype=torch.float32, device=params[0].device)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+        for p, v in zip(params, views):
+            p._aod_grad_view = v
+        # buckets = contiguous element ranges, cut at parameter boundaries, walking the parameters backwards
+        buckets, hi, i = [], n, len(params) - 1
+        while i >= 0:
+            lo = hi
+            first = i
+            while i >= 0 and (lo == hi or hi - offs[i] <= self.bucket_elems):
+                lo = offs[i]
+                i -= 1
+            buckets.append(dict(lo=lo, hi=hi, first_param=i + 1, last_param=first))
+            hi = lo
+        ent = dict(flat=flat, views=views, params=params, refs=[weakref.ref(p) for p in params], offs=offs, buckets=buckets)
+        self._ents[key] = ent
+        return ent
+
+    def _gather_small(self, ent, sources=None):
+        """Copy the gradients that do not already live in their slices into them (one batched launch); zero the slices of parameters
+        without a gradient this iteration."""
+        srcs, dsts = [], []
+        for i, (p, v) in enumerate(zip(ent['params'], ent['views'])):
+            g = sources[i] if sources is not None else p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                srcs.append(g.reshape(v.shape) if g.dtype == torch.float32 else g.reshape(v.shape).float())
+                dsts.append(v)
+            p.__dict__.pop('_aod_view_busy', None)
+        if srcs:
+            if hasattr(torch, '_foreach_copy_'):
+                torch._foreach_copy_(dsts, srcs)
+            else:
+                for d, s_ in zip(dsts, srcs):
+                    d.copy_(s_)
+
+    def start(self, params, sources=None):
+        """Launch the bucketed all-reduce of the parameters' gradients WITHOUT waiting (RCCL runs it on its own stream).  Returns a
+        handle whose wait() must be called before the gradients are read.  `sources`: gradient tensors to read instead of p.grad (the
+        static tensors a captured HIP graph writes, graphs.GraphedTrainStep).  The runner overlaps the main network's all-reduce with the
+        whole MEH forward/backward (disjoint parameters)."""
         if not is_dist():
-            return _PendingSync([], 1)
+            return _PendingSync(None, [], 1, True)
+        ent = self.attach(params)
+        self._gather_small(ent, sources)
         world = dist.get_world_size()
-        grads = [p.grad for p in params if p.grad is not None]
-        buckets, i = [], 0
-        while i < len(grads):
-            j, n = i, 0
-            while j < len(grads) and (n == 0 or n + grads[j].numel() <= self.bucket_elems):
-                n += grads[j].numel()
-                j += 1
-            flat = torch.cat([g.reshape(-1).float() for g in grads[i:j]])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-            buckets.append((grads[i:j], flat, work))
-            i = j
-        return _PendingSync(buckets, world)
+        avg = dist.get_backend() == 'nccl'
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(ent['flat'][b['lo']:b['hi']], op=op, async_op=True) for b in ent['buckets'] if b['hi'] > b['lo']]
+        return _PendingSync(ent, works, world, avg)
 
     def all_reduce_grads(self, params):
         self.start(params).wait()

@@ -462,15 +462,16 @@ def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac):
 def cpu_baseline(args, cd, do_train, do_score):
     """CPU oracle (port of the reference's CPU path, oracle/model.py) on a bounded sample: cells (threads, batch) =
     (2, 2) -- the reference's own torch.set_num_threads(2) and samples_per_gpu=2 (tools/train_RetinaNet.py:77, Config_RetinaNet.py:127) --,
-    (16, 2) and (all host cores capped at 64, B); per cell the training iteration, the scoring forward and the HUA stage (pre-NMS + NMS +
-    ComputeObjUnc on planted, trained-like head outputs so that the stage is not empty) are timed separately.  `value` = the best
-    cell's images/sec through both phases, computed like the GPU line's value."""
+    (16, 2), (all host cores capped at 64, 2) and (16, B); per cell the training iteration, the scoring forward and the HUA stage (pre-NMS +
+    NMS + ComputeObjUnc on planted, trained-like head outputs so that the stage is not empty; timed at batch 2 and scaled by images for the
+    batch-B cell) are timed separately.  `value` = the best cell's images/sec through both phases, computed like the GPU line's value.
+    torch's CPU kernels stop scaling well below the 256 host threads of the GPU box, which is why the all-core cell is not the best one."""
     from oracle import model as om
     from tests import synth
     H, W, depth, nc = cd['H'], cd['W'], cd['depth'], cd['classes']
     budget = max(args.cpu_seconds, 5.0)
     ncpu = os.cpu_count() or 1
-    cells = [(2, 2), (min(16, ncpu), 2), (min(ncpu, 64), min(args.batch or cd['batch'], 16))]
+    cells = [(2, 2), (min(16, ncpu), 2), (min(ncpu, 64), 2), (min(16, ncpu), min(args.batch or cd['batch'], 16))]
     sd = om.seeded_state_dict(depth=depth, num_classes=nc)
     train_keys = [k for k, v in sd.items() if v.is_floating_point() and not any(s in k for s in ('running', 'backbone.conv1.', 'backbone.bn1.', 'layer1.'))]
     for k in train_keys:
@@ -517,18 +518,22 @@ def cpu_baseline(args, cd, do_train, do_score):
                 feats = om.fpn(sd, om.backbone(sd, img, depth))
                 om.head_forward(sd, feats)
                 om.head_forward_L(sd, feats)
-        heads = synth.planted_heads(Bc, H, W, C=nc, seed=22)
+        heads = synth.planted_heads(2, H, W, C=nc, seed=22) if Bc == 2 else None
 
         def hua_it():
             with torch.no_grad():
-                om.score_images(None, torch.zeros(Bc, 3, H, W), sampler='torch', heads=heads, num_classes=nc)
+                om.score_images(None, torch.zeros(2, 3, H, W), sampler='torch', heads=heads, num_classes=nc)
         share = budget / (len(cells) * 3)
         cell = dict(threads=thr, batch=Bc)
         if do_train:
             cell['train_s'] = round(timed(train_it, share), 3)
         if do_score:
             cell['score_forward_s'] = round(timed(fwd_it, share), 3)
-            cell['hua_stage_s'] = round(timed(hua_it, share / 2), 3)
+            if Bc == 2:
+                cell['hua_stage_s'] = round(timed(hua_it, share / 2), 3)
+            else:       # same per-image work: scaled from the batch-2 cell with the same thread count
+                ref = next((c for c in out_cells if c['threads'] == thr and c['batch'] == 2), out_cells[-1])
+                cell['hua_stage_s'], cell['hua_stage_scaled_from_batch_2'] = round(ref['hua_stage_s'] * Bc / 2, 3), True
         tt = cell.get('train_s', 0.0) + cell.get('score_forward_s', 0.0) + cell.get('hua_stage_s', 0.0)
         cell['img_per_s'] = round(Bc * (int(do_train) + int(do_score)) / tt, 3)
         out_cells.append(cell)

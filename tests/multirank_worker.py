@@ -1,0 +1,125 @@
+"""Worker of tests/test_gpu_multirank.py (launched by torch.distributed.run with 2 ranks that share device 0 over gloo -- a 1-GPU box cannot
+host two RCCL ranks; the code path is the product's: GradSync's flat in-place buffers, per-segment HIP graphs, eager all-reduces between).
+
+Three data-parallel iterations, rank r training on its own batches, once through GraphedTrainStep (graph mode) and once eagerly
+(the runner's order of operations); then on rank 0 a ONE-process emulation: gradients of both ranks' batches computed one after the
+other, averaged, one optimizer step.  Checks: replicas bit-equal across ranks; DP == emulation up to fp32 summation order."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import model as omodel      # noqa: E402  (seeded weights only)
+from tests import synth                 # noqa: E402
+
+
+def build():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    from aod_meh_hua_amd.optim import FusedSGD
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    cfg.model.backbone.pop('init_cfg')
+    model = build_detector(cfg.model)
+    model.load_state_dict(omodel.seeded_state_dict(cls_bias=-2.0), strict=True)
+    model = model.cuda().train()
+    head = model.bbox_head
+    meh = set(id(p) for n in ('retina_L', 'L_convs') for p in getattr(head, n).parameters())
+    main = [p for p in model.parameters() if p.requires_grad and id(p) not in meh]
+    opt = FusedSGD(main, lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    opt_L = FusedSGD([p for p in model.parameters() if id(p) in meh], lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    return model, opt, opt_L
+
+
+def batch(step, rank, B=2, H=128):
+    seed = 100 + 10 * step + rank
+    gtb, gtl = synth.random_gts(B, H, H, seed=seed, gmin=1, gmax=3)
+    return dict(img=synth.images(B, H, H, seed=seed).cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=gtb, gt_labels=gtl)
+
+
+def digest(model):
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(v.detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def eager_dp_iter(model, opt, opt_L, gsync, data):
+    """the runner's eager order (utils/Epoch_Based_Runner_Lambda.py run_iter)"""
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    opt.zero_grad()
+    out['loss'].backward()
+    pending = gsync.start(opt.param_groups[0]['params'])
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    opt_L.zero_grad()
+    lossL['loss'].backward()
+    pending.wait()
+    opt.step()
+    gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
+    opt_L.step()
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    from aod_meh_hua_amd.graphs import GraphedTrainStep
+    from aod_meh_hua_amd.parallel import GradSync, broadcast_model
+    res = {}
+    for mode in ('graph', 'eager'):
+        model, opt, opt_L = build()
+        broadcast_model(model)
+        gsync = GradSync(bucket_mb=16)
+        gs = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync, warmup=1, Labeled=True, Pseudo=False) if mode == 'graph' else None
+        for step in range(3):
+            d = batch(step, rank)
+            if gs is not None:
+                gs(d)
+            else:
+                eager_dp_iter(model, opt, opt_L, gsync, d)
+        torch.cuda.synchronize()
+        hs = [None] * world
+        dist.all_gather_object(hs, digest(model))
+        res[mode + '_replicas_equal'] = len(set(hs)) == 1
+        res[mode + '_grad_is_flat_slice'] = all(p.grad is not None and p.grad.data_ptr() == p._aod_grad_view.data_ptr() for p in opt.param_groups[0]['params'])
+        if rank == 0:
+            res[mode] = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    if rank == 0:
+        # one process, both ranks' batches, mean gradient
+        model, opt, opt_L = build()
+        pm, pl = opt.param_groups[0]['params'], opt_L.param_groups[0]['params']
+        for step in range(3):
+            gm, gl = [], []
+            for r in range(world):
+                d = batch(step, r)
+                out, head_out, feat_out, prev = model.train_step(d, Labeled=True, Pseudo=False)
+                opt.zero_grad()
+                out['loss'].backward()
+                gm.append([p.grad.detach().clone() for p in pm])
+                lossL = model.train_step_L(prev, head_out, feat_out)
+                opt_L.zero_grad()
+                lossL['loss'].backward()
+                gl.append([p.grad.detach().clone() for p in pl])
+            for ps, gs_, o in ((pm, gm, opt), (pl, gl, opt_L)):
+                for i, p in enumerate(ps):
+                    p.grad = sum(g[i] for g in gs_) / world
+                o.step()
+        ref = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        for mode in ('graph', 'eager'):
+            worst = max(float((res[mode][k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-12)) for k in ref if ref[k].is_floating_point())
+            res[mode + '_vs_mean_gradient_run'] = worst
+            del res[mode]
+        moved = float((ref['bbox_head.retina_cls.weight'] - omodel.seeded_state_dict(cls_bias=-2.0)['bbox_head.retina_cls.weight']).abs().max())
+        res['moved'] = moved
+        print('MULTIRANK ' + json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -59,17 +59,18 @@ def loss_inputs(N=1024, C=20, seed=21):
                 bbox_weights=bw, lam=lam, num_total_samples=max(int((labels < C).sum()), 1))
 
 
-def planted_heads(B=2, H=128, W=128, C=20, A=9, seed=22, n_plant=6):
+def planted_heads(B=2, H=128, W=128, C=20, A=9, seed=22, n_plant=6, plant_small=True):
     """Planted-logit head outputs (SURVEY 8c 'scoring'): cls = 0.5*N(0,1) with +8.0 on a few
     (anchor, class) 3x3 patches so that some anchors pass 0.3 / NMS finds objects;
-    reg = 0.1*N(0,1); L = U(.01,.31).  Returns NCHW lists like the head does."""
+    reg = 0.1*N(0,1); L = U(.01,.31).  Returns NCHW lists like the head does.  plant_small=False: nothing is planted on levels smaller
+    than 4 x 4 (with n_plant=0 the image then has no confident anchor at all and scores exactly 0)."""
     g = gen(seed)
     cls, reg, Ls = [], [], []
     for s in (8, 16, 32, 64, 128):
         h, w = max(H // s, 1), max(W // s, 1)
         c = 0.5 * torch.randn(B, A * C, h, w, generator=g)
         for b in range(B):
-            for _ in range(n_plant if h >= 4 else (1 if h >= 2 else 0)):
+            for _ in range(n_plant if h >= 4 else (1 if (h >= 2 and plant_small) else 0)):
                 a = int(torch.randint(0, A, (1,), generator=g))
                 k = int(torch.randint(0, C, (1,), generator=g))
                 y = int(torch.randint(0, h, (1,), generator=g))

@@ -58,15 +58,11 @@ def test_graphed_train_step_equals_eager():
         opt.param_groups[0]['lr'] = lr
         ref_losses.append(_eager_iter(model, opt, opt_L, d))
     ref = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    # graphed: capture happens on the first call (its warm-up iterations must not leak into the result, so reload afterwards)
+    # graphed: the capture happens inside the first call; its warm-up iterations are real updates that GraphedTrainStep must undo
+    # (parameters, momentum, BN buffers snapshotted / restored), so the first call applies batch 0 exactly once
     model2, opt2, opt_L2 = _build()
     sd0 = {k: v.detach().clone() for k, v in model2.state_dict().items()}
-    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=1, Labeled=True, Pseudo=False)
-    gs(batches[0])
-    model2.load_state_dict(sd0, strict=True)
-    for st in (opt2.state, opt_L2.state):
-        for s in st.values():
-            s['momentum_buffer'].zero_()      # first replay then behaves like a first step (buf = 0*m + d)
+    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=2, Labeled=True, Pseudo=False)
     got = []
     for d, lr in zip(batches, lrs):
         opt2.param_groups[0]['lr'] = lr
@@ -103,3 +99,33 @@ def test_graphed_score_equals_eager_and_follows_inputs():
         _, unc_g = gsc(img, metas, ids)
         assert torch.equal(torch.as_tensor(unc_e).float().cpu(), unc_g.float().cpu()), (seed, unc_e, unc_g)
     assert gsc.maybe(synth.images(1, 128, 128).cuda(), synth.metas(1, 128, 128), torch.zeros(1, dtype=torch.int64, device='cuda')) is None
+
+
+def test_capture_applies_the_batch_once_and_eager_iterations_may_interleave():
+    """(a) maybe() returns None for a first-seen shape, captures on its second consecutive appearance and from then on replays
+    it from the cache, also after other shapes ran eagerly in between; (b) every path applies exactly one update per batch: the sequence
+    graph / eager / graph equals three eager iterations; (c) an eager iteration between replays (zero_grad(set_to_none) rebinding .grad)
+    does not disturb later replays."""
+    from aod_meh_hua_amd.graphs import GraphedTrainStep
+    seq = [_batch(51), _batch(52), _batch(53, B=1), _batch(54), _batch(55, B=1), _batch(56)]
+    model, opt, opt_L = _build()
+    ref = [_eager_iter(model, opt, opt_L, d) for d in seq]
+    ref_sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    model2, opt2, opt_L2 = _build()
+    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=2, Labeled=True, Pseudo=False)
+    got, how = [], []
+    for d in seq:
+        o = gs.maybe(d)
+        if o is None:
+            how.append('eager')
+            got.append(_eager_iter(model2, opt2, opt_L2, d))
+        else:
+            how.append('graph')
+            got.append((float(o['loss']), float(o['log_vars']['loss_L'])))
+    torch.cuda.synchronize()
+    assert how == ['eager', 'graph', 'eager', 'graph', 'eager', 'graph'], how       # B=2 shape: captured once, replayed from the cache
+    assert len(gs.cache) == 1
+    assert np.allclose(np.array(got), np.array(ref), rtol=3e-3), (got, ref)
+    new = {k: v.detach().float().cpu() for k, v in model2.state_dict().items()}
+    worst = max(float((new[k] - ref_sd[k]).abs().max() / (ref_sd[k].abs().max() + 1e-12)) for k in ref_sd if ref_sd[k].is_floating_point())
+    assert worst < 5e-3, worst

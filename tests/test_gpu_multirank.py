@@ -23,3 +23,20 @@ def test_two_rank_bench_on_one_gpu():
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert out['config']['launch'] == 'hip-graph replay' and out['roofline'] is not None
+
+
+def test_two_rank_replicas_stay_equal_and_match_a_mean_gradient_run():
+    """after 3 data-parallel iterations rank 0 and rank 1 hold bit-equal parameters (graph mode and eager mode), .grad
+    is the slice of GradSync's flat buffer (all-reduce in place), and the result equals a 1-process run fed the mean gradient."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(ROOT, 'tests', 'multirank_worker.py')]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('MULTIRANK ')][-1]
+    out = json.loads(line[len('MULTIRANK '):])
+    assert out['graph_replicas_equal'] and out['eager_replicas_equal'], out
+    assert out['graph_grad_is_flat_slice'] and out['eager_grad_is_flat_slice'], out
+    assert out['moved'] > 0
+    # fp32 atomics in wgrad / column sums make single runs differ in the last bits; three small SGD steps stay within 1e-4 relative
+    assert out['graph_vs_mean_gradient_run'] < 1e-3 and out['eager_vs_mean_gradient_run'] < 1e-3, out
