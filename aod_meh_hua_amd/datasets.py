@@ -350,6 +350,53 @@ class GroupSampler(torch.utils.data.Sampler):
         return self.num_samples
 
 
+class DistributedGroupSampler(torch.utils.data.Sampler):
+    """mmdet/datasets/samplers/group_sampler.py:53-148: per epoch (seed + epoch) every aspect-ratio group is shuffled and padded to a
+    multiple of samples_per_gpu * world, whole batches are shuffled, and rank r takes the r-th contiguous share -- so a batch never mixes
+    portrait and landscape images and every rank draws a different, epoch-dependent share.  `set_epoch` is called by the runner at the
+    start of every training epoch (mmcv's DistSamplerSeedHook)."""
+
+    def __init__(self, dataset, samples_per_gpu=1, num_replicas=None, rank=None, seed=0):
+        import math
+        import torch.distributed as tdist
+        if num_replicas is None or rank is None:
+            ok = tdist.is_available() and tdist.is_initialized()
+            num_replicas = tdist.get_world_size() if ok else 1
+            rank = tdist.get_rank() if ok else 0
+        self.dataset, self.samples_per_gpu, self.num_replicas, self.rank, self.seed, self.epoch = dataset, samples_per_gpu, num_replicas, rank, seed or 0, 0
+        self.flag = np.asarray(dataset.flag).astype(np.int64)
+        self.group_sizes = np.bincount(self.flag)
+        self.num_samples = sum(int(math.ceil(sz * 1.0 / samples_per_gpu / num_replicas)) * samples_per_gpu for sz in self.group_sizes)
+        self.total_size = self.num_samples * num_replicas
+
+    def __iter__(self):
+        import math
+        g = torch.Generator()
+        g.manual_seed(self.epoch + self.seed)
+        indices = []
+        for i, size in enumerate(self.group_sizes):
+            if size > 0:
+                indice = np.where(self.flag == i)[0]
+                indice = indice[list(torch.randperm(int(size), generator=g).numpy())].tolist()
+                extra = int(math.ceil(size * 1.0 / self.samples_per_gpu / self.num_replicas)) * self.samples_per_gpu * self.num_replicas - len(indice)
+                tmp = indice.copy()
+                for _ in range(extra // size):
+                    indice.extend(tmp)
+                indice.extend(tmp[:extra % size])
+                indices.extend(indice)
+        assert len(indices) == self.total_size
+        indices = [indices[j] for i in list(torch.randperm(len(indices) // self.samples_per_gpu, generator=g))
+                   for j in range(i * self.samples_per_gpu, (i + 1) * self.samples_per_gpu)]
+        offset = self.num_samples * self.rank
+        return iter(indices[offset:offset + self.num_samples])
+
+    def __len__(self):
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
 def _collate_dc(items, samples_per_gpu):
     """mmcv.parallel.collate for a list of DataContainers (one GPU per process: a single chunk)."""
     first = items[0]
@@ -394,7 +441,10 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
     import torch.distributed as tdist
     sampler = None
     if dist and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
-        sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=shuffle, seed=seed or 0)
+        if shuffle and getattr(dataset, 'flag', None) is not None:
+            sampler = DistributedGroupSampler(dataset, samples_per_gpu, seed=seed or 0)          # builder.py:105-108
+        else:
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=shuffle, seed=seed or 0)
         shuffle = False
     if sampler is None and shuffle and getattr(dataset, 'flag', None) is not None and len(np.unique(dataset.flag)) > 1:
         sampler, shuffle = GroupSampler(dataset, samples_per_gpu), False          # builder.py:113-115 (aspect-ratio groups)

@@ -86,6 +86,9 @@ class MyEpochBasedRunnerLambda(BaseRunner):
         self.mode = 'train'
         self.data_loader = data_loader
         self._max_iters = self._max_epochs * len(data_loader)
+        sampler = getattr(data_loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):          # mmcv DistSamplerSeedHook: a different share / order every epoch under data parallelism
+            sampler.set_epoch(self.epoch)
         self.call_hook('before_train_epoch')
         for i, data_batch_L in enumerate(data_loader):
             if kwargs.get('onlyEval'):

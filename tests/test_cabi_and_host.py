@@ -170,3 +170,20 @@ def test_synthetic_dataset_and_loader_contract():
     assert len(data['gt_bboxes']) == 2 and data['gt_bboxes'][0].shape[1] == 4 and data['gt_labels'][0].dtype == torch.int64
     with pytest.raises(FileNotFoundError):                         # the real VOC path is built (tests/test_voc_data.py); no data here
         build_dataset(dict(type='VOCDataset', ann_file='/nonexistent/ImageSets/Main/x.txt', img_prefix='/nonexistent/VOC2007/', pipeline=[]))
+
+
+def test_ssd512_config_builds_the_seven_level_model():
+    """configs/ssd/ssd512_voc.py (reference: configs/ssd/ssd512_voc.py): 7 pyramid levels, strides 8 ... 512, 24 564 anchors per image."""
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/ssd/ssd512_voc.py'))
+    assert cfg.input_size == 512 and cfg.uncertainty_pool2 == 'objectSum_scaleAvg_classSum' and cfg.model.type == 'SSD_L_SingleStageDetector'
+    cfg.model.backbone.pop('init_cfg', None)
+    m = build_detector(cfg.model)
+    ag = m.bbox_head.anchor_generator
+    assert ag.num_levels == 7 and list(ag.num_base_anchors) == [4, 6, 6, 6, 6, 4, 4]
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    assert sum(a.shape[0] for a in ag.grid_anchors(sizes, 'cpu')) == 24564
+    assert ag.base_sizes == [20, 51, 133, 215, 296, 378, 460]          # int(512 * {4, 10, 26, 42, 58, 74, 90} / 100)
+    assert len(m.neck.extra_layers) == 5 and m.neck.extra_layers[-1][1].conv.kernel_size == (4, 4)
+    assert len(m.bbox_head.cls_convs) == 7

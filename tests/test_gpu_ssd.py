@@ -270,3 +270,39 @@ def test_ssd_full_model_scoring_runs_and_is_partition_invariant(built):
     u = torch.as_tensor(unc).float().cpu()
     s = torch.cat([torch.as_tensor(x).float().cpu().reshape(-1) for x in singles])
     assert torch.isfinite(u).all() and torch.equal(u, s)
+
+
+def test_ssd512_seven_levels_train_and_score_on_the_gpu():
+    """configs/ssd/ssd512_voc.py end to end on the HIP kernels: 24 564 anchors over 7 levels (strides 8 ... 512, the last extra conv is 4 x 4),
+    train_step + train_step_L backward, then the HUA scoring pass (7-level pair bookkeeping, 21-column Dirichlet)."""
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/ssd/ssd512_voc.py'))
+    cfg.model.backbone.pop('init_cfg', None)
+    torch.manual_seed(3)
+    model = build_detector(cfg.model)
+    model.init_weights()
+    model = model.cuda().train()
+    B, H = 4, 512
+    gtb, gtl = synth.random_gts(B, H, H, seed=61, gmin=1, gmax=4)
+    data = dict(img=synth.images(B, H, H, seed=62).cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    assert [tuple(f.shape[-2:]) for f in feat_out] == [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    assert sum(l.reshape(B, -1).shape[1] for l in head_out[4]) == 24564
+    assert torch.isfinite(out['loss']) and float(out['loss']) > 0
+    model.zero_grad()
+    out['loss'].backward()
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    lossL['loss'].backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    assert model.neck.extra_layers[4][1].conv.weight.grad is not None and model.bbox_head.L_convs[6][0].weight.grad is not None
+    model.eval()
+    with torch.no_grad():
+        for conv in model.bbox_head.cls_convs:                       # confident foreground logits so that objects / pairs exist
+            conv[-1].weight.mul_(40.0)
+        res, unc = model(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True, isEval=False, isUnc='Epistemic',
+                         uPool='Entropy_NMS', uPool2=cfg.uncertainty_pool2, scaleUnc=False, showNMS=False, saveUnc=False, saveMaxConf=False,
+                         clsW=False, batchIdx=0)
+    unc = torch.as_tensor(unc).float().cpu()
+    assert unc.shape == (B,) and torch.isfinite(unc).all() and (unc >= 0).all()
