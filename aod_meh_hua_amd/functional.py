@@ -158,6 +158,20 @@ import os as _os
 _FUSE_ACT = _os.environ.get('AOD_FUSE_ACT', '1') != '0'      # debug switch for A/B timing
 
 
+# precision of the conv operands: 'bf16' (product) or 'bf16x3' (debug instrument: ~fp32 products on the same kernels, precision_x3.py)
+_PREC = _os.environ.get('AOD_CONV_PREC', 'bf16')
+
+
+def set_precision(p):
+    global _PREC
+    assert p in ('bf16', 'bf16x3')
+    _PREC = p
+
+
+def get_precision():
+    return _PREC
+
+
 class ActSlot:
     """Side channel between a conv and the ONE conv that consumes its ReLU output.  The consumer's dgrad epilogue applies the producer's
     ReLU mask and sums the columns (aod_conv2d res / mask / colsum), so the producer's backward receives the finished masked gradient and
@@ -305,6 +319,10 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
     the `res` input of ONE later conv_bn_act call (ResNet identity block), whose residual gradient is then routed through this conv."""
     single = torch.is_tensor(xs)
     xl = [xs] if single else list(xs)
+    if _PREC == 'bf16x3':
+        from .precision_x3 import conv_bn_act_x3
+        outs = conv_bn_act_x3(xl, w, bn, bias, res, dict(stride=stride, pad=pad, dil=dil, relu=relu, eps=bn.eps if bn is not None else 0.0))
+        return outs[0] if single else list(outs)
     meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out)
     if torch.is_grad_enabled():
         if relu and not out_f32:
@@ -332,6 +350,9 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
 # --------------------------------------------------------------------------- stem helpers
 def image_to_nhwc(img, cpad=8):
     """fp32 NCHW image batch -> bf16 NHWC rows viewed as [B, cpad, H, W] (no grad: images are leaves)."""
+    if _PREC == 'bf16x3':
+        from .precision_x3 import image_to_nhwc_x3
+        return image_to_nhwc_x3(img)
     B, C, H, W = img.shape
     rows, _ = ho.nchw_to_rows(img.detach().float(), cpad)
     return as_nchw(rows, B, H, W)
@@ -339,6 +360,9 @@ def image_to_nhwc(img, cpad=8):
 
 def max_pool_3x3_s2(x):
     """resnet.py:610 -- only used inside the frozen stem (no backward needed)."""
+    if _PREC == 'bf16x3':
+        from .precision_x3 import max_pool_x3
+        return max_pool_x3(x)
     assert not x.requires_grad, 'maxpool backward is not implemented (stem is frozen, resnet.py:612-628)'
     B, C, H, W = x.shape
     rows, s = ho.maxpool3x3s2(as_rows(x), Seg(B, H, W))
@@ -382,6 +406,9 @@ def pyramid_buffer(shapes, channels, device, dtype=torch.bfloat16):
 
 
 def upsample_add(lateral, top):
+    if _PREC == 'bf16x3':
+        from .precision_x3 import upsample_add_x3
+        return upsample_add_x3(lateral, top)
     return UpsampleAddFn.apply(lateral, top)
 
 

@@ -140,14 +140,14 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
 
 
 def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,
-                      post_scale=None, out=None, x_rows_total=None, colsum=None, alg=None):
+                      post_scale=None, out=None, x_rows_total=None, colsum=None, alg=None, out_f32=False):
     """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad].
     res / mask / colsum: fused activation backward of the producer of x (see aod_conv2d)."""
     Npad = dz_rows.shape[1]
     rows = x_rows_total if x_rows_total is not None else sum(s.rows for s in x_segs)
     if out is None:
-        out = torch.empty(rows, Cin, dtype=torch.bfloat16, device=dz_rows.device)
-    d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
+        out = torch.empty(rows, Cin, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz_rows.device)
+    d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, out_f32)
     ws, wsb = _splitk_ws(d, dz_rows.device)
     _prof('dgrad', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
                                    ptr(post_scale), None, ptr(colsum), ptr(ws), wsb, stream()), alg)

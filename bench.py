@@ -368,6 +368,25 @@ def main():
         hua.update(head_scale=round(cal_k, 3), fg_anchor_frac_at_calibration=round(cal_frac, 5))
         assert hua['pairs_per_img'] > 0, 'degenerate HUA phase: no (candidate, object) pair in the scoring batch'
 
+    prec = None
+    if rank == 0 and world == 1 and do_train:
+        # the same training iteration in the bf16x3 debug precision (operands split into bf16 head + tail, ~fp32 products on the same MFMA
+        # kernels; aod_meh_hua_amd/precision_x3.py, tests/test_gpu_precision_x3.py): what ~fp32-exact arithmetic would cost on this path
+        from aod_meh_hua_amd import functional as AF
+        AF.set_precision('bf16x3')
+        try:
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step(0, True, False, graph=False)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+        finally:
+            AF.set_precision('bf16')
+        prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_train_img_per_s=round(B / min(ts), 1),
+                    note='debug instrument (3x MFMA work, fp32 activations, torch glue): residuals vs the fp32 reference fall from ~1e-2 to ~1e-5')
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, cd, do_train, do_score)
@@ -385,7 +404,7 @@ def main():
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
                                 parallelism=f'dp{world}', phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
                                 arithmetic='bf16 x bf16 -> fp32 MFMA convolutions; fp32 losses / geometry / scoring / optimizer'),
-                    phase_rates=phase, hua=hua, roofline=roof, cpu_baseline=cpu)
+                    phase_rates=phase, hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
