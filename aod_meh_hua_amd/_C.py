@@ -40,6 +40,9 @@ _SIGS = {
     'aod_conv2d_ws_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv2d_ws': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     'aod_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
+    'aod_conv2d_wgrad_splits': (C.c_int, [C.POINTER(ConvDesc)]),
+    'aod_conv2d_wgrad_slabs': (C.c_int, [C.POINTER(ConvDesc), P, P, P, I32, I64, P, P]),
+    'aod_unpack_wgrad_slabs': (C.c_int, [P, I32, I64, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P, P, P]),
     'aod_conv_row_table_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv_row_table': (C.c_int, [C.POINTER(ConvDesc), P, P]),
     'aod_pack_weight_fwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),

@@ -892,6 +892,7 @@ struct WgradParams {
   int M;
   int tiles_n, tiles_k, splits, rows_per_split;
   long long x_bytes, z_bytes, tab_bytes;
+  long long slab_stride;     // > 0: split s STORES its partial tile into dw + s * slab_stride (deterministic, summed by the unpack); 0: fp32 atomics
 };
 
 // byte offset of (row, 16-B chunk) in a 256-B-pitch bf16 image that serves transposed reads
@@ -1029,7 +1030,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     }
     __syncthreads();
   }
-  // accumulate into dW[n][kk] (fp32 atomics; one dword per lane, 16 consecutive columns per row group)
+  // slab mode: every pixel split owns a slab and STORES its partial tile (plain dword stores run at ~6 TB/s chip-wide, float atomics at
+  // ~1.3 TB/s: 512 workgroups x 64 KB of atomics were a 25 us tail on every launch); the unpack kernel adds the slabs in split order,
+  // so the weight gradient no longer depends on arrival order.  Otherwise: accumulate into dW[n][kk] with fp32 atomics (one dword per
+  // lane, 16 consecutive columns per row group).
+  float* const dwp = p.dw + (long long)split * p.slab_stride;
+  const bool slab = p.slab_stride > 0;
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1042,13 +1048,39 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
 #ifdef AOD_WGRAD_NO_EPI      // ablation build (tools/dbg): how much of the kernel is the atomic epilogue
         if (n < p.N && k < p.K && acc[i][j][r] == 12345.678f) p.dw[(long long)n * p.K + k] = 1.f;
 #else
-        if (n < p.N && k < p.K) atomicAdd(p.dw + (long long)n * p.K + k, acc[i][j][r]);
+        if (n < p.N && k < p.K) {
+          if (slab) dwp[(long long)n * p.K + k] = acc[i][j][r];
+          else atomicAdd(p.dw + (long long)n * p.K + k, acc[i][j][r]);
+        }
 #endif
       }
 }
 
-extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, const void* row_table,
-                                aod_stream_t stream) {
+// split of the pixel axis over workgroups: all workgroups co-resident (<= 2 per CU, no ragged second round); cost model (measured on
+// MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup ends with
+// 64 KB of output -- fp32 atomics at ~1.3 TB/s chip-wide (0.05 us per workgroup) or, in slab mode, plain stores at ~5.5 TB/s (0.012 us)
+// plus the unpack kernel's read of one more slab per split.
+static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps) {
+  tiles_n = (N + 127) / 128;
+  tiles_k = (K + 127) / 128;
+  const int tiles = tiles_n * tiles_k;
+  int best = 1;
+  double best_cost = 1e30;
+  const int max_s = 512 / tiles > 0 ? 512 / tiles : 1;
+  for (int sp = 1; sp <= max_s; ++sp) {
+    const int rows = ((M + sp - 1) / sp + 63) / 64 * 64;
+    const int nsp = (M + rows - 1) / rows;
+    const int wgs = tiles * nsp;
+    double cost = (rows / 64) * (wgs > 256 ? 1.7 : 1.45);
+    cost += slabs ? wgs * 0.012 + nsp * ((double)N * K * 4.0) / 2.5e6 : wgs * 0.05;
+    if (cost < best_cost) { best_cost = cost; best = sp; }
+  }
+  rps = ((M + best - 1) / best + 63) / 64 * 64;
+  splits = (M + rps - 1) / rps;
+}
+
+static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
+                        const void* row_table, aod_stream_t stream) {
   AOD_CHECK_ARG(d && x && dz && dw && row_table, "wgrad: null pointer");
   AOD_CHECK_ARG(!d->transposed, "wgrad: descriptor must be the forward descriptor");
   AOD_CHECK_ARG(d->N % 8 == 0, "wgrad: N %d must be a multiple of 8 (pad dZ)", d->N);
@@ -1073,25 +1105,15 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   p.z_bytes = zrows * p.N * 2;
   p.tab_bytes = (long long)p.M * (long long)sizeof(RowRec);
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
-  p.tiles_n = (p.N + 127) / 128;
-  p.tiles_k = (p.K + 127) / 128;
+  int splits, rps;
+  wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps);
   const int tiles = p.tiles_n * p.tiles_k;
-  // split of the pixel axis over workgroups: all workgroups co-resident (<= 2 per CU, no ragged second round); cost model
-  // (measured on MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup
-  // ends with 64 KB of fp32 atomics (~1.3 TB/s chip-wide = 0.05 us per workgroup)
-  int best = 1;
-  double best_cost = 1e30;
-  const int max_s = 512 / tiles > 0 ? 512 / tiles : 1;
-  for (int sp = 1; sp <= max_s; ++sp) {
-    const int rows = ((p.M + sp - 1) / sp + 63) / 64 * 64;
-    const int wgs = tiles * ((p.M + rows - 1) / rows);
-    const double cost = (rows / 64) * (wgs > 256 ? 1.7 : 1.45) + wgs * 0.05;
-    if (cost < best_cost) { best_cost = cost; best = sp; }
-  }
-  int splits = best;
-  int rps = ((p.M + splits - 1) / splits + 63) / 64 * 64;
-  splits = (p.M + rps - 1) / rps;
   p.splits = splits; p.rows_per_split = rps;
+  p.slab_stride = slab_stride;
+  if (slab_stride > 0) {
+    AOD_CHECK_ARG(splits <= max_slabs, "wgrad: %d slabs needed, %d provided (aod_conv2d_wgrad_splits)", splits, max_slabs);
+    AOD_CHECK_ARG(slab_stride >= (long long)p.N * p.K, "wgrad: slab stride smaller than N*K");
+  }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
@@ -1103,6 +1125,27 @@ extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const v
   else hipLaunchKernelGGL(conv_wgrad_kernel<4>, dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int aod_conv2d_wgrad(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, const void* row_table,
+                                aod_stream_t stream) {
+  return wgrad_launch(d, x, dz, dw, 0, 0, row_table, stream);
+}
+
+extern "C" int aod_conv2d_wgrad_splits(const aod_conv_desc_t* d) {
+  if (!d || d->transposed) return 0;
+  ConvKParams cp;
+  memset(&cp, 0, sizeof(cp));
+  if (fill_params(d, cp) || cp.M == 0) return 0;
+  int tn, tk, splits, rps;
+  wgrad_plan(cp.M, cp.N, cp.K, true, tn, tk, splits, rps);
+  return splits;
+}
+
+extern "C" int aod_conv2d_wgrad_slabs(const aod_conv_desc_t* d, const void* x, const void* dz, float* slabs, int nslabs, int64_t slab_stride,
+                                      const void* row_table, aod_stream_t stream) {
+  AOD_CHECK_ARG(nslabs >= 1 && slab_stride > 0, "wgrad_slabs: nslabs / slab_stride");
+  return wgrad_launch(d, x, dz, slabs, slab_stride, nslabs, row_table, stream);
 }
 
 // =====================================================================================
@@ -1151,6 +1194,56 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ d
     if (threadIdx.x == 0) {
       const float d = red[0] + red[1] + red[2] + red[3];
       wdot[oo] = bn_s1 ? bn_invstd[oo] * (d - bn_mean[oo] * bn_s1[oo]) : d;      // BN weight gradient when the statistics are given
+    }
+  }
+}
+// Slab form: dw = [nslabs][Opad][RS][Ipad] partial sums written by conv_wgrad_kernel's splits; one block per output channel adds the
+// slabs IN ORDER (deterministic), reading each slab row with consecutive lanes on consecutive channels, transposes [rs][c] -> [c][rs]
+// through LDS and writes the OIHW gradient with consecutive lanes on consecutive elements.
+constexpr int UNP_CH = 1024;      // channels per LDS chunk (x RS <= 9 taps)
+constexpr int UNP_T = 1024;       // threads: 16 waves per block keep enough slab loads in flight (one block per output channel)
+__global__ __launch_bounds__(UNP_T) void unpack_wgrad_slabs_kernel(const float* __restrict__ dw, int nslabs, long long slab_stride,
+                                                                  float* __restrict__ g, const float* __restrict__ scale,
+                                                                  const float* __restrict__ w, float* __restrict__ wdot,
+                                                                  const float* __restrict__ bn_s1, const float* __restrict__ bn_mean,
+                                                                  const float* __restrict__ bn_invstd, int O, int I, int RS, int Ipad, int accumulate) {
+  __shared__ float tile[UNP_CH * 9 + 1];
+  __shared__ float red[UNP_T / 64];
+  const int oo = blockIdx.x;
+  const float sc = scale ? scale[oo] : 1.f;
+  float dot = 0.f;
+  for (int c0 = 0; c0 < I; c0 += UNP_CH) {
+    const int nc = min(UNP_CH, I - c0);
+    for (int i = threadIdx.x; i < nc * RS; i += UNP_T) {
+      const int rs = i / nc, c = i - rs * nc;                       // consecutive lanes on consecutive channels of one slab row
+      const float* src = dw + ((long long)oo * RS + rs) * Ipad + c0 + c;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                 // fixed association: ((s0+s4+..)+(s1+s5+..))+((s2+..)+(s3+..))
+      int sl = 0;
+      for (; sl + 4 <= nslabs; sl += 4) {
+        const float a0 = src[(long long)sl * slab_stride], a1 = src[(long long)(sl + 1) * slab_stride];
+        const float a2 = src[(long long)(sl + 2) * slab_stride], a3 = src[(long long)(sl + 3) * slab_stride];
+        v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+      }
+      for (; sl < nslabs; ++sl) v0 += src[(long long)sl * slab_stride];
+      tile[c * RS + rs] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    const long long g0 = ((long long)oo * I + c0) * RS;
+    for (int i = threadIdx.x; i < nc * RS; i += UNP_T) {
+      const float v = tile[i];
+      if (w) dot += w[g0 + i] * v;
+      g[g0 + i] = accumulate ? g[g0 + i] + v * sc : v * sc;
+    }
+    __syncthreads();
+  }
+  if (wdot) {
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d = 0.f;
+      for (int k = 0; k < UNP_T / 64; ++k) d += red[k];
+      wdot[oo] = bn_s1 ? bn_invstd[oo] * (d - bn_mean[oo] * bn_s1[oo]) : d;
     }
   }
 }
@@ -1275,6 +1368,19 @@ extern "C" int aod_pack_weight_fwd(const float* w, void* o, int O, int I, int R,
 extern "C" int aod_pack_weight_dgrad(const float* w, void* o, int O, int I, int R, int S, int Opad, const float* scale, aod_stream_t stream) {
   AOD_CHECK_ARG(w && o && Opad >= O && Opad % 8 == 0, "pack_weight_dgrad: Opad must be a multiple of 8 and >= O");
   hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(grid_for((long long)Opad * R * S * I)), dim3(256), 0, (hipStream_t)stream, w, scale, (bf16_t*)o, O, I, R * S, Opad);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t slab_stride, float* g, int O, int I, int R, int S, int Ipad,
+                                      int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
+                                      const float* bn_mean, const float* bn_invstd, aod_stream_t stream) {
+  AOD_CHECK_ARG(dw_slabs && g && nslabs >= 1 && slab_stride > 0, "unpack_wgrad_slabs: null / empty");
+  AOD_CHECK_ARG(R * S <= 9, "unpack_wgrad_slabs: at most 9 taps (larger filters take aod_unpack_wgrad)");
+  AOD_CHECK_ARG(!wdot || w_oihw, "unpack_wgrad_slabs: wdot needs the weights");
+  AOD_CHECK_ARG(!bn_s1 || (wdot && bn_mean && bn_invstd), "unpack_wgrad_slabs: BN mode needs wdot, mean and invstd");
+  if (O == 0) return 0;
+  hipLaunchKernelGGL(unpack_wgrad_slabs_kernel, dim3(O), dim3(UNP_T), 0, (hipStream_t)stream, dw_slabs, nslabs, (long long)slab_stride, g, scale,
+                     w_oihw, wdot, bn_s1, bn_mean, bn_invstd, O, I, R * S, Ipad, accumulate);
   AOD_LAUNCH_CHECK();
   return 0;
 }

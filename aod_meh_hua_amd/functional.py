@@ -78,7 +78,7 @@ class ParamPrep:
     through tensor._version of (weight, gamma, beta, running_mean, running_var)."""
 
     def __init__(self):
-        self.items, self.order, self.table, self.dirty = {}, [], None, True
+        self.items, self.order, self.table, self.dirty, self.tables = {}, [], None, True, {}
 
     def _versions(self, it):
         return tuple(-1 if t is None else t._version for t in (r() if r is not None else None for r in it.srcs))
@@ -128,9 +128,21 @@ class ParamPrep:
             self.dirty = True
         if self.dirty:
             self.order = list(self.items.values())
-            recs = (_PrepRec * max(len(self.order), 1))()
+            self.tables = {}
+            self.dirty = False
+        # only the STALE layers are re-derived.  Which layers are stale together repeats (all trainable layers of one model after its
+        # optimizer step; never the frozen stem / layer1; never a second, frozen model): one device table per staleness pattern.
+        stale = tuple(i for i, it in enumerate(self.order) if it.ver != self._versions(it))
+        if not stale:
+            return
+        ent = self.tables.get(stale)
+        if ent is None:
+            if len(self.tables) > 16:
+                self.tables.clear()
+            recs = (_PrepRec * len(stale))()
             blk = 0
-            for r, it in zip(recs, self.order):
+            for r, i in zip(recs, stale):
+                it = self.order[i]
                 src = [x() if x is not None else None for x in it.srcs]
                 for t in src:
                     assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), 'parameters must be contiguous fp32'
@@ -140,14 +152,12 @@ class ParamPrep:
                 r.O, r.I, r.RS, r.Ipad, r.Opad = it.dims
                 r.blk0, r.eps = blk, it.eps
                 blk += it.nblk
-            self.nblocks = blk
             host = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
-            self.table = host.to(self.order[0].wf.device) if self.order else None
-            self.dirty = False
-        if self.order:
-            ho.call('aod_param_prep', ho.ptr(self.table), len(self.order), self.nblocks, ho.stream())
-        for it in self.order:
-            it.ver = self._versions(it)
+            ent = self.tables[stale] = (host.to(self.order[stale[0]].wf.device), blk)
+        self.table = ent[0]           # (kept alive for captured graphs by graphs._pin_caches)
+        ho.call('aod_param_prep', ho.ptr(ent[0]), len(stale), ent[1], ho.stream())
+        for i in stale:
+            self.order[i].ver = self._versions(self.order[i])
 
 
 PREP = ParamPrep()

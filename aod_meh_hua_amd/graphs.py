@@ -26,7 +26,7 @@ def _pin_caches():
     """References to every cached device buffer a captured kernel may point at (row tables, the wgrad scratch, parameter-preparation
     buffers and table, scoring meta tensors): the host-side caches evict / regrow, a graph must keep what it captured alive."""
     from . import scoring
-    return (dict(ho._ROW_TABLES), dict(ho._DW), list(AF.PREP.items.values()), AF.PREP.table, dict(scoring._META))
+    return (dict(ho._ROW_TABLES), dict(ho._DW), dict(ho._SLABS), list(AF.PREP.items.values()), AF.PREP.table, dict(scoring._META))
 
 
 def _unwrap(model):

@@ -155,11 +155,15 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
 
 
 def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None, alg=None):
-    """dW[Npad][R][S][C] fp32 (accumulated into `dw` if given)."""
+    """dW of a conv: with `dw` given, [Npad][R][S][C] fp32 ACCUMULATED into it (fp32 atomics); otherwise the deterministic slab form --
+    returns [nslabs][Npad][R][S][C] partial sums in a per-device scratch (valid until the next wgrad launch; unpack_wgrad adds them)."""
     Cin, Npad = x_rows.shape[1], dz_rows.shape[1]
-    if dw is None:
-        dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
+    nslabs = 0
+    if dw is None and R * S <= 9 and SLAB_WGRAD:
+        nslabs = int(lib.aod_conv2d_wgrad_splits(C.byref(d)))
+    if dw is None and nslabs == 0:
+        dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     if len(_ROW_TABLES) > 512:
         _ROW_TABLES.clear()
     key = (tuple(x_segs), tuple(dz_segs), Cin, Npad, R, S, stride, pad, dil, x_rows.device.index)
@@ -168,11 +172,27 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
         tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=x_rows.device)
         call('aod_conv_row_table', C.byref(d), ptr(tab), stream())
         _ROW_TABLES[key] = tab
+    if nslabs:
+        stride_ = Npad * R * S * Cin
+        slabs = _slab_scratch(nslabs * stride_, x_rows.device).view(nslabs, Npad, R, S, Cin)
+        _prof('wgrad', d, lambda: call('aod_conv2d_wgrad_slabs', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(slabs), nslabs, stride_, ptr(tab), stream()), alg)
+        return slabs
     _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), ptr(tab), stream()), alg)
     return dw
 
 
 _DW = {}
+_SLABS = {}
+SLAB_WGRAD = os.environ.get('AOD_WGRAD_SLABS', '1') != '0'      # debug switch: 0 = fp32-atomic accumulation into one dW (round-1 form)
+
+
+def _slab_scratch(n, device):
+    """Per-device scratch for the wgrad slabs (at most 512 workgroups x 64 KB = 33.5 MB per launch); need not be initialised."""
+    buf = _SLABS.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, (1 << 23) + (1 << 21)), dtype=torch.float32, device=device)
+        _SLABS[device] = buf
+    return buf[:n]
 
 
 def _dw_scratch(n, device):
@@ -210,6 +230,15 @@ def reset_zero_arena():
 def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None):
     """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot; with bn = (s1, mean, invstd) wdot is the
     BatchNorm weight gradient invstd * (<w, dw> - mean * s1)."""
+    if dw_orsi.dim() == 5:          # slab form (conv2d_wgrad_rows without `dw`)
+        nslabs, Opad, R, S, Ipad = dw_orsi.shape
+        if grad_oihw is None:
+            grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
+        wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
+        call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), ptr(scale),
+             ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
+             ptr(bn[2]) if bn else None, stream())
+        return (grad_oihw, wdot) if want_wdot else grad_oihw
     Opad, R, S, Ipad = dw_orsi.shape
     if grad_oihw is None:
         grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)

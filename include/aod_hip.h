@@ -87,6 +87,13 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
  * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */
 int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz, float* dw_f32,
                      const void* row_table, aod_stream_t stream);
+/* Deterministic form of the same operation (no float atomics): the kernel splits the pixel axis over aod_conv2d_wgrad_splits(desc)
+ * workgroup groups; split s STORES its partial result into slabs + s * slab_stride ([N][R][S][C] fp32 each, need not be initialised;
+ * slab_stride >= N*R*S*C elements) and aod_unpack_wgrad_slabs adds the slabs in split order.  Plain stores run at ~6 TB/s where float
+ * atomics run at ~1.3 TB/s chip-wide, and the weight gradient becomes bit-reproducible run to run (1-GPU vs N-GPU traces comparable). */
+int aod_conv2d_wgrad_splits(const aod_conv_desc_t* desc);
+int aod_conv2d_wgrad_slabs(const aod_conv_desc_t* desc, const void* x, const void* dz, float* slabs, int nslabs, int64_t slab_stride,
+                           const void* row_table, aod_stream_t stream);
 /* Row table of a forward descriptor (32 B per destination pixel: source block origin, top-left tap, extents,
  * dZ row).  Depends only on segment geometry / stride / pad / filter size: build once, reuse for every wgrad
  * launch with that geometry. */
@@ -107,6 +114,11 @@ int aod_pack_weight_dgrad(const float* w_oihw, void* w_packed, int O, int I, int
 int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int S, int Ipad, int accumulate, int clear_src,
                      const float* scale, const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean,
                      const float* bn_invstd, aod_stream_t stream);
+
+/* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 9 taps. */
+int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t slab_stride, float* grad_oihw, int O, int I, int R, int S, int Ipad,
+                           int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
+                           const float* bn_mean, const float* bn_invstd, aod_stream_t stream);
 
 /* Batched re-derivation of everything the conv launches read from the parameters, for ALL layers in one launch (after an optimizer
  * step every trainable layer is stale): items_dev = device array of `nitems` records of aod_param_prep_item_bytes() bytes,

@@ -226,12 +226,21 @@ def test_conv_dgrad_and_wgrad(ho, case):
     xpad[:, :Creal] = x.detach()
     x_rows = nhwc_rows(xpad).cuda().bfloat16()
     xs, zs = [ho.Seg(B, H, W)], [ho.Seg(B, OH, OW)]
-    # wgrad
+    # wgrad: slab form (default for <= 9 taps: every pixel split stores its partial, the unpack adds the slabs in order) ...
     dw = ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, R, R, stride, pad, dil)
     gw = ho.unpack_wgrad(dw, N, Creal)
     torch.cuda.synchronize()
     scale = float(w.grad.abs().max())
     assert close(gw, w.grad, 5e-3, 5e-3 * scale)
+    if R * R <= 9:
+        assert dw.dim() == 5
+        gw2 = ho.unpack_wgrad(ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, R, R, stride, pad, dil), N, Creal)
+        assert torch.equal(gw, gw2)                         # ... is bit-reproducible run to run
+        # ... and agrees with the fp32-atomic accumulation form of the same kernel
+        acc = torch.zeros(Npad, R, R, C, device='cuda')
+        ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, R, R, stride, pad, dil, dw=acc)
+        gw3 = ho.unpack_wgrad(acc, N, Creal, clear=False)
+        assert close(gw3, gw, 1e-4, 1e-5 * scale)
     # dgrad
     wd = ho.pack_weight_dgrad(w.detach().cuda(), Npad)
     wd_full = wd
