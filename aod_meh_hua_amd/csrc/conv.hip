@@ -63,7 +63,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // OPS: which optional epilogue operands the instance supports -- 0 none, 1 ReLU mask only, 2 residual and mask (their prefetch registers
 // are what pushes the 8-wave form into spills, so it exists without them)
 template <int BM, int BN, int NT, int OPS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 4 : 1, NT == 512 ? 4 : 8))) void conv_igemm_kernel(const ConvKParams p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
@@ -75,6 +75,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
   constexpr int WM = BM / WAVES_M, WN = BN / 2;  // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int CP = BN + 4;               // fp32 epilogue pitch
+  // the fp32 epilogue image of a 256 x 256 tile (266 KB) does not fit the LDS: it is written and stored in EP passes of EBM rows
+  constexpr int EP = (BM * CP * 4 > 144 * 1024) ? 2 : 1;
+  constexpr int EBM = BM / EP;
+  constexpr bool PREFETCH = EP == 1;       // residual / mask rows prefetched into registers before the K loop (not for the big tile: 16 x 8 regs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
   const bool linear = one_seg && !p.perm;       // destination rows of the tile are consecutive: drow = m + const
   // destination row of every tile row, parked in LDS behind the staging / epilogue area (read by the general epilogue, and by the
   // fast one on tiles that straddle a segment boundary)
-  constexpr int EPI_BYTES = BM * CP * 4;
+  constexpr int EPI_BYTES = EBM * CP * 4;
   constexpr int DROW_OFF = (2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES);
   long long* s_drow = reinterpret_cast<long long*>(smem + DROW_OFF);
   if (t < BM) {
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
   // together with the first operand tile and consumed after the main loop -- a load-use chain per store iteration would expose one
   // memory latency per 16 B and cap memory-bound layers at a third of the bandwidth
   constexpr int NCH = BN / 8;              // 8-column chunks per tile row
-  constexpr int E_IT = BM * NCH / NT;
+  constexpr int E_IT = EBM * NCH / NT;     // row segments per thread and epilogue pass
   const int ec = t % NCH, er = t / NCH;
   float cs1[8], cb1[8], cs2[8];
-  bf16x8 pres[E_IT], pmask[E_IT];
+  bf16x8 pres[PREFETCH ? E_IT : 1], pmask[PREFETCH ? E_IT : 1];
   // interior tiles of the common configuration (bf16 destination, N % 8 == 0, no post-scale / raw copy) take an epilogue without per-thread
   // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
   const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
@@ -325,11 +329,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
         }
       }
       if (!from_table) {
-        if (OPS > 1 && p.res) {
+        if (PREFETCH && OPS > 1 && p.res) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + lin_off + it * lin_step);
         }
-        if (OPS > 0 && p.mask) {
+        if (PREFETCH && OPS > 0 && p.mask) {
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + lin_off + it * lin_step);
         }
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
         cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
       }
     }
-    if (OPS > 0 && (p.res || p.mask)) {
+    if (PREFETCH && OPS > 0 && (p.res || p.mask)) {
 #pragma unroll
       for (int it = 0; it < E_IT; ++it) {
         const int row = er + it * (NT / NCH);
@@ -441,22 +445,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
 #endif
   TSTAMP(3);
   float* sc = reinterpret_cast<float*>(smem);
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int ep = 0; ep < EP; ++ep) {
+  const int r0e = ep * EBM;                  // first tile row of this pass
+  if (EP > 1 && ep > 0) __syncthreads();     // the previous pass's image has been stored
+  if (EP == 1 || (wm * WM) / EBM == ep) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sc[(wm * WM + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sc[(wm * WM - r0e + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
+  }
   __syncthreads();
   TSTAMP(4);
 
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // fast tiles: no per-thread predicates at all, only workgroup-uniform branches -- the general loop below costs ~500 instructions
   // per 16-B store, this one under 100
   if (fast) {
     bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + n0 + ec * 8;
-    bf16_t* const yl = reinterpret_cast<bf16_t*>(p.y) + lin_off;
+    bf16_t* const yl = reinterpret_cast<bf16_t*>(p.y) + lin_off + (long long)r0e * p.N;
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
       const int row = er + it * (NT / NCH);
@@ -471,13 +481,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += cb1[j];
+      const long long eoff = linear ? lin_off + (long long)r0e * p.N + it * lin_step : s_drow[r0e + row] * p.N + n0 + ec * 8;
       if (OPS > 1 && p.res) {
+        const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + eoff);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)pres[it][j];
+        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
       if (OPS > 0 && p.mask) {
+        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(p.mask + eoff);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ((float)pmask[it][j] > 0.f) ? v[j] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }
       if (p.relu) {
 #pragma unroll
@@ -486,16 +499,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       bf16x8 ov;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { csum[j] += v[j]; ov[j] = (bf16_t)v[j]; }
-      *reinterpret_cast<bf16x8*>(linear ? yl + it * lin_step : yb + s_drow[row] * p.N) = ov;
+      *reinterpret_cast<bf16x8*>(linear ? yl + it * lin_step : yb + s_drow[r0e + row] * p.N) = ov;
     }
   } else
 #pragma unroll
   for (int it = 0; it < E_IT; ++it) {
     const int row = er + it * (NT / NCH);
-    const int m = m0 + row;
+    const int m = m0 + r0e + row;
     const int n = n0 + ec * 8;
     if (m >= p.M || n >= p.N) continue;
-    const long long drow = s_drow[row];
+    const long long drow = s_drow[r0e + row];
     float v[8], raw[8];
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
@@ -509,12 +522,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
       if (OPS > 1 && p.res) {
-        const bf16x8 rv = pres[it];
+        const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
       if (OPS > 0 && p.mask) {
-        const bf16x8 mv = pmask[it];
+        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(p.mask + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }
@@ -566,6 +579,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       }
     }
   }
+  }    // epilogue passes
   TSTAMP(5);
 #ifdef AOD_TILE_TIMING
   __builtin_amdgcn_s_waitcnt(0);      // vmcnt/lgkmcnt 0: stores acknowledged
@@ -595,7 +609,8 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
   const size_t stage = (size_t)(BM + BN) * 128 * 2;
-  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  const size_t epi_full = (size_t)BM * (BN + 4) * 4;
+  const size_t epi = epi_full > 144 * 1024 ? epi_full / 2 : epi_full;      // (two epilogue passes for the 256 x 256 tile)
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
@@ -800,6 +815,18 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // deep convs without a residual operand (forward and dgrad of the head towers, the 3x3 of the backbone): the 128 x 128 tile on 8
   // waves -- four waves per SIMD hide more of the K loop's waits than two (-4 % on the head-tower shape); with the residual's prefetch
   // registers as well the 8-wave form spills and loses
+  // The 256 x 256 tile (one 8-wave workgroup per CU, 128 FLOP per staged byte instead of 64, two epilogue passes) runs deep-K layers
+  // 15-18 % faster per tile (tools/dbg/tile256.py: 794 -> 934 TFLOP/s on the FPN P3 shape) but one workgroup per CU quantises hard: it
+  // is chosen only when its tiles fill whole rounds of the 256 CUs to >= 92 % (AOD_TILE_256=1 forces it, =0 disables it).
+  static const char* dbg_t256 = getenv("AOD_TILE_256");
+  const long long t256 = ntiles(256, 256);
+  const bool fits256 = t256 >= 240 && t256 * 100 >= ((t256 + 255) / 256) * 256 * 92;
+  if (!(dbg_t256 && dbg_t256[0] == '0') && !p.res && !p.out_f32 && p.N % 256 == 0 && p.K >= 1024 &&
+      ((dbg_t256 && dbg_t256[0] == '1' && t256 >= 128) || fits256)) {
+    if (!p.mask) launch_conv<256, 256, 512, 0>(p, st); else launch_conv<256, 256, 512, 1>(p, st);
+    AOD_LAUNCH_CHECK();
+    return 0;
+  }
   static const char* dbg_w8 = getenv("AOD_TILE_W8");
   if (!(dbg_w8 && dbg_w8[0] == '0') && !p.res && p.N >= 128 && p.K >= 1024 && ntiles(128, 128) >= want) {
     if (!p.mask) launch_conv<128, 128, 512, 0>(p, st); else launch_conv<128, 128, 512, 1>(p, st);

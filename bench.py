@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--mode', default='train+score', choices=['train', 'score', 'train+score', 'pool'])
     ap.add_argument('--pool', type=int, default=10000, help='--mode pool: number of pool images (all ranks together)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-precision-check', action='store_true', help='skip the bf16x3 debug-precision iterations after the timed region (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--shapes', default=None, help='write the per-shape conv breakdown of the instrumented step to this file')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
@@ -369,7 +370,7 @@ def main():
         assert hua['pairs_per_img'] > 0, 'degenerate HUA phase: no (candidate, object) pair in the scoring batch'
 
     prec = None
-    if rank == 0 and world == 1 and do_train:
+    if rank == 0 and world == 1 and do_train and not args.no_precision_check:
         # the same training iteration in the bf16x3 debug precision (operands split into bf16 head + tail, ~fp32 products on the same MFMA
         # kernels; aod_meh_hua_amd/precision_x3.py, tests/test_gpu_precision_x3.py): what ~fp32-exact arithmetic would cost on this path
         from aod_meh_hua_amd import functional as AF

@@ -369,3 +369,23 @@ def test_cpu_tensor_is_refused(ho):
     from aod_meh_hua_amd._C import AodHipError
     with pytest.raises(AodHipError):
         ho.add_relu(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_conv_256x256_tile_equals_the_default_tile(tmp_path):
+    """The 256 x 256 tile (two epilogue passes, no operand prefetch; chosen automatically when its tiles fill whole rounds of the CUs)
+    against the 128 x 128 tile on a ragged, five-segment tower shape, forward and dgrad with mask + column sums: same K order per
+    output element, so the bf16 results are identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ('0', '1'):
+        f = str(tmp_path / f'tile{flag}.pt')
+        p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dbg', 'tile256_check.py'), f], env=dict(os.environ, AOD_TILE_256=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[flag] = torch.load(f)
+    assert torch.equal(outs['0']['y'], outs['1']['y'])
+    assert torch.equal(outs['0']['dx'], outs['1']['dx'])
+    assert torch.allclose(outs['0']['cs'], outs['1']['cs'], rtol=1e-4, atol=1e-2)          # (atomic column sums: order differs)
+    assert float(outs['1']['y'].float().abs().mean()) > 0.1 and float(outs['1']['dx'].float().abs().mean()) > 0.01

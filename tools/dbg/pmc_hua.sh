@@ -8,7 +8,7 @@ mkdir -p $D
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace -d $D/g$i -o out --output-format csv -- python3 $R/bench.py --mode score --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $D/bench_$i.json 2>$D/err_$i.txt
+  rocprofv3 --pmc $grp --kernel-trace -d $D/g$i -o out --output-format csv -- python3 $R/bench.py --mode score --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph > $D/bench_$i.json 2>$D/err_$i.txt
 done
 python3 - <<PY
 import csv, glob, collections, json
