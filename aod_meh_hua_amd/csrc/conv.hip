@@ -12,6 +12,7 @@
 //   with ds_read_b64_tr_b16 (hardware transpose); split over m across workgroups, fp32 atomics.
 #include "common.h"
 
+struct ConvGroup { const bf16_t* x; const bf16_t* w; void* y; const float* pre_shift; const bf16_t* mask; float* colsum; };
 struct ConvKParams {
   const bf16_t* x;
   const bf16_t* w;
@@ -30,6 +31,9 @@ struct ConvKParams {
   float* ws;          // split-K workspace, fp32 [ksplit][M][N] in GEMM-row order; conv_splitk_finalize sums the slabs IN ORDER (deterministic)
   int perm;           // dgrad of a stride-2 conv: GEMM rows run CLASS-MAJOR inside a segment (the four (y & 1, x & 1) classes of the
                       // destination pixels one after the other), so a tile is one class and the filter taps that can never hit it are skipped
+  int ngroups;        // > 1: grouped launch (aod_conv2d_grouped): grp[] replaces x / w / y / pre_shift / mask / colsum
+  ConvGroup grp[4];
+  int stagger;        // 8-wave forms: waves 4-7 run half a K-step behind waves 0-3 (see the K loop)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
@@ -62,7 +66,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 
 // OPS: which optional epilogue operands the instance supports -- 0 none, 1 ReLU mask only, 2 residual and mask (their prefetch registers
 // are what pushes the 8-wave form into spills, so it exists without them)
-template <int BM, int BN, int NT, int OPS>
+template <int BM, int BN, int NT, int OPS, bool GROUPED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   constexpr int BK = 64;
@@ -89,14 +93,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // class-major launches keep the round-robin block -> XCD assignment: the classes differ in work (1 / 2 / 2 / 4 taps of a 3x3, 1 / 0 / 0 / 0
   // of a 1x1) and contiguous per-XCD tile ranges would hand whole classes to single XCDs
   int wg;
-  if (!p.perm) wg = xcd_swizzle(blockIdx.x, nwg * p.ksplit);
+  if (!p.perm) wg = xcd_swizzle(blockIdx.x, nwg * (GROUPED ? p.ngroups : p.ksplit));
   else if ((nwg & 31) == 0) {
     // ... but inside each quarter of the tile range (~ one class) every XCD still takes a contiguous chunk (neighbouring column tiles
     // share their A rows in that XCD's L2), and the quarters are interleaved in launch order
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, q = j & 3, k = j >> 2, tq = nwg >> 2;
     wg = q * tq + x * (tq >> 3) + k;
   } else wg = blockIdx.x;
-  const int tile = wg % nwg, kz = wg / nwg;        // kz: which slice of the K-steps (split-K launches)
+  const int tile = wg % nwg, zz = wg / nwg;
+  const int kz = GROUPED ? 0 : zz;           // kz: which slice of the K-steps (split-K launches)
+  // grouped launch: `ngroups` convolutions of identical geometry (the cls / reg / evidence towers at one depth) share one grid, so
+  // that their tiles fill whole rounds of the CUs together; group = which operand set this workgroup uses
+  const int gi = GROUPED ? zz : 0;
+  // (constant indices only: a run-time index into the by-value argument struct would move the whole struct to scratch memory; the
+  // selection exists in the GROUPED instances only -- in the 256 x 256 tile, which sits at the register cap, it costs ~15 %)
+#define AOD_GSEL(f, dflt) (GROUPED ? (gi == 0 ? p.grp[0].f : (gi == 1 ? p.grp[1].f : (gi == 2 ? p.grp[2].f : p.grp[3].f))) : (dflt))
+  const bf16_t* const g_x = AOD_GSEL(x, p.x);
+  const bf16_t* const g_w = AOD_GSEL(w, p.w);
+  const float* const g_shift = AOD_GSEL(pre_shift, p.pre_shift);
+#define g_y AOD_GSEL(y, p.y)
+#define g_mask AOD_GSEL(mask, p.mask)
+#define g_colsum AOD_GSEL(colsum, p.colsum)
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef AOD_TILE_TIMING
@@ -113,8 +130,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   const int prow = lane >> 3;                       // row inside the wave's 8-row group
   const int kc = (lane & 7) ^ ((4 * uw + (lane >> 4)) & 7);   // k-chunk this lane fetches (same for every pass)
   const int C8 = p.C >> 3;
-  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)g_x, 0, (int)p.x_bytes, 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)g_w, 0, (int)p.w_bytes, 0x00020000);
   constexpr unsigned OOB = 0xfffffff0u;
 
   unsigned rbase[A_IT];                             // byte offset of pixel (b, 0, 0) of the row's source block
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       {
         // bias through a buffer descriptor that is EMPTY when there is no bias: the range check then returns zeros and the load needs
         // no branch (a branch would make the compiler wait for the loaded values where the two paths merge, i.e. right here)
-        const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_shift, 0, p.pre_shift ? p.N * 4 : 0, 0x00020000);
+        const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)g_shift, 0, g_shift ? p.N * 4 : 0, 0x00020000);
         const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_scale, 0, p.pre_scale ? p.N * 4 : 0, 0x00020000);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, n * 4 + 16, 0, 0);
@@ -333,9 +350,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
           for (int it = 0; it < E_IT; ++it) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + lin_off + it * lin_step);
         }
-        if (PREFETCH && OPS > 0 && p.mask) {
+        if (PREFETCH && OPS > 0 && g_mask) {
 #pragma unroll
-          for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + lin_off + it * lin_step);
+          for (int it = 0; it < E_IT; ++it) pmask[it] = *reinterpret_cast<const bf16x8*>(g_mask + lin_off + it * lin_step);
         }
         return;
       }
@@ -344,11 +361,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       for (int j = 0; j < 8; ++j) {
         const bool ok = n + j < p.N;
         cs1[j] = (p.pre_scale && ok) ? p.pre_scale[n + j] : 1.f;
-        cb1[j] = (p.pre_shift && ok) ? p.pre_shift[n + j] : 0.f;
+        cb1[j] = (g_shift && ok) ? g_shift[n + j] : 0.f;
         cs2[j] = (p.post_scale && ok) ? p.post_scale[n + j] : 1.f;
       }
     }
-    if (PREFETCH && OPS > 0 && (p.res || p.mask)) {
+    if (PREFETCH && OPS > 0 && (p.res || g_mask)) {
 #pragma unroll
       for (int it = 0; it < E_IT; ++it) {
         const int row = er + it * (NT / NCH);
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
         const long long off = ok ? drow * p.N + n : 0;
         if (OPS > 1 && p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
-        if (OPS > 0 && p.mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(p.mask + off);
+        if (OPS > 0 && g_mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(g_mask + off);
       }
     }
   };
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // while the rows are resolved
   bool have = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;     // (kt_ld is the same in every lane; say so, or the loop control goes through EXEC)                    // (a class without a reachable tap has no K-step at all: its dX is the epilogue of zero)
   if (have) load_b(0);
-  if (linear && p.ksplit == 1) prefetch_epilogue(false);
+  if (linear && p.ksplit == 1 && PREFETCH) prefetch_epilogue(false);
   {
     // Row decode: lane j of a wave resolves the wave's row j & 31 ONCE (source block, top-left tap, image size); the 8 lanes that
     // gather the 8 k-chunks of a row then pick the record up with a lane shuffle (decoding per lane repeated the two divisions of a
@@ -390,39 +407,53 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   TSTAMP(9);
   if (have) { load_a(0); advance(); }
   __syncthreads();
-  if (!linear && p.ksplit == 1) prefetch_epilogue(true);     // destination rows are not consecutive: they come from the LDS table
+  if (!linear && p.ksplit == 1 && PREFETCH) prefetch_epilogue(true);     // destination rows are not consecutive: they come from the LDS table
   TSTAMP(2);
 #ifdef AOD_TILE_TIMING
   if (g_tile_stamps && threadIdx.x == 0) g_tile_stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();     // shader clock around the K loop
 #endif
   const int lr = lane & 15, lq = lane >> 4;
+  // STAGGER (8-wave forms): waves 4-7 share their SIMDs with waves 0-3 and run the same program -- in lockstep both waves of a SIMD issue
+  // their LDS-DMA, then both read fragments, then both want the matrix pipe.  Waves 4-7 therefore run half a K-step late: the MFMAs
+  // of the second k-block are carried across the barrier (their fragments are already in registers) and issued at the top of the next
+  // iteration, while waves 0-3 issue their loads and fragment reads (MI355X_MICROARCH.md 'Two waves per SIMD', item 9).
+  const bool late = p.stagger && NT == 512 && uw >= 4;
+  bool carried = false;
+  bf16x8 af[MI], bfr[NI];
+  auto frag_read = [&](const char* sa, const char* sb, int ks) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * WM + i * 16 + lr;
+      af[i] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + (((ks * 4 + lq) ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int row = wn * WN + j * 16 + lr;
+      bfr[j] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + (((ks * 4 + lq) ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  auto mfma_block = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  };
   for (int cur = 0; have; cur ^= 1) {
     const bool more = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
+    if (late && carried) mfma_block();
     if (more) gload(cur ^ 1);
     have = more;
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row = wm * WM + i * 16 + lr;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + (((ks * 4 + lq) ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int row = wn * WN + j * 16 + lr;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + (((ks * 4 + lq) ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    static_assert(BK == 64, "two 32-deep k-blocks per K-step");
+    frag_read(sa, sb, 0);
+    mfma_block();
+    frag_read(sa, sb, 1);
+    if (!late) mfma_block(); else carried = true;
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier: next tile is resident afterwards
   }
+  if (late && carried) mfma_block();
 
   if (p.ksplit > 1) {
     // split-K: this slice's fp32 partial tile goes to its own slab, straight from the accumulators (one dword per lane, 16
@@ -444,6 +475,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   if (g_tile_stamps && threadIdx.x == 0) g_tile_stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
 #endif
   TSTAMP(3);
+  if (!PREFETCH) prefetch_epilogue(!linear);     // big tile: the bias / scale vectors are fetched after the K loop (16-24 registers it cannot spare)
   float* sc = reinterpret_cast<float*>(smem);
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -465,8 +497,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // fast tiles: no per-thread predicates at all, only workgroup-uniform branches -- the general loop below costs ~500 instructions
   // per 16-B store, this one under 100
   if (fast) {
-    bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + n0 + ec * 8;
-    bf16_t* const yl = reinterpret_cast<bf16_t*>(p.y) + lin_off + (long long)r0e * p.N;
+    bf16_t* const yb = reinterpret_cast<bf16_t*>(g_y) + n0 + ec * 8;
+    bf16_t* const yl = reinterpret_cast<bf16_t*>(g_y) + lin_off + (long long)r0e * p.N;
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
       const int row = er + it * (NT / NCH);
@@ -487,8 +519,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
-      if (OPS > 0 && p.mask) {
-        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(p.mask + eoff);
+      if (OPS > 0 && g_mask) {
+        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + eoff);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }
@@ -526,8 +558,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
       }
-      if (OPS > 0 && p.mask) {
-        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(p.mask + off);
+      if (OPS > 0 && g_mask) {
+        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }
@@ -542,7 +574,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
       for (int j = 0; j < 8; ++j) csum[j] += v[j];
       if (p.out_f32) {
-        float* o = reinterpret_cast<float*>(p.y) + off;
+        float* o = reinterpret_cast<float*>(g_y) + off;
         if ((p.N & 3) == 0) {
           *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
           *reinterpret_cast<f32x4*>(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -554,7 +586,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         bf16x8 ov;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off) = ov;
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(g_y) + off) = ov;
       }
       if (p.zraw) {
         bf16x8 zv;
@@ -567,14 +599,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         const long long off = drow * p.N + n + j;
         float u = v[j];
         if (p.pre_scale) u *= p.pre_scale[n + j];
-        if (p.pre_shift) u += p.pre_shift[n + j];
+        if (g_shift) u += g_shift[n + j];
         if (p.res) u += (float)p.res[off];
-        if (p.mask) u = ((float)p.mask[off] > 0.f) ? u : 0.f;
+        if (g_mask) u = ((float)g_mask[off] > 0.f) ? u : 0.f;
         if (p.post_scale) u *= p.post_scale[n + j];
         if (p.relu) u = fmaxf(u, 0.f);
         csum[j] += u;
-        if (p.out_f32) reinterpret_cast<float*>(p.y)[off] = u;
-        else reinterpret_cast<bf16_t*>(p.y)[off] = (bf16_t)u;
+        if (p.out_f32) reinterpret_cast<float*>(g_y)[off] = u;
+        else reinterpret_cast<bf16_t*>(g_y)[off] = (bf16_t)u;
         if (p.zraw) p.zraw[off] = (bf16_t)raw[j];
       }
     }
@@ -588,7 +620,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   if (g_tile_stamps && threadIdx.x == 0)
     g_tile_stamps[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 #endif
-  if (p.colsum) {
+  if (g_colsum) {
     // column sums of this tile: per-thread partials -> LDS [NT / NCH][BN] -> one fp32 atomic per column
     __syncthreads();
     float* sr = reinterpret_cast<float*>(smem);
@@ -598,12 +630,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     if (t < BN && n0 + t < p.N) {
       float s = 0.f;
       for (int r = 0; r < NT / NCH; ++r) s += sr[r * BN + t];
-      atomicAdd(p.colsum + n0 + t, s);
+      atomicAdd(g_colsum + n0 + t, s);
     }
   }
 }
 
-template <int BM, int BN, int NT = 256, int OPS = 2>
+#undef g_y
+#undef g_mask
+#undef g_colsum
+#undef AOD_GSEL
+
+template <int BM, int BN, int NT = 256, int OPS = 2, bool GROUPED = false>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
   ConvKParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
@@ -614,10 +651,10 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS>), dim3(q.tiles_m * q.tiles_n * q.ksplit), dim3(NT), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
   return 0;
 }
 
@@ -762,6 +799,7 @@ static int conv_params(const aod_conv_desc_t* desc, const void* src, const void*
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
   p.ksplit = 1;
+  { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
   p.perm = (desc->transposed && desc->stride == 2 && desc->R * desc->S > 1 && desc->R * desc->S <= 64) ? 1 : 0;     // (no gain measured for 1x1)
   static const char* dbg_perm = getenv("AOD_DGRAD_CLASSES");
   if (dbg_perm && dbg_perm[0] == '0') p.perm = 0;
@@ -839,6 +877,45 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
   else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) launch_conv<128, 64>(p, st);
   else launch_conv<64, 64>(p, st);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, const void* const* src, const void* const* w_packed,
+                                  void* const* dst, const float* const* pre_shift, const void* const* mask, float* const* colsum,
+                                  aod_stream_t stream) {
+  AOD_CHECK_ARG(desc && src && w_packed && dst && ngroups >= 1 && ngroups <= 4, "conv_grouped: 1..4 groups");
+  AOD_CHECK_ARG(!desc->out_f32, "conv_grouped: bf16 destinations only");
+  ConvKParams p;
+  int rc = conv_params(desc, src[0], w_packed[0], dst[0], nullptr, pre_shift ? pre_shift[0] : nullptr, nullptr, mask ? mask[0] : nullptr, nullptr,
+                       nullptr, colsum ? colsum[0] : nullptr, p);
+  if (rc) return rc;
+  if (p.M == 0) return 0;
+  AOD_CHECK_ARG(!p.perm, "conv_grouped: class-major stride-2 dgrad launches are not grouped");
+  p.ngroups = ngroups;
+  bool any_mask = false;
+  for (int g = 0; g < ngroups; ++g) {
+    AOD_CHECK_ARG(src[g] && w_packed[g] && dst[g], "conv_grouped: null operand in group %d", g);
+    p.grp[g].x = (const bf16_t*)src[g]; p.grp[g].w = (const bf16_t*)w_packed[g]; p.grp[g].y = dst[g];
+    p.grp[g].pre_shift = pre_shift ? pre_shift[g] : nullptr;
+    p.grp[g].mask = mask ? (const bf16_t*)mask[g] : nullptr;
+    p.grp[g].colsum = colsum ? colsum[g] : nullptr;
+    any_mask = any_mask || p.grp[g].mask;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // the tile whose grouped tile count fills the CU rounds best: 256 x 256 at one workgroup per CU, else 128 x 128 on 8 waves at two
+  auto fill = [&](int bm, int bn, int slots) {
+    const long long t = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * ngroups;
+    return (double)t / (double)(((t + slots - 1) / slots) * slots);
+  };
+  static const char* dbg_t256 = getenv("AOD_TILE_256");
+  const bool ok256 = !(dbg_t256 && dbg_t256[0] == '0') && p.N % 256 == 0 && p.K >= 1024;
+  if (ok256 && fill(256, 256, 256) * 1.12 >= fill(128, 128, 512)) {        // (the big tile is ~15 % faster per FLOP when its rounds are full)
+    if (!any_mask) launch_conv<256, 256, 512, 0, true>(p, st); else launch_conv<256, 256, 512, 1, true>(p, st);
+  } else {
+    AOD_CHECK_ARG(p.N >= 128, "conv_grouped: N >= 128 required");
+    if (!any_mask) launch_conv<128, 128, 512, 0, true>(p, st); else launch_conv<128, 128, 512, 1, true>(p, st);
+  }
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -357,6 +357,22 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
     return outs[0] if single else list(outs)
 
 
+def conv_towers_nograd(xss, convs, relu=True):
+    """Inference-only: the same-depth convs of several head towers (list of parameter holders with .weight / .bias, identical shape)
+    applied to their own level lists `xss[g]` in ONE grouped launch (hipops.conv2d_rows_grouped): cls / reg / evidence towers of the
+    scoring pass.  Returns one level list per tower."""
+    assert not torch.is_grad_enabled() and _PREC == 'bf16'
+    G = len(convs)
+    rows, segs = zip(*[multi_rows(list(xs)) for xs in xss])
+    assert all(sg == segs[0] for sg in segs), 'towers must see the same pyramid geometry'
+    w0 = convs[0].weight
+    O, I, R, S = w0.shape
+    pis = [PREP.get(c.weight, None, rows[0].shape[1], 0.0) for c in convs]
+    outs, dsegs = ho.conv2d_rows_grouped(list(rows), list(segs[0]), [pi.wf for pi in pis], O, R, S, convs[0].stride[0], convs[0].padding[0],
+                                         convs[0].dilation[0], pre_shifts=[c.bias.detach() if c.bias is not None else None for c in convs], relu=relu)
+    return [[as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for s in dsegs] for o in outs]
+
+
 # --------------------------------------------------------------------------- stem helpers
 def image_to_nhwc(img, cpad=8):
     """fp32 NCHW image batch -> bf16 NHWC rows viewed as [B, cpad, H, W] (no grad: images are leaves)."""

@@ -139,6 +139,24 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
+def conv2d_rows_grouped(xs, src_segs, ws, N, R, S, stride=1, pad=0, dil=1, *, pre_shifts=None, relu=False, outs=None):
+    """G forward convs of identical geometry in ONE launch (aod_conv2d_grouped): xs / ws / pre_shifts / outs are lists of G row tensors
+    (inputs may be the same tensor), `src_segs` the shared segment list.  Returns (list of outputs, dst_segs)."""
+    G = len(xs)
+    Cin = xs[0].shape[1]
+    dst_segs = out_segs(src_segs, R, S, stride, pad, dil)
+    rows = sum(s.rows for s in dst_segs)
+    if outs is None:
+        outs = [torch.empty(rows, N, dtype=torch.bfloat16, device=xs[0].device) for _ in range(G)]
+    d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, False)
+    arr = lambda ts: (C.c_void_p * G)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    for t in list(xs) + list(ws) + list(outs):
+        ptr(t)                                   # (refuses CPU tensors)
+    call('aod_conv2d_grouped', C.byref(d), G, arr(xs), arr(ws), arr(outs), arr(pre_shifts) if pre_shifts is not None else None, None, None,
+         stream())
+    return outs, dst_segs
+
+
 def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,
                       post_scale=None, out=None, x_rows_total=None, colsum=None, alg=None, out_f32=False):
     """dX = conv_transpose(dZ, W).  dz_rows [rows_out, Npad]; w_dgrad [Cin][R][S][Npad].

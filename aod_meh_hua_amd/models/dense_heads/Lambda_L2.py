@@ -108,10 +108,25 @@ class Lambda_L2Net(L_AnchorHead):
         return s * (5.0 / loss.numel()), 0
 
     # ------------------------------------------------------------------ scoring
+    def forward_all_towers(self, feats):
+        """Scoring pass (no autograd): forward + forward_L (Lambda_L2.py:79-103) with the three towers advanced together -- the convs
+        of one depth are ONE grouped launch (functional.conv_towers_nograd), whose 3 x 341 tiles fill whole rounds of the CUs."""
+        feats = list(feats)
+        c, r, l = feats, feats, feats
+        for cc, rc, lc in zip(self.cls_convs, self.reg_convs, self.L_convs):
+            c, r, l = AF.conv_towers_nograd([c, r, l], [cc.conv, rc.conv, lc.conv], relu=True)
+        outs = (self.retina_cls(c, out_f32=True), self.retina_reg(r, out_f32=True))
+        return outs, self.retina_L(l, relu=True, out_f32=True)
+
     def simple_test(self, feats, img_metas, rescale=False, **kwargs):
         """Lambda_L2.py:398-420."""
-        outs = self.forward(feats)
-        L_scores = self.forward_L(feats, head_out=None)
+        import os
+        if (not torch.is_grad_enabled() and AF.get_precision() == 'bf16' and os.environ.get('AOD_GROUP_TOWERS', '1') != '0'
+                and len(self.cls_convs) == len(self.reg_convs) == len(self.L_convs) > 0 and all(m.with_activation for m in self.cls_convs)):
+            outs, L_scores = self.forward_all_towers(feats)
+        else:
+            outs = self.forward(feats)
+            L_scores = self.forward_L(feats, head_out=None)
         if not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_NoNMS':
             results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, with_nms=False, **kwargs)
         elif not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_ALL':

@@ -82,6 +82,14 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
                   const float* post_scale, void* zraw, float* colsum, void* workspace, size_t workspace_bytes,
                   aod_stream_t stream);
 
+/* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
+ * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).
+ * Alone each tower conv leaves a third of its last round of workgroups idle; together their tiles fill whole rounds (3 x 341 tiles of
+ * 256 x 256 = 3.996 rounds of the 256 CUs).  bf16 destinations; pre_shift / mask / colsum arrays (or their entries) may be NULL; a
+ * dgrad descriptor (transposed = 1, stride 1) is accepted.  Results are bit-identical to `ngroups` aod_conv2d calls. */
+int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, const void* const* src, const void* const* w_packed, void* const* dst,
+                       const float* const* pre_shift, const void* const* mask, float* const* colsum, aod_stream_t stream);
+
 /* replaces: the weight-gradient half of autograd's conv backward (cuDNN wgrad) for the same
  * call sites.  dw_f32 is [N][R][S][C] fp32 and is ACCUMULATED into (caller zeroes it);
  * x: forward input [rows, C] bf16; dz: [rows_out, N] bf16. */

@@ -159,3 +159,23 @@ def test_train_step_with_an_image_without_ground_truth(built):
     model.zero_grad()
     out['loss'].backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_grouped_tower_launch_equals_the_separate_towers(built):
+    """Scoring pass: the cls / reg / evidence towers advance together, one grouped launch per depth (aod_conv2d_grouped, 256 x 256 tiles when
+    the three towers' tiles fill whole CU rounds); same K order per output element -> bit-identical to the three separate stacks."""
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    head = model.bbox_head
+    for B, H in ((2, 128), (16, 512)):
+        g = synth.gen(77 + B)
+        feats = [torch.randn(B, 256, max(H // s, 1), max(H // s, 1), generator=g).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+                 for s in (8, 16, 32, 64, 128)]
+        with torch.no_grad():
+            (c1, r1), l1 = head.forward_all_towers(feats)
+            c0, r0 = head.forward(feats)
+            l0 = head.forward_L(feats)
+        torch.cuda.synchronize()
+        for a, b in zip(list(c1) + list(r1) + list(l1), list(c0) + list(r0) + list(l0)):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert float(c1[0].float().abs().mean()) > 0
