@@ -195,6 +195,37 @@ class ActSlot:
         self.res_ok, self.res_grad = False, None
 
 
+def _grad_rows(gouts, y_segs, O, device):
+    """the upstream gradient of a (level-batched) conv as one dense row tensor [M, O]"""
+    if len(gouts) == 1 and gouts[0] is not None:
+        return as_rows(gouts[0])
+    parts = []
+    for g, s in zip(gouts, y_segs):
+        parts.append(as_rows(g) if g is not None else torch.zeros(s.rows, O, device=device, dtype=torch.bfloat16))
+    dt = torch.float32 if any(p.dtype == torch.float32 for p in parts) else torch.bfloat16
+    # the level gradients usually ARE adjacent slices of one buffer (the dX of the next tower conv): view, don't copy
+    rb = O * parts[0].element_size()
+    adjacent = all(p.dtype == dt and p.is_contiguous() for p in parts) and all(
+        parts[i + 1].data_ptr() == parts[i].data_ptr() + parts[i].shape[0] * rb for i in range(len(parts) - 1))
+    if adjacent:
+        return torch.as_strided(parts[0], (sum(p.shape[0] for p in parts), O), (O, 1))
+    return torch.cat([p.to(dt) for p in parts])
+
+
+def _grad_slice(w, device):
+    """data parallelism (parallel.GradSync.attach): the weight gradient is unpacked straight into this parameter's slice of the flat
+    all-reduce buffer; autograd installs the returned slice as .grad, so the all-reduce runs in place.  A second use of the same weight
+    inside one backward pass gets a fresh tensor (autograd then adds it into the slice)."""
+    dst = getattr(w, '_aod_grad_view', None)
+    if dst is not None and (w.__dict__.get('_aod_view_busy') or dst.device != device
+                            or (w.grad is not None and w.grad.data_ptr() == dst.data_ptr())):
+        dst = None          # (.grad already IS the slice and was not reset to None: autograd will add into it)
+    if dst is not None:
+        w._aod_view_busy = True
+        dst = dst.detach()  # a tensor object of its own on the same memory: autograd installs it as .grad without a copy
+    return dst
+
+
 class ConvFn(Function):
     """y = act(conv(x, w) * scale + shift + res) over one or several pyramid levels sharing `w`.
 
@@ -230,22 +261,7 @@ class ConvFn(Function):
         O, I, R, S = w.shape
         cin = x_rows.shape[1]
         y_segs = ctx.y_segs
-        # gather the upstream gradient as one dense row tensor [M, O]
-        if len(gouts) == 1 and gouts[0] is not None:
-            g_rows = as_rows(gouts[0])
-        else:
-            parts = []
-            for g, s in zip(gouts, y_segs):
-                parts.append(as_rows(g) if g is not None else torch.zeros(s.rows, O, device=w.device, dtype=torch.bfloat16))
-            dt = torch.float32 if any(p.dtype == torch.float32 for p in parts) else torch.bfloat16
-            # the level gradients usually ARE adjacent slices of one buffer (the dX of the next tower conv): view, don't copy
-            rb = O * parts[0].element_size()
-            adjacent = all(p.dtype == dt and p.is_contiguous() for p in parts) and all(
-                parts[i + 1].data_ptr() == parts[i].data_ptr() + parts[i].shape[0] * rb for i in range(len(parts) - 1))
-            if adjacent:
-                g_rows = torch.as_strided(parts[0], (sum(p.shape[0] for p in parts), O), (O, 1))
-            else:
-                g_rows = torch.cat([p.to(dt) for p in parts])
+        g_rows = _grad_rows(gouts, y_segs, O, w.device)
         dsegs = dense_segs(y_segs)
         Opad = (O + 7) // 8 * 8
         need_w = ctx.needs_input_grad[1]
@@ -284,16 +300,7 @@ class ConvFn(Function):
         x_segs = ctx.x_segs
         if need_w or need_bn:
             dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'], alg=(I, O))
-            # data parallelism (parallel.GradSync.attach): the weight gradient is unpacked straight into this parameter's slice of the
-            # flat all-reduce buffer; autograd installs the returned slice as .grad, so the all-reduce runs in place.  A second use of the
-            # same weight inside one backward pass gets a fresh tensor (autograd then adds it into the slice).
-            dst = getattr(w, '_aod_grad_view', None) if need_w else None
-            if dst is not None and (w.__dict__.get('_aod_view_busy') or dst.device != dw.device
-                                    or (w.grad is not None and w.grad.data_ptr() == dst.data_ptr())):
-                dst = None          # (.grad already IS the slice and was not reset to None: autograd will add into it)
-            if dst is not None:
-                w._aod_view_busy = True
-                dst = dst.detach()  # a tensor object of its own on the same memory: autograd installs it as .grad without a copy
+            dst = _grad_slice(w, dw.device) if need_w else None
             if need_bn:
                 gw, ggamma = ho.unpack_wgrad(dw, O, I, grad_oihw=dst, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
                 gbeta = s1
@@ -355,6 +362,102 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
         for o in outs:
             o._aod_slot = meta['slot']
     return outs[0] if single else list(outs)
+
+
+class ConvPairFn(Function):
+    """Two same-shape tower convs (conv + bias + ReLU, bf16, stride 1; Lambda_L2.py:85-94: cls_convs[i] and reg_convs[i]) as ONE grouped
+    launch forward and ONE grouped dgrad launch backward (aod_conv2d_grouped): alone each leaves a third of its last round of workgroups
+    idle, together their 2 x 341 tiles of 256 x 256 run at the big tile's rate.  Same results as two ConvFn calls, same ActSlot protocol
+    (the consumer's dgrad epilogue performs the producer's ReLU backward + bias column sums).
+
+    forward(ctx, meta, wA, bA, wB, bB, *xsA, *xsB) -> (*ysA, *ysB)"""
+
+    @staticmethod
+    def forward(ctx, meta, wA, bA, wB, bB, *xs):
+        nl = len(xs) // 2
+        O, I, R, S = wA.shape
+        rows, segs = zip(multi_rows(xs[:nl]), multi_rows(xs[nl:]))
+        assert segs[0] == segs[1] and wB.shape == wA.shape, 'paired tower convs need identical geometry'
+        cin = rows[0].shape[1]
+        pis = [PREP.get(w, None, cin, 0.0) for w in (wA, wB)]
+        outs, y_segs = ho.conv2d_rows_grouped(list(rows), list(segs[0]), [pi.wf for pi in pis], O, R, S, 1, meta['pad'], meta['dil'],
+                                              pre_shifts=[bA.detach(), bB.detach()], relu=True, alg=(I, O))
+        ctx.meta, ctx.x_segs, ctx.y_segs, ctx.nl = meta, list(segs[0]), y_segs, nl
+        ctx.save_for_backward(wA, wB, rows[0], rows[1], outs[0], outs[1])
+        return tuple(as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for o in outs for s in y_segs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        wA, wB, xA, xB, yA, yB = ctx.saved_tensors
+        meta, nl, y_segs, x_segs = ctx.meta, ctx.nl, ctx.y_segs, ctx.x_segs
+        O, I, R, S = wA.shape
+        dsegs, xd = dense_segs(y_segs), dense_segs(x_segs)
+        dzs, gws, gbs = [], [], []
+        for gi, (w, x_rows, a_rows) in enumerate(((wA, xA, yA), (wB, xB, yB))):
+            g_rows = _grad_rows(gouts[gi * nl:(gi + 1) * nl], y_segs, O, w.device)
+            slot = meta['slot'][gi]
+            if slot is not None and slot.masked and g_rows.dtype == torch.bfloat16:
+                dz, s1 = g_rows, slot.s1                      # the consumer's dgrad epilogue already did the activation backward
+                slot.masked, slot.s1 = False, None
+            else:
+                dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=True, want_gm=False, want_dz=True)
+            dzs.append(dz)
+            gbs.append(s1[:O] if ctx.needs_input_grad[2 + 2 * gi] else None)
+            gw = None
+            if ctx.needs_input_grad[1 + 2 * gi]:
+                dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, 1, meta['pad'], meta['dil'], alg=(I, O))
+                gw = ho.unpack_wgrad(dw, O, I, grad_oihw=_grad_slice(w, dw.device))
+            gws.append(gw)
+        gxs = [None] * (2 * nl)
+        need = [any(ctx.needs_input_grad[5 + gi * nl:5 + (gi + 1) * nl]) for gi in range(2)]
+        if any(need):
+            assert all(need), 'paired tower convs: both inputs need gradients or neither'
+            wds = [PREP.get(w, None, xA.shape[1], 0.0).wd for w in (wA, wB)]
+            dense = all(a.row0 == b.row0 for a, b in zip(x_segs, xd))
+            in_slots = meta['in_slot']
+            fuse = [sl is not None and dense for sl in in_slots]
+            assert all(sl is None or sl.res_grad is None for sl in in_slots)
+            s1_in = [ho.zeros_f32(I, dzs[0].device) if f else None for f in fuse]
+            dxs = ho.conv2d_dgrad_rows_grouped(dzs, dsegs, xd, wds, I, R, S, 1, meta['pad'], meta['dil'],
+                                               masks=[xA if fuse[0] else None, xB if fuse[1] else None], colsums=s1_in, alg=(I, O))
+            for gi in range(2):
+                if fuse[gi]:
+                    in_slots[gi].masked, in_slots[gi].s1 = True, s1_in[gi]
+                for i, s in enumerate(xd):
+                    gxs[gi * nl + i] = as_nchw(dxs[gi][s.row0:s.row0 + s.rows], s.B, s.H, s.W)
+        return (None, gws[0], gbs[0], gws[1], gbs[1]) + tuple(gxs)
+
+
+def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False):
+    """cls / reg tower convs of one depth (ConvModule.conv holders: weight, bias, padding, dilation) on their own level lists; falls back to
+    two conv_bn_act calls whenever the grouped form does not apply."""
+    import os
+    wA, wB = convA.weight, convB.weight
+    ok = (_PREC == 'bf16' and os.environ.get('AOD_GROUP_TOWERS', '1') != '0' and wA.shape == wB.shape and wA.shape[0] % 8 == 0
+          and wA.shape[0] >= 128 and convA.bias is not None and convB.bias is not None and convA.stride[0] == convB.stride[0] == 1
+          and convA.padding == convB.padding and convA.dilation == convB.dilation and len(xsA) == len(xsB)
+          and all(a.shape == b.shape and a.dtype == torch.bfloat16 for a, b in zip(xsA, xsB)))
+    if not ok:
+        return (conv_bn_act(list(xsA), wA, bias=convA.bias, pad=convA.padding[0], dil=convA.dilation[0], relu=True, sole_consumer=sole_consumer),
+                conv_bn_act(list(xsB), wB, bias=convB.bias, pad=convB.padding[0], dil=convB.dilation[0], relu=True, sole_consumer=sole_consumer))
+    meta = dict(pad=convA.padding[0], dil=convA.dilation[0], slot=[None, None], in_slot=[None, None])
+    grad = torch.is_grad_enabled()
+    if grad:
+        meta['slot'] = [ActSlot(), ActSlot()]
+        if sole_consumer and _FUSE_ACT:
+            for gi, xl in enumerate((xsA, xsB)):
+                slots = [getattr(x, '_aod_slot', None) for x in xl]
+                if slots[0] is not None and all(sl is slots[0] for sl in slots) and all(x.requires_grad for x in xl):
+                    meta['in_slot'][gi] = slots[0]
+                    slots[0].res_ok = False
+    outs = ConvPairFn.apply(meta, wA, convA.bias, wB, convB.bias, *xsA, *xsB)
+    nl = len(xsA)
+    ya, yb = list(outs[:nl]), list(outs[nl:])
+    if grad:
+        for gi, ys in enumerate((ya, yb)):
+            for o in ys:
+                o._aod_slot = meta['slot'][gi]
+    return ya, yb
 
 
 def conv_towers_nograd(xss, convs, relu=True):

@@ -139,7 +139,7 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     return (out, dst_segs, z) if save_z else (out, dst_segs)
 
 
-def conv2d_rows_grouped(xs, src_segs, ws, N, R, S, stride=1, pad=0, dil=1, *, pre_shifts=None, relu=False, outs=None):
+def conv2d_rows_grouped(xs, src_segs, ws, N, R, S, stride=1, pad=0, dil=1, *, pre_shifts=None, relu=False, outs=None, alg=None):
     """G forward convs of identical geometry in ONE launch (aod_conv2d_grouped): xs / ws / pre_shifts / outs are lists of G row tensors
     (inputs may be the same tensor), `src_segs` the shared segment list.  Returns (list of outputs, dst_segs)."""
     G = len(xs)
@@ -152,9 +152,35 @@ def conv2d_rows_grouped(xs, src_segs, ws, N, R, S, stride=1, pad=0, dil=1, *, pr
     arr = lambda ts: (C.c_void_p * G)(*[(t.data_ptr() if t is not None else None) for t in ts])
     for t in list(xs) + list(ws) + list(outs):
         ptr(t)                                   # (refuses CPU tensors)
-    call('aod_conv2d_grouped', C.byref(d), G, arr(xs), arr(ws), arr(outs), arr(pre_shifts) if pre_shifts is not None else None, None, None,
-         stream())
+    keep = [arr(xs), arr(ws), arr(outs), arr(pre_shifts) if pre_shifts is not None else None]
+    if PROFILE is None:
+        call('aod_conv2d_grouped', C.byref(d), G, keep[0], keep[1], keep[2], keep[3], None, None, stream())
+    else:                                       # (profiling: the G groups count as G launches' worth of FLOPs in one record)
+        for _ in range(1):
+            _prof('fwd', d, lambda: call('aod_conv2d_grouped', C.byref(d), G, keep[0], keep[1], keep[2], keep[3], None, None, stream()),
+                  (alg[0] * G, alg[1]) if alg is not None else (Cin * G, N))
     return outs, dst_segs
+
+
+def conv2d_dgrad_rows_grouped(dzs, dz_segs, x_segs, wds, Cin, R, S, stride=1, pad=0, dil=1, *, masks=None, colsums=None, alg=None):
+    """G dgrads of identical geometry in one launch: dX_g = conv_T(dZ_g, W_g) (* [mask_g > 0], column sums into colsums[g])."""
+    G = len(dzs)
+    Npad = dzs[0].shape[1]
+    rows = sum(s.rows for s in x_segs)
+    outs = [torch.empty(rows, Cin, dtype=torch.bfloat16, device=dzs[0].device) for _ in range(G)]
+    d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
+    arr = lambda ts: (C.c_void_p * G)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    for t in list(dzs) + list(wds) + outs:
+        ptr(t)
+    keep = [arr(dzs), arr(wds), arr(outs), arr(masks) if masks is not None else None, arr(colsums) if colsums is not None else None]
+    fn = lambda: call('aod_conv2d_grouped', C.byref(d), G, keep[0], keep[1], keep[2], None, keep[3], keep[4], stream())
+    if PROFILE is None:
+        fn()
+    else:
+        _prof('dgrad', d, fn, (alg[0] * G, alg[1]) if alg is not None else (Npad * G, Cin))
+    return outs
+
+
 
 
 def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pad=0, dil=1, *, res=None, mask=None,

@@ -60,10 +60,15 @@ class Lambda_L2Net(L_AnchorHead):
         """Lambda_L2.py:79-94, all levels per launch.  Returns (cls_scores[L], bbox_preds[L]) fp32 [B, A*C, h, w]."""
         feats = list(feats)
         cls_feat, reg_feat = feats, feats
-        for i, conv in enumerate(self.cls_convs):          # every tower activation has exactly one consumer (the next conv)
-            cls_feat = conv(cls_feat, sole_consumer=i > 0)
-        for i, conv in enumerate(self.reg_convs):
-            reg_feat = conv(reg_feat, sole_consumer=i > 0)
+        if len(self.cls_convs) == len(self.reg_convs) and all(m.with_activation for m in list(self.cls_convs) + list(self.reg_convs)):
+            # the two towers advance together: one grouped launch per depth (functional.ConvPairFn)
+            for i, (cc, rc) in enumerate(zip(self.cls_convs, self.reg_convs)):          # every tower activation has exactly one consumer
+                cls_feat, reg_feat = AF.conv_pair_act(cls_feat, reg_feat, cc.conv, rc.conv, sole_consumer=i > 0)
+        else:
+            for i, conv in enumerate(self.cls_convs):
+                cls_feat = conv(cls_feat, sole_consumer=i > 0)
+            for i, conv in enumerate(self.reg_convs):
+                reg_feat = conv(reg_feat, sole_consumer=i > 0)
         return (self.retina_cls(cls_feat, out_f32=True, sole_consumer=len(self.cls_convs) > 0),
                 self.retina_reg(reg_feat, out_f32=True, sole_consumer=len(self.reg_convs) > 0))
 
