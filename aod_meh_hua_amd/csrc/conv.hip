@@ -994,7 +994,7 @@ struct WgradParams {
   const RowRec* tab;
   int C, N, K, R, S, dil;
   int M;
-  int tiles_n, tiles_k, splits, rows_per_split;
+  int tiles_n, tiles_k, splits, rows_per_split, stagger;
   long long x_bytes, z_bytes, tab_bytes;
   long long slab_stride;     // > 0: split s STORES its partial tile into dw + s * slab_stride (deterministic, summed by the unpack); 0: fp32 atomics
 };
@@ -1094,8 +1094,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   __syncthreads();
   // transposed-read lane roles: group g = lane>>4 covers k rows 8g..8g+7 of a 32-row sub-step; lane 4q+pp -> row q, cols 4pp..4pp+3
   const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  // stagger (8-wave form): waves 4-7 run half a step behind waves 0-3, with which they share their SIMDs (see conv_igemm_kernel)
+  const bool late = p.stagger && NW == 8 && uw >= 4;
+  bool carried = false;
+  bf16x8 af[4], bfr[NJ];
+  auto frag_read = [&](const char* sz, const char* sx, int ks) {
+    const int r0 = ks * 32 + 8 * g + q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = wm * 64 + i * 16 + pp * 4;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0, col >> 3) + (col & 7) * 2));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
+      af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = wn * (16 * NJ) + j * 16 + pp * 4;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
+      bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto mfma_block = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  };
   for (int stp = 0; stp < nsteps; ++stp) {
     const int cur = stp & 1;
+    if (late && carried) mfma_block();
     if (stp + 1 < nsteps) {
       rread((stp + 1) & 1);                                 // landed before the previous barrier
       gload(ms + (stp + 1) * BKM, cur ^ 1);
@@ -1104,36 +1137,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     if (stp + 2 < nsteps) tdma(ms + (stp + 2) * BKM, stp & 1);
     const char* sz = smem + cur * STAGE;
     const char* sx = sz + IMG;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[NJ];
-      const int r0 = ks * 32 + 8 * g + q;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = wm * 64 + i * 16 + pp * 4;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0, col >> 3) + (col & 7) * 2));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = wn * (16 * NJ) + j * 16 + pp * 4;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-        bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    frag_read(sz, sx, 0);
+    mfma_block();
+    frag_read(sz, sx, 1);
+    if (!late) mfma_block(); else carried = true;
     __syncthreads();
   }
+  if (late && carried) mfma_block();
   // slab mode: every pixel split owns a slab and STORES its partial tile (plain dword stores run at ~6 TB/s chip-wide, float atomics at
   // ~1.3 TB/s: 512 workgroups x 64 KB of atomics were a 25 us tail on every launch); the unpack kernel adds the slabs in split order,
   // so the weight gradient no longer depends on arrival order.  Otherwise: accumulate into dW[n][kk] with fp32 atomics (one dword per
@@ -1214,6 +1224,7 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   const int tiles = p.tiles_n * p.tiles_k;
   p.splits = splits; p.rows_per_split = rps;
   p.slab_stride = slab_stride;
+  { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
   if (slab_stride > 0) {
     AOD_CHECK_ARG(splits <= max_slabs, "wgrad: %d slabs needed, %d provided (aod_conv2d_wgrad_splits)", splits, max_slabs);
     AOD_CHECK_ARG(slab_stride >= (long long)p.N * p.K, "wgrad: slab stride smaller than N*K");
