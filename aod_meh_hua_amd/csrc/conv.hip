@@ -11,6 +11,7 @@
 //   their ROW index, so the LDS images keep the global row-major form and fragments are read
 //   with ds_read_b64_tr_b16 (hardware transpose); split over m across workgroups, fp32 atomics.
 #include "common.h"
+#include "pointwise.h"
 
 struct ConvGroup { const bf16_t* x; const bf16_t* w; void* y; const float* pre_shift; const bf16_t* mask; float* colsum; };
 struct ConvKParams {
@@ -833,6 +834,16 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   if (rc) return rc;
   if (p.M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // 1x1, stride 1: a plain GEMM over consecutive rows -- the persistent streaming kernel (pointwise.hip) when its launch heuristic wants it
+  if (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && !p.out_f32 && !p.zraw && !p.post_scale) {
+    PwArgs a;
+    const long long s0 = p.seg_src0[0], d0 = p.seg_dst0[0];
+    a.x = p.x + s0 * p.C; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y) + d0 * p.N;
+    a.pre_scale = p.pre_scale; a.pre_shift = p.pre_shift;
+    a.res = p.res ? p.res + d0 * p.N : nullptr; a.mask = p.mask ? p.mask + d0 * p.N : nullptr; a.colsum = p.colsum;
+    a.M = p.M; a.N = p.N; a.K = p.C; a.relu = p.relu;
+    if (aod_pw_wants(a)) return aod_pw_gemm(a, st);
+  }
   const int ks = (workspace && !p.perm) ? choose_ksplit(p) : 1;
   if (ks > 1) {
     const size_t need = (size_t)ks * p.M * p.N * 4;
@@ -1004,21 +1015,24 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
   return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-// dW[n][kk] += sum_m dZ[m][n] * X[pix(m, tap(kk))][c(kk)]: 128 x 128 output tile per workgroup, 64 pixels per step.
-// Both LDS images keep the global row-major form ([pixel][128 columns], 256-B rows) and are filled by LDS-DMA:
-// one wave-instruction = 4 pixel rows x 16 chunks, the conflict-avoiding XOR applied on the SOURCE chunk index,
-// which is the same for the 4 rows a lane serves -> every lane owns ONE fixed (tap, channel-chunk) column.
-// NW waves per workgroup (4 or 8): the 128 x 128 dW tile is split 2 x 2 (64 x 64 per wave) or 2 x 4 (64 x 32 per wave); the 8-wave form
-// puts four waves on a SIMD instead of two.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
+// dW[n][kk] += sum_m dZ[m][n] * X[pix(m, tap(kk))][c(kk)]: (128 TN) x (128 TK) output tile per workgroup, 64 pixels per step.
+// Both operands are staged as 128-column SUB-IMAGES that keep the global row-major form ([pixel][128 columns], 256-B rows), TN of dZ and
+// TK of X per stage, filled by LDS-DMA: one wave-instruction = 4 pixel rows x 16 chunks, the conflict-avoiding XOR applied on the SOURCE
+// chunk index, which is the same for the 4 rows a lane serves -> every lane owns ONE fixed (tap, channel-chunk) column per sub-image.
+// NW waves per workgroup (4 or 8).  128 x 128 tile: split 2 x 2 (64 x 64 per wave) or 2 x 4 (64 x 32 per wave), two workgroups per
+// CU.  256 x 256 tile (TN = TK = 2, 8 waves as 2 x 4, 128 x 64 per wave, one workgroup per CU): the fragment reads are 8-B transposed
+// reads, so the 128 x 128 form moves 768 B of LDS per MFMA -- more than the LDS delivers at the matrix pipe's rate; the big tile halves
+// that (and the LDS-DMA traffic per MFMA), like the 256 x 256 tile of the forward kernel.
+template <int NW, int TN, int TK>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int RPW = 4 * NW;          // pixel rows covered per pass of all waves
   constexpr int PASSES = 64 / RPW;
   constexpr int WNC = NW / 2;          // waves along the (tap, channel) axis
-  constexpr int NJ = 8 / WNC;          // 16-column groups per wave along that axis
+  constexpr int NI = 4 * TN;           // 16-row groups per wave along the dZ-channel axis (2 waves along it)
+  constexpr int NJ = 8 * TK / WNC;     // 16-column groups per wave along the (tap, channel) axis
   constexpr int BKM = 64;
-  constexpr int IMG = BKM * 256;
-  constexpr int STAGE = 2 * IMG;
+  constexpr int IMG = BKM * 256;       // one 128-column sub-image
+  constexpr int STAGE = (TN + TK) * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   int bid = blockIdx.x;
   const int split = bid % p.splits; bid /= p.splits;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int n0 = tile_n * (128 * TN), k0 = tile_k * (128 * TK);
   const int ms = split * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   if (ms >= me) return;
@@ -1034,19 +1048,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
   const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group
   const int ch = (lane & 15) ^ ((prow << 2) | (uw & 3));       // source chunk of this lane (fixed)
-  const int zn = n0 + ch * 8;
-  const bool zok = zn < p.N;
-  const int kk = k0 + ch * 8;
-  const bool kok = kk < p.K;
-  const int tap = kok ? kk / p.C : 0, c0 = kok ? kk - tap * p.C : 0;
-  const int tr = tap / p.S, ts = tap - tr * p.S;
-  const int dy = tr * p.dil, dx = ts * p.dil;
-
-  // per-lane constants: byte offset of this lane's (tap, channel chunk) relative to a pixel's top-left tap, and its mask bit
-  const unsigned cdx = (unsigned)((dx * p.C + c0) * 2);
-  const unsigned long long tbit = kok ? (1ull << tap) : 0ull;
-  const unsigned zcol = (unsigned)(zn * 2);
   constexpr unsigned OOB_BASE = 0xf0000000u;
+
+  // per-lane constants of each sub-image: dZ column, and for X the byte offset of the lane's (tap, channel chunk) relative to a pixel's
+  // top-left tap, its row offset and its mask bit
+  unsigned zcol[TN];
+  bool zok[TN];
+#pragma unroll
+  for (int h = 0; h < TN; ++h) {
+    const int zn = n0 + 128 * h + ch * 8;
+    zok[h] = zn < p.N;
+    zcol[h] = (unsigned)(zn * 2);
+  }
+  unsigned cdx[TK];
+  int dy[TK];
+  unsigned long long tbit[TK];
+#pragma unroll
+  for (int h = 0; h < TK; ++h) {
+    const int kk = k0 + 128 * h + ch * 8;
+    const bool kok = kk < p.K;
+    const int tap = kok ? kk / p.C : 0, c0 = kok ? kk - tap * p.C : 0;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    dy[h] = tr * p.dil;
+    cdx[h] = (unsigned)((ts * p.dil * p.C + c0) * 2);
+    tbit[h] = kok ? (1ull << tap) : 0ull;
+  }
   // Row records reach the lanes through LDS: waves 0 and 1 fetch the 64 records of a step with ONE LDS-DMA instruction each (two steps
   // ahead, into a two-slot ring behind the operand stages), every lane then picks its four with ds_read.  Fetching them into VGPRs
   // (global_load) beside the LDS-DMA operand loads made every K-step drain the whole vector-memory queue: 27 % of the kernel.
@@ -1066,22 +1092,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   };
   auto gload = [&](int mbase, int buf) {
     char* sz = smem + buf * STAGE;
-    char* sx = sz + IMG;
+    char* sx = sz + TN * IMG;
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) {
       const int m = mbase + RPW * i + 4 * uw + prow;
       const bool mok = m < me;
       const RowRec r = rec[i];
-      const unsigned zoff = (mok && zok) ? r.zoff + zcol : OOB_BASE;
-      const unsigned xoff = (mok && (r.mask & tbit)) ? r.xrow + (unsigned)dy * r.wc2 + cdx : OOB_BASE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + (RPW * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + (RPW * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < TN; ++h) {
+        const unsigned zoff = (mok && zok[h]) ? r.zoff + zcol[h] : OOB_BASE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + h * IMG + (RPW * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < TK; ++h) {
+        const unsigned xoff = (mok && (r.mask & tbit[h])) ? r.xrow + (unsigned)dy[h] * r.wc2 + cdx[h] : OOB_BASE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + h * IMG + (RPW * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
+      }
     }
   };
 
-  f32x4 acc[4][NJ];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -1097,31 +1129,51 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   // stagger (8-wave form): waves 4-7 run half a step behind waves 0-3, with which they share their SIMDs (see conv_igemm_kernel)
   const bool late = p.stagger && NW == 8 && uw >= 4;
   bool carried = false;
-  bf16x8 af[4], bfr[NJ];
+  // Fragment reads are ISSUED from inline asm: behind the ds_read_tr builtin hipcc (ROCm 7.2) waits vmcnt(0) ahead of the first read of
+  // every step -- i.e. for the LDS-DMA of the NEXT stage issued just above -- which serialises load and compute inside each wave (the
+  // plain ds_read_b128 of the forward kernel does not get that wait).  The asm reads are invisible to the compiler's counters; frag_wait()
+  // is their s_waitcnt and makes every destination opaque, so no MFMA is scheduled above it.
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  u32x2_t alo[NI], ahi[NI], blo[NJ], bhi[NJ];
+  auto tr_read = [&](u32x2_t& dst, const char* ptr) {
+    const unsigned a = (unsigned)(unsigned long long)ptr;       // (the low half of a shared-aperture address is the LDS byte address)
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+  };
   auto frag_read = [&](const char* sz, const char* sx, int ks) {
     const int r0 = ks * 32 + 8 * g + q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int col = wm * 64 + i * 16 + pp * 4;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0, col >> 3) + (col & 7) * 2));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sz + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-      af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int i = 0; i < NI; ++i) {
+      const int col = wm * (16 * NI) + i * 16 + pp * 4;       // column of the dZ stage: sub-image col >> 7
+      const char* im = sz + (col >> 7) * IMG;
+      const int c = col & 127;
+      tr_read(alo[i], im + tr_off(r0, c >> 3) + (c & 7) * 2);
+      tr_read(ahi[i], im + tr_off(r0 + 4, c >> 3) + (c & 7) * 2);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = wn * (16 * NJ) + j * 16 + pp * 4;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0, col >> 3) + (col & 7) * 2));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (__attribute__((address_space(3))) bf16x4*)(sx + tr_off(r0 + 4, col >> 3) + (col & 7) * 2));
-      bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const char* im = sx + (col >> 7) * IMG;
+      const int c = col & 127;
+      tr_read(blo[j], im + tr_off(r0, c >> 3) + (c & 7) * 2);
+      tr_read(bhi[j], im + tr_off(r0 + 4, c >> 3) + (c & 7) * 2);
     }
+  };
+  bf16x8 af[NI], bfr[NJ];
+  auto frag_wait = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4_t){alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]});
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (u32x4_t){blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]});
   };
   auto mfma_block = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
@@ -1136,10 +1188,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     // slot stp & 1 held this step's records; every wave read them one iteration ago (ahead of the barrier), so it can be refilled
     if (stp + 2 < nsteps) tdma(ms + (stp + 2) * BKM, stp & 1);
     const char* sz = smem + cur * STAGE;
-    const char* sx = sz + IMG;
+    const char* sx = sz + TN * IMG;
     frag_read(sz, sx, 0);
+    frag_wait();
     mfma_block();
     frag_read(sz, sx, 1);
+    frag_wait();                                            // (also in the late waves: their reads of this stage end before the barrier)
     if (!late) mfma_block(); else carried = true;
     __syncthreads();
   }
@@ -1152,12 +1206,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
   const bool slab = p.slab_stride > 0;
   const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wm * 64 + i * 16 + lq * 4 + r;
+        const int n = n0 + wm * (16 * NI) + i * 16 + lq * 4 + r;
         const int k = k0 + wn * (16 * NJ) + j * 16 + lr;
 #ifdef AOD_WGRAD_NO_EPI      // ablation build (tools/dbg): how much of the kernel is the atomic epilogue
         if (n < p.N && k < p.K && acc[i][j][r] == 12345.678f) p.dw[(long long)n * p.K + k] = 1.f;
@@ -1174,19 +1228,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
 // MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup ends with
 // 64 KB of output -- fp32 atomics at ~1.3 TB/s chip-wide (0.05 us per workgroup) or, in slab mode, plain stores at ~5.5 TB/s (0.012 us)
 // plus the unpack kernel's read of one more slab per split.
-static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps) {
-  tiles_n = (N + 127) / 128;
-  tiles_k = (K + 127) / 128;
+static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big) {
+  // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
+  static const char* dbg_big = getenv("AOD_WGRAD_256");
+  big = (N % 256 == 0 && K % 256 == 0 && M >= 49152) ? 1 : 0;      // (measured: 16 x 32 x 32 pixels lose 15 %, 16 x 64 x 64 gain 10 %)
+  if (dbg_big && dbg_big[0] == '0') big = 0;
+  const int T = big ? 256 : 128;
+  tiles_n = (N + T - 1) / T;
+  tiles_k = (K + T - 1) / T;
   const int tiles = tiles_n * tiles_k;
   int best = 1;
   double best_cost = 1e30;
-  const int max_s = 512 / tiles > 0 ? 512 / tiles : 1;
+  const int slots = big ? 256 : 512;
+  const int max_s = slots / tiles > 0 ? slots / tiles : 1;
   for (int sp = 1; sp <= max_s; ++sp) {
     const int rows = ((M + sp - 1) / sp + 63) / 64 * 64;
     const int nsp = (M + rows - 1) / rows;
     const int wgs = tiles * nsp;
-    double cost = (rows / 64) * (wgs > 256 ? 1.7 : 1.45);
-    cost += slabs ? wgs * 0.012 + nsp * ((double)N * K * 4.0) / 2.5e6 : wgs * 0.05;
+    double cost = (rows / 64) * (big ? 2.9 : (wgs > 256 ? 1.7 : 1.45));
+    cost += slabs ? wgs * 0.012 * (big ? 4 : 1) + nsp * ((double)N * K * 4.0) / 2.5e6 : wgs * 0.05 * (big ? 4 : 1);
     if (cost < best_cost) { best_cost = cost; best = sp; }
   }
   rps = ((M + best - 1) / best + 63) / 64 * 64;
@@ -1219,8 +1279,8 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   p.z_bytes = zrows * p.N * 2;
   p.tab_bytes = (long long)p.M * (long long)sizeof(RowRec);
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
-  int splits, rps;
-  wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps);
+  int splits, rps, big;
+  wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps, big);
   const int tiles = p.tiles_n * p.tiles_k;
   p.splits = splits; p.rows_per_split = rps;
   p.slab_stride = slab_stride;
@@ -1231,13 +1291,15 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
     attr_done = true;
   }
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
-  if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL(conv_wgrad_kernel<8>, dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(conv_wgrad_kernel<4>, dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
+  if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+  else if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL((conv_wgrad_kernel<8, 1, 1>), dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -1252,8 +1314,8 @@ extern "C" int aod_conv2d_wgrad_splits(const aod_conv_desc_t* d) {
   ConvKParams cp;
   memset(&cp, 0, sizeof(cp));
   if (fill_params(d, cp) || cp.M == 0) return 0;
-  int tn, tk, splits, rps;
-  wgrad_plan(cp.M, cp.N, cp.K, true, tn, tk, splits, rps);
+  int tn, tk, splits, rps, big;
+  wgrad_plan(cp.M, cp.N, cp.K, true, tn, tk, splits, rps, big);
   return splits;
 }
 

@@ -82,6 +82,13 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
                   const float* post_scale, void* zraw, float* colsum, void* workspace, size_t workspace_bytes,
                   aod_stream_t stream);
 
+/* 1x1 / stride-1 / one-segment launches of aod_conv2d(_ws) without zraw / post_scale / fp32 destination are plain GEMMs over consecutive
+ * rows (the conv1 / conv3 of every bottleneck, mmdet/models/backbones/resnet.py:260-290, and their dgrads): a persistent streaming
+ * kernel (csrc/pointwise.hip) takes them when its tiles fill the CUs.  mode -1 (default): that heuristic (environment AOD_PW_STREAM=0/1
+ * overrides), 0: always the general implicit-GEMM kernel, 1: the streaming kernel whenever the shape allows (K % 64 == 0, N % 64 == 0,
+ * N <= 2048).  Process-wide; results of the two kernels are bit-identical (tests/test_gpu_kernels.py).  Returns the previous mode. */
+int aod_set_pointwise_mode(int mode);
+
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).
  * Alone each tower conv leaves a third of its last round of workgroups idle; together their tiles fill whole rounds (3 x 341 tiles of

@@ -389,3 +389,63 @@ def test_conv_256x256_tile_equals_the_default_tile(tmp_path):
     assert torch.equal(outs['0']['dx'], outs['1']['dx'])
     assert torch.allclose(outs['0']['cs'], outs['1']['cs'], rtol=1e-4, atol=1e-2)          # (atomic column sums: order differs)
     assert float(outs['1']['y'].float().abs().mean()) > 0.1 and float(outs['1']['dx'].float().abs().mean()) > 0.01
+
+
+def test_wgrad_256x256_tile_against_fp32_reference(ho):
+    """The 256 x 256 wgrad tile (chosen for N, K multiples of 256 and >= 49152 pixels: the head towers at the bench size) on a ragged
+    two-segment shape against torch's fp32 weight gradient of the same bf16-rounded operands, and bit-reproducible run to run."""
+    g = synth.gen(77)
+    levels = [(12, 64, 64), (3, 23, 19)]
+    C = N = 256
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9.0))
+    x_rows, dz_rows, xs, zs, want, r0 = [], [], [], [], torch.zeros(N, C, 3, 3), 0
+    for B, H, W in levels:
+        x = bf(torch.randn(B, C, H, W, generator=g))
+        dz = bf(torch.randn(B, N, H, W, generator=g))
+        want += torch.nn.grad.conv2d_weight(x, w.shape, dz, stride=1, padding=1)
+        xs.append(ho.Seg(B, H, W, r0)); zs.append(ho.Seg(B, H, W, r0)); r0 += B * H * W
+        x_rows.append(nhwc_rows(x)); dz_rows.append(nhwc_rows(dz))
+    assert r0 >= 49152
+    x_rows, dz_rows = torch.cat(x_rows).cuda().bfloat16(), torch.cat(dz_rows).cuda().bfloat16()
+    dw = ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, 3, 3, 1, 1, 1)
+    assert dw.dim() == 5 and dw.shape[0] > 14               # slabs of the big tile (256 / 9 tiles = 28 pixel splits)
+    gw = ho.unpack_wgrad(dw, N, C)
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert close(gw, want, 5e-3, 5e-3 * scale)
+    gw2 = ho.unpack_wgrad(ho.conv2d_wgrad_rows(x_rows, xs, dz_rows, zs, 3, 3, 1, 1, 1), N, C)
+    assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize('shape', [(3, 37, 29, 64, 192, True, True), (2, 64, 64, 256, 64, False, True), (1, 50, 41, 128, 256, True, False),
+                                   (2, 16, 16, 1024, 128, True, True)])
+def test_pointwise_streaming_kernel_equals_the_general_kernel(ho, shape):
+    """csrc/pointwise.hip (persistent streaming GEMM for 1x1 / stride-1 convs) against the implicit-GEMM kernel on the same launch:
+    scale + shift + residual + mask + ReLU epilogue and column sums; same K order per output element -> identical bf16 results."""
+    from aod_meh_hua_amd._C import lib
+    B, H, W, Ci, Co, with_res, with_mask = shape
+    g = synth.gen(300 + Ci + Co)
+    M = B * H * W
+    segs = [ho.Seg(B, H, W, 0)]
+    x = torch.randn(M, Ci, generator=g).cuda().bfloat16()
+    wp = ho.pack_weight_fwd((torch.randn(Co, Ci, 1, 1, generator=g) / np.sqrt(Ci)).cuda())
+    scale, shift = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    res = torch.randn(M, Co, generator=g).cuda().bfloat16() if with_res else None
+    mask = torch.randn(M, Co, generator=g).cuda().bfloat16() if with_mask else None
+    outs = []
+    prev = lib.aod_set_pointwise_mode(0)
+    try:
+        for mode in (0, 1):
+            lib.aod_set_pointwise_mode(mode)
+            out = torch.full((M, Co), 7.0, device='cuda', dtype=torch.bfloat16)
+            cs = torch.zeros(Co, device='cuda')
+            d = ho.make_desc(Ci, Co, 1, 1, 1, 0, 1, segs, segs, False, True, False)
+            ho.call('aod_conv2d', ho.C.byref(d), ho.ptr(x), ho.ptr(wp), ho.ptr(out), ho.ptr(scale), ho.ptr(shift), ho.ptr(res), ho.ptr(mask), None, None,
+                    ho.ptr(cs), ho.stream())
+            torch.cuda.synchronize()
+            outs.append((out, cs))
+    finally:
+        lib.aod_set_pointwise_mode(prev)
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert float(outs[1][0].float().abs().mean()) > 0.05
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-2)
