@@ -29,6 +29,41 @@ extern "C" int aod_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int B, int
   return 0;
 }
 
+// ---------------------------------------------------------------- NCHW fp32 -> space-to-depth NHWC bf16 (stem input)
+// [B][C <= 4][H][W] -> [B][H/2][W/2][16]: channel slot (dy * 2 + dx) * C + c holds pixel (2Y + dy, 2X + dx); slots >= 4C are zero.  In
+// this layout the 7x7 / stride-2 / pad-3 stem conv is a 4x4 / stride-1 / pad-2 conv (tap r = 2R + dy - 1, s = 2S + dx - 1): a filter row
+// of an output pixel is 4 x 32 B = one contiguous 128-B line (the 8-channel NHWC form gathers 49 scattered 16-B pieces, every other
+// pixel of a row) and K shrinks from 49 x 8 to 16 x 16.  One thread per destination pixel: six 8-B loads, two 16-B stores.
+__global__ void nchw_to_s2d_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long long n = (long long)B * H2 * W2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W2); long long r = i / W2;
+    const int Y = (int)(r % H2); const long long b = r / H2;
+    bf16_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (bf16_t)0.f;
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const float2 p = *reinterpret_cast<const float2*>(src + ((b * C + c) * H + 2 * Y + dy) * (long long)W + 2 * X);
+        v[(dy * 2 + 0) * C + c] = (bf16_t)p.x;
+        v[(dy * 2 + 1) * C + c] = (bf16_t)p.y;
+      }
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { lo[k] = v[k]; hi[k] = v[8 + k]; }
+    *reinterpret_cast<bf16x8*>(dst + i * 16) = lo;
+    *reinterpret_cast<bf16x8*>(dst + i * 16 + 8) = hi;
+  }
+}
+extern "C" int aod_nchw_f32_to_s2d_bf16(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(src && dst && C >= 1 && C <= 4 && H % 2 == 0 && W % 2 == 0, "nchw_to_s2d: C <= 4 and even H, W required (C %d, %d x %d)", C, H, W);
+  hipLaunchKernelGGL(nchw_to_s2d_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, C, H, W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- maxpool 3x3 s2 p1
 __global__ void maxpool_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int H, int W, int C8, int OH, int OW) {
   const long long n = (long long)B * OH * OW * C8;

@@ -374,9 +374,11 @@ bool aod_pw_wants(const PwArgs& a) {
   if (a.K % 64 != 0 || a.N % 64 != 0 || a.N > PW_NMAX || a.M < 1) return false;
   if ((long long)a.M * a.K * 2 >= 0xe0000000ll || (long long)a.M * a.N * 2 >= 0xe0000000ll) return false;
   if (mode == 1) return true;
-  // one workgroup per CU: the tiles have to fill the 256 CUs
-  const int bn = a.N % 128 == 0 ? 128 : 64;
-  return pw_tiles(a, 64, bn) >= 224;
+  // Measured against the general kernel on every 1x1 shape of the bench step (tools/dbg/pw_stream.py): both run the wide layers at the
+  // HBM rate (3.7-5.2 TB/s) and the general kernel wins the deep, small-M ones (its 128 x 128 x 4-wave tiles at two workgroups per CU
+  // hide more latency than one 8-wave workgroup); the streaming kernel wins where the output is narrow and long -- 64 columns over
+  // >= 65536 rows: -9 % forward, -34 % in the dgrad form, whose column sums otherwise queue 4096 atomics per address.
+  return a.N == 64 && a.M >= 65536;
 }
 
 int aod_pw_gemm(const PwArgs& a, hipStream_t st) {

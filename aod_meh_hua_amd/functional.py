@@ -487,6 +487,42 @@ def image_to_nhwc(img, cpad=8):
     return as_nchw(rows, B, H, W)
 
 
+def _stem_w4(conv):
+    """[O, C, 7, 7] stem filter regrouped for the space-to-depth input: [O, 4C, 4, 4] with w4[o, (dy*2+dx)*C + c, R, S] =
+    w7[o, c, 2R + dy - 1, 2S + dx - 1] (zero where that tap index is -1); cached on the module until the weight changes."""
+    w7 = conv.weight
+    ent = conv.__dict__.get('_aod_w4')
+    if ent is None or ent[0] != w7._version or ent[1].device != w7.device:
+        O, Cc = w7.shape[:2]
+        wp = torch.zeros(O, Cc, 8, 8, dtype=torch.float32, device=w7.device)
+        wp[:, :, 1:, 1:] = w7.detach().float()                                   # index r + 1 = 2R + dy
+        w4 = wp.view(O, Cc, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(O, 4 * Cc, 4, 4).contiguous()    # [o, dy, dx, c, R, S]
+        ent = conv.__dict__['_aod_w4'] = (w7._version, w4)
+    return ent[1]
+
+
+def stem_s2d_applies(img, conv, bn):
+    """the frozen 7x7 / stride-2 / pad-3 stem on an fp32 image with even sides (resnet.py:575-600 with frozen_stages >= 0)"""
+    return (_PREC == 'bf16' and _os.environ.get('AOD_STEM_S2D', '1') != '0' and img.dtype == torch.float32 and img.dim() == 4
+            and img.shape[1] <= 4 and img.shape[2] % 2 == 0 and img.shape[3] % 2 == 0 and tuple(conv.weight.shape[2:]) == (7, 7)
+            and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and tuple(conv.dilation) == (1, 1) and conv.bias is None
+            and not conv.weight.requires_grad and not any(p.requires_grad for p in bn.parameters()) and not bn.training)
+
+
+def stem_conv_s2d(img, conv, bn):
+    """relu(bn(conv7x7_s2(img))) of the frozen stem as a 4x4 / stride-1 conv over the space-to-depth image (aod_nchw_f32_to_s2d_bf16):
+    contiguous 128-B filter rows instead of 49 scattered 16-B taps, K = 256 instead of 392.  No autograd graph (nothing here trains)."""
+    B, Cc, H, W = img.shape
+    O = conv.weight.shape[0]
+    rows, segs = ho.nchw_to_s2d_rows(img.detach())
+    w4 = _stem_w4(conv)
+    pi = PREP.get(w4, (bn.weight, bn.bias, bn.running_mean, bn.running_var), 16, bn.eps)
+    dst = [Seg(B, H // 2, W // 2, 0)]                 # (the natural output of a 4x4 / pad-2 filter has one more row and column)
+    y, _ = ho.conv2d_rows(rows, segs, pi.wf, O, 4, 4, 1, 2, 1, pre_scale=pi.scale, pre_shift=pi.shift, relu=True, dst_segs=dst,
+                          alg=(49.0 * Cc / 16.0, O))      # algorithmic FLOPs: the 7 x 7 x C filter
+    return as_nchw(y, B, H // 2, W // 2)
+
+
 def max_pool_3x3_s2(x):
     """resnet.py:610 -- only used inside the frozen stem (no backward needed)."""
     if _PREC == 'bf16x3':

@@ -306,6 +306,14 @@ def nchw_to_rows(img_f32, cpad=8):
     return out, [Seg(B, H, W, 0)]
 
 
+def nchw_to_s2d_rows(img_f32):
+    """fp32 [B, C <= 4, H, W] (H, W even) -> space-to-depth bf16 rows [B * H/2 * W/2, 16] (aod_nchw_f32_to_s2d_bf16)"""
+    B, Cc, H, W = img_f32.shape
+    out = torch.empty(B * (H // 2) * (W // 2), 16, dtype=torch.bfloat16, device=img_f32.device)
+    call('aod_nchw_f32_to_s2d_bf16', ptr(img_f32.contiguous()), ptr(out), B, Cc, H, W, stream())
+    return out, [Seg(B, H // 2, W // 2, 0)]
+
+
 def rows_to_nchw(rows, seg: Seg):
     """View rows of one segment as a [B, C, H, W] channels_last tensor (no copy)."""
     Cc = rows.shape[1]

@@ -150,6 +150,10 @@ int aod_param_prep_item_bytes(void);
  * NCHW fp32 image -> NHWC bf16 with channels zero-padded to Cpad (stem input). replaces the
  * implicit layout of `img` in SSL_L_single_stage.py:45-49 extract_feat. */
 int aod_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int B, int C, int H, int W, int Cpad, aod_stream_t stream);
+/* Stem input in space-to-depth form: fp32 [B][C <= 4][H][W] (H, W even) -> bf16 [B][H/2][W/2][16], channel slot (dy * 2 + dx) * C + c =
+ * pixel (2Y + dy, 2X + dx), remaining slots zero.  The 7x7 / stride-2 / pad-3 stem conv (mmdet/models/backbones/resnet.py:575-600)
+ * over the image equals a 4x4 / stride-1 / pad-2 conv over this tensor with the filter taps regrouped the same way. */
+int aod_nchw_f32_to_s2d_bf16(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);
 /* MaxPool 3x3 s2 p1, NHWC bf16 (resnet.py:610). */
 int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod_stream_t stream);
 /* FPN top-down: dst[b,y,x,c] += src[b,y/2,x/2,c] (nearest 2x, fpn.py:163-172) and its adjoint */

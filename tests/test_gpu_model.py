@@ -179,3 +179,33 @@ def test_grouped_tower_launch_equals_the_separate_towers(built):
         for a, b in zip(list(c1) + list(r1) + list(l1), list(c0) + list(r0) + list(l0)):
             assert a.shape == b.shape and torch.equal(a, b)
         assert float(c1[0].float().abs().mean()) > 0
+
+
+def test_space_to_depth_stem_equals_the_7x7_stem(built, monkeypatch):
+    """The frozen stem as a 4x4 / stride-1 conv over the space-to-depth image against the 7x7 / stride-2 form of the same kernel and
+    against torch's fp32 conv of the bf16-rounded operands: same products, regrouped -- only the fp32 summation order differs."""
+    import torch.nn.functional as F
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    bb = model.backbone
+    from aod_meh_hua_amd import functional as AF
+    for B, H, W in ((2, 128, 160), (3, 62, 34)):
+        img = synth.images(B, H, W).cuda()
+        assert AF.stem_s2d_applies(img, bb.conv1, bb.norm1)
+        with torch.no_grad():
+            y1 = AF.stem_conv_s2d(img, bb.conv1, bb.norm1)
+            monkeypatch.setenv('AOD_STEM_S2D', '0')
+            assert not AF.stem_s2d_applies(img, bb.conv1, bb.norm1)
+            y0 = bb.conv1(AF.image_to_nhwc(img, 8), bn=bb.norm1, relu=True)
+            monkeypatch.delenv('AOD_STEM_S2D')
+            bn = bb.norm1
+            w = bb.conv1.weight.detach().bfloat16().float()
+            z = F.conv2d(img.bfloat16().float(), w, None, 2, 3)
+            sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+            ref = torch.relu(z * sc[None, :, None, None] + (bn.bias.detach() - bn.running_mean * sc)[None, :, None, None])
+        torch.cuda.synchronize()
+        assert y1.shape == y0.shape == ref.shape
+        scale = float(ref.abs().max())
+        assert float((y1.float() - ref).abs().max()) <= 1e-2 * scale          # bf16 output rounding (2^-8 relative) + summation order
+        assert float((y1.float() - y0.float()).abs().max()) <= 1e-2 * scale
+        assert float(y1.float().abs().mean()) > 1e-3

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench as B
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda')
-model, cfg = B.build_model(dev)
+cd = B.CONFIGS['voc512']
+model, cfg = B.build_model(dev, cd)
 opt, opt_L = B.make_optimizers(model, cfg)
 data = B.synth_batch(16, 512, 512, dev, 0)
 from aod_meh_hua_amd.scoring import score_batch  # noqa
@@ -20,10 +21,10 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
 rows = []
-for ka in prof.key_averages(group_by_stack_n=12):
+for ka in prof.key_averages(group_by_stack_n=16):
     if not ka.key.startswith('aten::') or ka.device_time_total <= 0: continue
     if ka.key in ('aten::empty', 'aten::to', 'aten::_to_copy', 'aten::contiguous', 'aten::clone', 'aten::reshape', 'aten::item'): continue
     site = next((s for s in ka.stack if 'aod_meh_hua_amd' in s or 'bench.py' in s), ka.stack[0] if ka.stack else '?')
     rows.append((ka.count, ka.key, ka.device_time_total, site.strip()[-120:]))
-for n, name, us, site in sorted(rows, key=lambda r: -r[2])[:70]:
+for n, name, us, site in sorted(rows, key=lambda r: -r[2])[:110]:
     print(f'{n:3d} {us:8.0f} us  {name:24s} {site}')
