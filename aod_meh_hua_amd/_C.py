@@ -37,6 +37,7 @@ P, I32, I64, F32, U64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uin
 _SIGS = {
     'aod_version': (C.c_int, []),
     'aod_set_pointwise_mode': (C.c_int, [I32]),
+    'aod_bottleneck64_fwd': (C.c_int, [P, I32, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_conv2d': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, P]),
     'aod_conv2d_ws_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv2d_ws': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]),

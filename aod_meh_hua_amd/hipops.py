@@ -41,6 +41,18 @@ def _prof(kind, desc, fn, alg=None):
     return r
 
 
+def prof_flops(kind, shape, flops, fn):
+    """like _prof for launches that are not one convolution (fused bottleneck): `shape` = (M, N, K, taps, stride) of the listing"""
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((kind, shape, float(flops), e0, e1))
+    return r
+
+
 BYTES_PROFILE = None     # bench.py: (kernel name, algorithmic bytes, start_event, end_event) for the HBM-bound row kernels
 
 
@@ -312,6 +324,19 @@ def nchw_to_s2d_rows(img_f32):
     out = torch.empty(B * (H // 2) * (W // 2), 16, dtype=torch.bfloat16, device=img_f32.device)
     call('aod_nchw_f32_to_s2d_bf16', ptr(img_f32.contiguous()), ptr(out), B, Cc, H, W, stream())
     return out, [Seg(B, H // 2, W // 2, 0)]
+
+
+def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_rows, out=None):
+    """aod_bottleneck64_fwd: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + res) for a 64-channel bottleneck, one launch"""
+    M, Cin = x_rows.shape
+    assert M == B * H * W and res_rows.shape == (M, 256)
+    if out is None:
+        out = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device)
+    flops = 2.0 * M * (Cin * 64 + 576 * 64 + 64 * 256)
+    prof_flops('fwd', (M, 256, Cin + 576 + 64, 11, 1), flops,
+               lambda: call('aod_bottleneck64_fwd', ptr(x_rows), Cin, B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
+                            ptr(b3), ptr(res_rows), ptr(out), stream()))
+    return out
 
 
 def rows_to_nchw(rows, seg: Seg):

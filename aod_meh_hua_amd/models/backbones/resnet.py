@@ -42,6 +42,9 @@ class Bottleneck(BaseModule):
         """resnet.py:262-301: relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + identity) -- 3 (4) launches."""
         # identity block: the block input feeds conv1 and, as the residual, conv3 -- nothing else (stage outputs, which also go to
         # the neck, always enter a block WITH a downsample branch), so conv1's dgrad epilogue can finish the previous block's backward
+        if AF.bottleneck64_applies(self, x):       # frozen / inference 64-channel block: one launch, intermediates stay in LDS
+            identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])
+            return AF.bottleneck64_fwd(x, self, identity)
         out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if self.downsample is None else False)
         out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True)      # conv1's / conv2's outputs feed only the next conv:
         identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])

@@ -89,6 +89,16 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
  * N <= 2048).  Process-wide; results of the two kernels are bit-identical (tests/test_gpu_kernels.py).  Returns the previous mode. */
 int aod_set_pointwise_mode(int mode);
 
+/* A whole 64-channel ResNet bottleneck, forward only (mmdet/models/backbones/resnet.py:262-301 with eval-mode BN; layer1 is frozen,
+ * resnet.py:612-628, so nothing of it is needed by the backward pass either):
+ *   y = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(relu(bn1(conv1_1x1(x)))))))) + res)
+ * x [B*H*W][Cin] bf16 NHWC rows (Cin % 64 == 0), w1 [64][Cin], w2 [64][3][3][64], w3 [256][64] packed forward weights, s* / b* the
+ * folded BN scale / shift vectors (fp32), res and y [B*H*W][256] bf16 (res may be x).  One kernel: the two 64-channel intermediates
+ * stay in LDS, x and y cross HBM once (csrc/bottleneck.hip). */
+int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                         const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
+                         aod_stream_t stream);
+
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).
  * Alone each tower conv leaves a third of its last round of workgroups idle; together their tiles fill whole rounds (3 x 341 tiles of

@@ -209,3 +209,33 @@ def test_space_to_depth_stem_equals_the_7x7_stem(built, monkeypatch):
         assert float((y1.float() - ref).abs().max()) <= 1e-2 * scale          # bf16 output rounding (2^-8 relative) + summation order
         assert float((y1.float() - y0.float()).abs().max()) <= 1e-2 * scale
         assert float(y1.float().abs().mean()) > 1e-3
+
+
+def test_fused_bottleneck_equals_the_three_launch_block(built, monkeypatch):
+    """aod_bottleneck64_fwd (conv1 on the tile halo -> LDS, conv2 gathered from LDS, conv3 + residual from LDS: one launch per frozen layer1
+    block) against the block as three / four launches of the implicit-GEMM kernel, on a one-tile image, ragged multi-tile images and
+    both input widths: same bf16 rounding points and the same K order per output element -> identical bits."""
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    from aod_meh_hua_amd import functional as AF
+    layer1 = model.backbone.layer1
+    g = synth.gen(5)
+    for B, H, W in ((1, 16, 16), (2, 50, 37), (3, 33, 64)):
+        x = torch.randn(B, 64, H, W, generator=g).relu().cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            for blk in layer1:
+                monkeypatch.setenv('AOD_FUSE_BOTTLENECK', '0')
+                assert not AF.bottleneck64_applies(blk, x)
+                y0 = blk(x)
+                monkeypatch.setenv('AOD_FUSE_BOTTLENECK', '1')
+                assert AF.bottleneck64_applies(blk, x)
+                y1 = blk(x)
+                torch.cuda.synchronize()
+                assert y1.shape == y0.shape and torch.equal(y1, y0)
+                assert float(y0.float().abs().mean()) > 1e-3
+                x = y0
+    monkeypatch.delenv('AOD_FUSE_BOTTLENECK')
+    # the trainable stages keep the per-conv launches (their backward needs the intermediates)
+    model.train()
+    xg = torch.randn(1, 256, 16, 16).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    assert not AF.bottleneck64_applies(model.backbone.layer2[0], xg)
