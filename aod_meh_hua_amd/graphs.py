@@ -100,6 +100,9 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         out['loss'].backward()
         self.cur['live'] = (out, head_out, feat_out, prev)
+        # every 0-dim value the caller gets back, packed into ONE static vector inside the graph: a step then hands out copies with one
+        # device copy per segment instead of one per log entry (~60 launches of 4 us each, serialised behind the replay)
+        self.cur['pack'] = torch.stack([out['loss'].detach().float().reshape(())] + [v.detach().float().reshape(()) for v in out['log_vars'].values()])
 
     def _seg_b(self):
         # the MEH step only reads detached features / losses and its own parameters, so the main update (segment C) may follow it:
@@ -109,6 +112,7 @@ class GraphedTrainStep:
         self.opt_L.zero_grad()
         loss_L['loss'].backward()
         self.cur['live_L'] = loss_L
+        self.cur['pack_L'] = torch.stack([v.detach().float().reshape(()) for v in loss_L['log_vars'].values()])
 
     def _seg_c(self):
         self.opt.step()
@@ -259,9 +263,11 @@ class GraphedTrainStep:
         tp = [p for p in ent['touched'] if p.grad is not None]
         torch._C._autograd._unsafe_set_version_counter(tp, [p._version + 1 for p in tp])
         out, loss_L = ent['live'][0], ent['live_L']
-        log_vars = type(out['log_vars'])((k, v.clone()) for k, v in out['log_vars'].items())     # static tensors: hand out copies
-        log_vars.update((k, v.clone()) for k, v in loss_L['log_vars'].items())
-        return dict(loss=out['loss'].detach().clone(), log_vars=log_vars, num_samples=out['num_samples'])
+        # static tensors: hand out copies (two device copies: the packed vectors of segments A and B)
+        pa, pb = self.cur['pack'].clone(), self.cur['pack_L'].clone()
+        log_vars = type(out['log_vars'])(zip(out['log_vars'].keys(), pa[1:].unbind(0)))
+        log_vars.update(zip(loss_L['log_vars'].keys(), pb.unbind(0)))
+        return dict(loss=pa[0], log_vars=log_vars, num_samples=out['num_samples'])
 
 
 class GraphedScore:
