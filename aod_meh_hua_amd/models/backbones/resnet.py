@@ -135,12 +135,12 @@ class ResNet(BaseModule):
         """resnet.py:630-645.  `x`: fp32 NCHW image batch (converted once to bf16 NHWC, 3 -> 8 channels)
         or an already-NHWC bf16 tensor."""
         if AF.stem_s2d_applies(x, self.conv1, self.norm1):
-            x = AF.stem_conv_s2d(x, self.conv1, self.norm1)        # frozen stem: space-to-depth form of the same convolution
+            x = AF.stem_pool_s2d(x, self.conv1, self.norm1)        # frozen stem: conv (space-to-depth form) + BN + ReLU + max-pool, one launch
         else:
             if x.dtype != torch.bfloat16:
                 x = AF.image_to_nhwc(x, 8)
             x = self.conv1(x, bn=self.norm1, relu=True)
-        x = AF.max_pool_3x3_s2(x)
+            x = AF.max_pool_3x3_s2(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):

@@ -164,6 +164,11 @@ int aod_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int B, int C, int H, 
  * pixel (2Y + dy, 2X + dx), remaining slots zero.  The 7x7 / stride-2 / pad-3 stem conv (mmdet/models/backbones/resnet.py:575-600)
  * over the image equals a 4x4 / stride-1 / pad-2 conv over this tensor with the filter taps regrouped the same way. */
 int aod_nchw_f32_to_s2d_bf16(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);
+/* The frozen stem in one launch on the space-to-depth image: y = max_pool_3x3_s2_p1(relu(bn1(conv1(x)))) (resnet.py:630-637; conv1 as the
+ * 4x4 / stride-1 / pad-2 filter [64][4][4][16] over x_s2d [B][H2][W2][16]).  y [B][H4][W4][64] bf16 with H4 = (H2 - 1) / 2 + 1; the
+ * 64-channel conv output never leaves LDS (csrc/stem.hip). */
+int aod_stem_pool_fwd(const void* x_s2d, const void* w_packed, const float* scale, const float* shift, void* y, int B, int H2, int W2,
+                      aod_stream_t stream);
 /* MaxPool 3x3 s2 p1, NHWC bf16 (resnet.py:610). */
 int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod_stream_t stream);
 /* FPN top-down: dst[b,y,x,c] += src[b,y/2,x/2,c] (nearest 2x, fpn.py:163-172) and its adjoint */

@@ -209,6 +209,13 @@ def test_space_to_depth_stem_equals_the_7x7_stem(built, monkeypatch):
         assert float((y1.float() - ref).abs().max()) <= 1e-2 * scale          # bf16 output rounding (2^-8 relative) + summation order
         assert float((y1.float() - y0.float()).abs().max()) <= 1e-2 * scale
         assert float(y1.float().abs().mean()) > 1e-3
+        # ... and with the max-pool fused behind it (aod_stem_pool_fwd: the conv output stays in LDS): identical bits
+        with torch.no_grad():
+            pooled = AF.stem_pool_s2d(img, bb.conv1, bb.norm1)
+            sep = AF.max_pool_3x3_s2(y1)
+        torch.cuda.synchronize()
+        assert pooled.shape == sep.shape and torch.equal(pooled, sep)
+        assert torch.equal(pooled.float(), F.max_pool2d(y1.float(), 3, 2, 1))
 
 
 def test_fused_bottleneck_equals_the_three_launch_block(built, monkeypatch):

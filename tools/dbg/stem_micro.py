@@ -23,3 +23,10 @@ with torch.no_grad():
     print('s2d stem all  %.1f us' % t(lambda: AF.stem_conv_s2d(img, bb.conv1, bb.norm1)))
     y = AF.stem_conv_s2d(img, bb.conv1, bb.norm1)
     print('maxpool       %.1f us' % t(lambda: AF.max_pool_3x3_s2(y)))
+    print('fused s2d + conv + bn + relu + pool  %.1f us' % t(lambda: AF.stem_pool_s2d(img, bb.conv1, bb.norm1)))
+    for shp in ((16, 512, 512), (2, 128, 160), (3, 62, 34), (1, 30, 66)):
+        im = torch.randn(shp[0], 3, shp[1], shp[2], device=dev)
+        a = AF.stem_pool_s2d(im, bb.conv1, bb.norm1)
+        b = AF.max_pool_3x3_s2(AF.stem_conv_s2d(im, bb.conv1, bb.norm1))
+        torch.cuda.synchronize()
+        print(shp, 'fused == separate:', a.shape == b.shape and bool(torch.equal(a, b)), 'max|diff|', float((a.float() - b.float()).abs().max()), 'mean', float(b.float().abs().mean()))
