@@ -347,8 +347,9 @@ def main():
             try:
                 pm = json.load(open(os.path.join(ROOT, 'profiles', pf)))
                 # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants of the 128 x 128 tile)
-                pref = 'void conv_wgrad_kernel' if kind == 'wgrad' else 'void conv_igemm_kernel<128, 128'
-                ks = [k for k in pm if k.startswith(pref)]
+                # forward / dgrad: every instance of the implicit-GEMM kernel plus the fused forward kernels (bottleneck, stem, pointwise)
+                pref = ('conv_wgrad_kernel',) if kind == 'wgrad' else ('conv_igemm_kernel', 'bottleneck64_fwd_kernel', 'stem_pool_kernel', 'pw_gemm_kernel')
+                ks = [k for k in pm if any(q in k for q in pref)]
                 nl = sum(pm[k]['launches'] for k in ks)
                 traffic = round(sum((pm[k]['read_MB_per_launch'] + pm[k]['write_MB_per_launch']) * pm[k]['launches'] for k in ks) / nl * 1e6)
                 break
