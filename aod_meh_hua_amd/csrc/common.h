@@ -44,6 +44,34 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// block rows [nr][C] (contiguous in global memory) -> LDS rows of pitch P, consecutive lanes on consecutive elements; (row, column) advance
+// incrementally (an integer division per element cost more than the load), 16-B loads when a row is a whole number of them
+template <int LB>
+__device__ __forceinline__ void aod_stage_rows(const float* __restrict__ src, float* __restrict__ srow, int nr, int C, int P) {
+  const int tot = nr * C;
+  if ((C & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15ull) == 0) {
+    const int C4 = C >> 2, tot4 = tot >> 2;
+    const int drow = LB / C4, dcol = LB - drow * C4;
+    int row = (int)threadIdx.x / C4, col = (int)threadIdx.x - row * C4;
+    for (int i = threadIdx.x; i < tot4; i += LB) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      float* d = srow + row * P + 4 * col;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      row += drow; col += dcol;
+      if (col >= C4) { col -= C4; ++row; }
+    }
+    return;
+  }
+  const int drow = LB / C, dcol = LB - drow * C;
+  int row = (int)threadIdx.x / C, col = (int)threadIdx.x - row * C;
+  for (int i = threadIdx.x; i < tot; i += LB) {
+    srow[row * P + col] = src[i];
+    row += drow; col += dcol;
+    if (col >= C) { col -= C; ++row; }
+  }
+}
+
+
 // Philox4x32-10 (Salmon et al. 2011), the counter-based RNG of the HUA sampler and of the synthetic pool images; restated in numpy in
 // oracle/hua.py (known-answer test: tests/test_oracle_golden.py::test_philox_known_answer)
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* r) {

@@ -10,6 +10,24 @@ constexpr int MAXC = 96;
 
 __device__ __forceinline__ float focal_pow(float b, float gamma) { return gamma == 2.f ? b * b : powf(b, gamma); }
 
+// The row kernels are VALU-bound, not HBM-bound: per class the reference formula costs two exponentials, up to three logarithms and three
+// divisions, and libm's expf / logf / IEEE division are 12-30 instructions each (~4000 instructions per 20-class row; PMC and the
+// secondary roofline of bench.py: 0.10 of the HBM rate).  AOD_LOSS_FAST_MATH (default) evaluates them with the hardware transcendentals
+// (v_exp_f32, v_log_f32, v_rcp_f32: 1 ulp each, arguments are normal floats), same formulas in the same order.  The golden parity tests
+// keep their tolerances (rtol 2e-5 per row against the reference's own values); -DAOD_LOSS_FAST_MATH=0 restores libm.
+#ifndef AOD_LOSS_FAST_MATH
+#define AOD_LOSS_FAST_MATH 1
+#endif
+#if AOD_LOSS_FAST_MATH
+__device__ __forceinline__ float l_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float l_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float l_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
+__device__ __forceinline__ float l_exp(float x) { return expf(x); }
+__device__ __forceinline__ float l_log(float x) { return logf(x); }
+__device__ __forceinline__ float l_div(float a, float b) { return a / b; }
+#endif
+
 // Row layout in the kernels below: LPR lanes share one anchor row, lane part j owns the classes [j*cpl, (j+1)*cpl) with
 // cpl = ceil(C / LPR) <= CT.  CT is a compile-time bound: the loops are fully unrolled and predicated, so x[] / p[] / gp[] live in
 // registers -- with a run-time trip count (or a 96-wide bound for the 80/81-class heads) they were demoted to scratch memory
@@ -37,18 +55,21 @@ __device__ __forceinline__ float edl_row_fwd(const float* x, int n, int c0, long
   m = grp_max<LPR>(m);
   float S = 0.f;
 #pragma unroll
-  for (int c = 0; c < CT; ++c) if (c < n) { p[c] = expf(x[c] - m); S += p[c]; }
+  for (int c = 0; c < CT; ++c) if (c < n) { p[c] = l_exp(x[c] - m); S += p[c]; }
   S = grp_sum<LPR>(S);
   float tot = 0.f;
 #pragma unroll
   for (int c = 0; c < CT; ++c) if (c < n) {
-    const float pr = p[c] / S;
+    const float pr = l_div(p[c], S);
     p[c] = pr;
-    const float z = logf(pr / (1.f - pr + 1e-9f) + 1e-9f);
-    const float q = 1.f / (1.f + expf(-z));
+    const float z = l_log(l_div(pr, 1.f - pr + 1e-9f) + 1e-9f);
+    const float q = l_div(1.f, 1.f + l_exp(-z));
+    const bool pos = label == c0 + c;
+    // (one logarithm per class: its argument is selected, not its result)
+    const float lg = l_log(fmaxf(pos ? q : 1.f - q, FLT_MIN_F));
     float l;
-    if (label == c0 + c) l = -alpha * focal_pow(1.f - q, gamma) * logf(fmaxf(q, FLT_MIN_F));
-    else l = -(1.f - alpha) * focal_pow(q, gamma) * logf(fmaxf(1.f - q, FLT_MIN_F));
+    if (pos) l = -alpha * focal_pow(1.f - q, gamma) * lg;
+    else l = -(1.f - alpha) * focal_pow(q, gamma) * lg;
     tot += l;
   }
   return grp_sum<LPR>(tot);
@@ -64,9 +85,7 @@ __global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict_
   const int P = C | 1;  // odd pitch -> conflict-free row reads
   const long long r0 = (long long)blockIdx.x * RB;
   const int nr = (int)min((long long)RB, nrows - r0);
-  const float* src = cls + r0 * C;
-  const int tot = nr * C;
-  for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
+  aod_stage_rows<LB>(cls + r0 * C, srow, nr, C, P);
   __syncthreads();
   float s_cls = 0.f, s_box = 0.f, s_nor = 0.f;
   const int lrow = threadIdx.x / LPR, part = threadIdx.x % LPR;
@@ -157,9 +176,9 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
   const int P = C | 1;
   const long long r0 = (long long)blockIdx.x * RB;
   const int nr = (int)min((long long)RB, nrows - r0);
-  const float* src = cls + r0 * C;
   const int tot = nr * C;
-  for (int i = threadIdx.x; i < tot; i += LB) srow[(i / C) * P + (i % C)] = src[i];
+  aod_stage_rows<LB>(cls + r0 * C, srow, nr, C, P);
+  __shared__ long long s_obase[LB];       // element offset of each row's class 0 in the destination
   __syncthreads();
   const int lrow = threadIdx.x / LPR, part = threadIdx.x % LPR;
   const bool live = lrow < nr;
@@ -168,6 +187,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
   const int n = min(cpl, C - c0);
   {
     const long long r = r0 + row;
+    if (live && part == 0) s_obase[row] = (r / A) * pitch_cls + (r % A) * C;
     float x[CT], p[CT], gp[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) x[c] = c < n ? srow[row * P + c0 + c] : 0.f;
@@ -177,24 +197,26 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
     m = grp_max<LPR>(m);
     float S = 0.f;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) if (c < n) { p[c] = expf(x[c] - m); S += p[c]; }
+    for (int c = 0; c < CT; ++c) if (c < n) { p[c] = l_exp(x[c] - m); S += p[c]; }
     S = grp_sum<LPR>(S);
     const long long label = labels[r];
     const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[r] : g_noR_s);
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) if (c < n) {
-      const float pr = p[c] / S;
+      const float pr = l_div(p[c], S);
       p[c] = pr;
       const float om = 1.f - pr + 1e-9f;
-      const float u = pr / om;
-      const float z = logf(u + 1e-9f);
-      const float q = 1.f / (1.f + expf(-z));
+      const float u = l_div(pr, om);
+      const float z = l_log(u + 1e-9f);
+      const float q = l_div(1.f, 1.f + l_exp(-z));
+      const bool pos = label == c0 + c;
+      const float lg = l_log(fmaxf(pos ? q : 1.f - q, FLT_MIN_F));
       float gz;   // d l / d z  (mmcv sigmoid_focal_loss backward)
-      if (label == c0 + c) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * logf(fmaxf(q, FLT_MIN_F)));
-      else gz = -(1.f - alpha) * focal_pow(q, gamma) * (gamma * (1.f - q) * logf(fmaxf(1.f - q, FLT_MIN_F)) - q);
+      if (pos) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * lg);
+      else gz = -(1.f - alpha) * focal_pow(q, gamma) * (gamma * (1.f - q) * lg - q);
       // dz/dp = (1+eps) / ((1-p+eps)^2 (u+eps))
-      const float g = coef * gz * (1.f + 1e-9f) / (om * om * (u + 1e-9f));
+      const float g = l_div(coef * gz * (1.f + 1e-9f), om * om * (u + 1e-9f));
       gp[c] = g;
       dot += pr * g;
     }
@@ -218,13 +240,17 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < tot; i += LB) {
-    const int row = i / C, c = i - row * C;
-    const long long r = r0 + row;
-    const long long o = (r / A) * pitch_cls + (r % A) * C + c;
-    const float gx = srow[row * P + c];
-    if (OUT_BF16) ((bf16_t*)grad_cls)[o] = (bf16_t)gx;
-    else ((float*)grad_cls)[o] = gx;
+  {
+    const int drow = LB / C, dcol = LB - drow * C;
+    int row = (int)threadIdx.x / C, c = (int)threadIdx.x - row * C;
+    for (int i = threadIdx.x; i < tot; i += LB) {
+      const long long o = s_obase[row] + c;
+      const float gx = srow[row * P + c];
+      if (OUT_BF16) ((bf16_t*)grad_cls)[o] = (bf16_t)gx;
+      else ((float*)grad_cls)[o] = gx;
+      row += drow; c += dcol;
+      if (c >= C) { c -= C; ++row; }
+    }
   }
 }
 

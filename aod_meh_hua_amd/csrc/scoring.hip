@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __rest
   const long long r0 = (long long)blockIdx.x * 256;
   const int nr = (int)min((long long)256, rows_per_img - r0);
   const float* src = cls + ((long long)b * rows_per_img + r0) * C;
-  for (int i = threadIdx.x; i < nr * C; i += 256) srow[(i / C) * P + (i % C)] = src[i];
+  aod_stage_rows<256>(src, srow, nr, C, P);
   __syncthreads();
   bool fg = false;
   if ((int)threadIdx.x < nr) {

@@ -309,6 +309,11 @@ def main():
     barrier()
     if rank == 0:
         ho.PROFILE, ho.BYTES_PROFILE = [], []
+    # The eager step is enqueued from Python far more slowly than the device executes it; an event pair around a launch would then span
+    # the idle time until the launch arrives (~10 us per small kernel).  A device-side spin keeps the stream busy while the host enqueues
+    # the whole step, so that the events are processed back to back and a pair brackets nothing but its kernel (the rocprofv3 averages
+    # under profiles/ are the cross-check).
+    torch.cuda._sleep(int(0.6 * 2.0e9))
     step(args.warmup + args.steps, graph=False)              # EVERY rank (the step contains collectives); HIP events need the eager path
     barrier()
     if rank == 0:
