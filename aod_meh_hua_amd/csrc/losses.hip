@@ -168,7 +168,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
                                                         const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
                                                         float gamma, float alpha, const float* __restrict__ g_cls,
-                                                        const float* __restrict__ g_bbox, const float* __restrict__ g_noR, float g_noR_s,
+                                                        const float* __restrict__ g_bbox, const float* __restrict__ g_noR, float g_noR_s, int g_noR_bcast,
                                                         void* __restrict__ grad_cls, void* __restrict__ grad_bbox, int A, int pitch_cls,
                                                         int pitch_box) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
     for (int c = 0; c < CT; ++c) if (c < n) { p[c] = l_exp(x[c] - m); S += p[c]; }
     S = grp_sum<LPR>(S);
     const long long label = labels[r];
-    const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[r] : g_noR_s);
+    const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[g_noR_bcast ? 0 : r] : g_noR_s);
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) if (c < n) {
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
 
 extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
                                     const float* bbox_tgt, const float* bbox_w, int64_t nrows, int C, float gamma, float alpha,
-                                    const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar, void* grad_cls,
-                                    void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
+                                    const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar, int g_noR_is_scalar,
+                                    void* grad_cls, void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
   if (nrows == 0) return 0;
   AOD_CHECK_ARG(cls && labels && label_w && g_cls && grad_cls, "edl_bwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_bwd: bad C/A/pitch");
@@ -266,7 +266,7 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
 #define AOD_EDL_BWD(BF, LPR_)                                                                                                              \
   hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, 24, LPR_>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / LPR_) * (C | 1) * 4, (hipStream_t)stream, cls, \
                      (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR, \
-                     g_noR_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box)
+                     g_noR_scalar, g_noR_is_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box)
   if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
   else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
 #undef AOD_EDL_BWD

@@ -623,6 +623,16 @@ def upsample_add(lateral, top):
 
 
 # --------------------------------------------------------------------------- losses
+class PackedLosses(list):
+    """The per-level loss terms of one name (loss_cls / loss_bbox / loss_noR / loss_L) as the reference hands them to `_parse_losses`
+    (SSL_Lambda.py:126-154) -- a list -- plus `.packed`: ONE device vector whose sum is the sum of the per-level means the reference
+    forms with a `.mean()` and an add per level.  `_parse_losses` sums the vector (one launch, and one in backward) instead."""
+
+    def __init__(self, items, packed):
+        super().__init__(items)
+        self.packed = packed
+
+
 class RetinaLossFn(Function):
     """Per level: (loss_cls_sum, loss_bbox_sum, loss_noR[N]) = fused EDL softmax-focal + L1
     (Lambda_L2.py:112-121).  Sums are NOT yet divided by avg_factor (done by the caller with a
@@ -641,17 +651,24 @@ class RetinaLossFn(Function):
         noR, sums = ho.edl_focal_l1_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, gamma, alpha)
         ctx.save_for_backward(cls_rows, box_rows, labels, label_w, bbox_t, bbox_w)
         ctx.cfg = (gamma, alpha, cls_score.shape, bbox_pred.shape)
-        return sums[0], sums[1], noR
+        return sums[0], sums[1], noR, sums[2]      # sums[2] = sum(noR): lets the caller form mean(loss_noR) without a pass over the rows
 
     @staticmethod
-    def backward(ctx, g_cls, g_box, g_noR):
+    def backward(ctx, g_cls, g_box, g_noR, g_sum):
         cls_rows, box_rows, labels, label_w, bbox_t, bbox_w = ctx.saved_tensors
         gamma, alpha, cshape, bshape = ctx.cfg
         dev = cls_rows.device
         g_cls = torch.zeros(1, device=dev) if g_cls is None else g_cls.reshape(1).float().contiguous()
         g_box = torch.zeros(1, device=dev) if g_box is None else g_box.reshape(1).float().contiguous()
         g_noR_t = None if g_noR is None else g_noR.float().contiguous()
-        gc, gb = ho.edl_focal_l1_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, g_cls, g_box, g_noR_t, 0.0, gamma, alpha)
+        scalar = False
+        if g_sum is not None:          # gradient of the row SUM: one device scalar for every row
+            if g_noR_t is None:
+                g_noR_t, scalar = g_sum.reshape(1).float().contiguous(), True
+            else:
+                g_noR_t = g_noR_t + g_sum.float()
+        gc, gb = ho.edl_focal_l1_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, g_cls, g_box, g_noR_t, 0.0, gamma, alpha,
+                                     g_noR_is_scalar=scalar)
         B, AC, H, W = cshape
         return (as_nchw(gc.view(B * H * W, AC), B, H, W), as_nchw(gb.view(B * H * W, bshape[1]), B, H, W),
                 None, None, None, None, None, None, None)

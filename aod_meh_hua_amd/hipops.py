@@ -398,7 +398,7 @@ def edl_focal_l1_fwd(cls, labels, label_w, bbox_pred=None, bbox_tgt=None, bbox_w
 
 
 def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g_bbox, g_noR=None, g_noR_scalar=0.0,
-                     gamma=2.0, alpha=0.25, out_bf16=False, A=1, pitch_cls=None, pitch_box=None, grad_cls=None, grad_bbox=None):
+                     gamma=2.0, alpha=0.25, g_noR_is_scalar=False, out_bf16=False, A=1, pitch_cls=None, pitch_box=None, grad_cls=None, grad_bbox=None):
     rows, Cc = cls.shape
     pitch_cls = pitch_cls or A * Cc
     pitch_box = pitch_box or A * 4
@@ -410,9 +410,9 @@ def edl_focal_l1_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, g_cls, g
     if grad_bbox is None and bbox_pred is not None:
         grad_bbox = alloc(pitch_box, A * 4)
     esz = 2 if out_bf16 else 4
-    prof_bytes('edl_l1_bwd', rows * (Cc * 4 + 8 + 4 + (4 if g_noR is not None else 0) + Cc * esz + ((48 + 4 * esz) if bbox_pred is not None else 0)),
+    prof_bytes('edl_l1_bwd', rows * (Cc * 4 + 8 + 4 + (4 if (g_noR is not None and not g_noR_is_scalar) else 0) + Cc * esz + ((48 + 4 * esz) if bbox_pred is not None else 0)),
                lambda: call('aod_edl_focal_l1_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), rows, Cc,
-                            gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
+                            gamma, alpha, ptr(g_cls), ptr(g_bbox), ptr(g_noR), float(g_noR_scalar), int(bool(g_noR_is_scalar)), ptr(grad_cls), ptr(grad_bbox), int(out_bf16), A,
                             pitch_cls, pitch_box, stream()))
     return grad_cls, grad_bbox
 

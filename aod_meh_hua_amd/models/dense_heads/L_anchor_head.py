@@ -151,22 +151,44 @@ class L_AnchorHead(BaseModule):
         head_info = ['cls_scores', 'bbox_preds', 'all_anchor_list', 'labels_list', 'label_weights_list', 'bbox_targets_list',
                      'bbox_weights_list', 'num_total_samples']
         head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
-        losses_cls, losses_bbox, losses_noR = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list,
-                                                          bt_list, bw_list, list(range(len(cls_scores))),
-                                                          num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
-                                                          defer_avg=self._can_defer_avg, **kwargs)
+        outs = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list,
+                           list(range(len(cls_scores))), num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
+                           defer_avg=self._can_defer_avg, **kwargs)
+        losses_cls, losses_bbox, losses_noR = outs[0], outs[1], outs[2]
         if self._can_defer_avg:
-            # the per-level "sum / num_total_samples" of loss_single (L_anchor_head.py:266-288) for all levels at once: same quotients,
-            # 2 launches instead of 10 (and as many fewer in backward)
-            losses_cls = list((torch.stack(losses_cls) / num_total_samples).unbind(0))
-            losses_bbox = list((torch.stack(losses_bbox) / num_total_samples).unbind(0))
+            # the per-level "sum / num_total_samples" of loss_single (L_anchor_head.py:266-288) and the "mean(loss_noR)" of
+            # _parse_losses (SSL_Lambda.py:136-141) for all levels at once: the same quotients from three launches (stack, divisor, divide)
+            # instead of ten divisions and five row reductions -- and as many fewer in backward
+            from ... import functional as AF
+            L = len(losses_cls)
+            S = torch.stack(list(losses_cls) + list(losses_bbox) + list(outs[3])).view(3, L)
+            counts = self._level_counts([int(t.numel()) for t in losses_noR], S.device)
+            D = torch.cat([num_total_samples.reshape(1).expand(2 * L), counts]).view(3, L)
+            Q = S / D
+            losses_cls = AF.PackedLosses(Q[0].unbind(0), Q[0])
+            losses_bbox = AF.PackedLosses(Q[1].unbind(0), Q[1])
+            losses_noR = AF.PackedLosses(losses_noR, Q[2])           # the rows stay what train_step hands to the MEH step
         return dict(loss_cls=losses_cls, loss_bbox=losses_bbox, loss_noR=losses_noR), head_out
+
+    def _level_counts(self, counts, device):
+        key = (tuple(counts), str(device))
+        cache = self.__dict__.setdefault('_count_cache', {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = torch.tensor(counts, dtype=torch.float32, device=device)
+        return cache[key]
 
     _can_defer_avg = False      # set by heads whose loss_single understands defer_avg
 
     @force_fp32(apply_to=('L_scores'))
     def loss_L(self, L_scores, head_out, losses, **kwargs):
         """L_anchor_head.py:322-327."""
+        if self._can_defer_avg:
+            from ... import functional as AF
+            sums, scales = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], defer_scale=True, **kwargs)
+            Q = torch.stack(list(sums)) * self._level_counts([float(v) for v in scales], sums[0].device)     # 5 * mean(.) per level
+            return dict(loss_L=AF.PackedLosses(Q.unbind(0), Q))
         losses_L, _ = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], **kwargs)
         return dict(loss_L=losses_L)
 

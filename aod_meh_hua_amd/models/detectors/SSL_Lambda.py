@@ -67,6 +67,8 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
         for loss_name, loss_value in losses.items():
             if isinstance(loss_value, torch.Tensor):
                 log_vars[loss_name] = mean(loss_value)
+            elif getattr(loss_value, 'packed', None) is not None:
+                log_vars[loss_name] = loss_value.packed.sum()        # functional.PackedLosses: the per-level means in one vector
             elif isinstance(loss_value, list):
                 loss_sum = None
                 for _loss in loss_value:
@@ -75,7 +77,10 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
                 log_vars[loss_name] = loss_sum if loss_sum is not None else torch.zeros((), device=kwargs.get('device'))
             else:
                 raise TypeError(f'{loss_name} is not a tensor or list of tensors')
-        loss = sum(_value for _key, _value in log_vars.items() if 'loss' in _key)
+        terms = [_value for _key, _value in log_vars.items() if 'loss' in _key]
+        loss = terms[0]
+        for _value in terms[1:]:           # (sum() would start from the int 0: one more launch)
+            loss = loss + _value
         for loss_name, loss_value in log_vars.items():
             log_vars[loss_name] = loss_value.detach()
         return loss, log_vars

@@ -201,14 +201,15 @@ int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, const float* l
                          int64_t nrows, int C, float gamma, float alpha,
                          float* loss_noR, float* sums3, float* partials, aod_stream_t stream);
 /* grad_cls = d(sum(l*w))*g_cls + d(sum_rows loss_noR * g_noR[row]);  grad_bbox = sign(p-t)*bw*g_bbox.
- * g_cls, g_bbox: device scalars (already divided by avg_factor); g_noR: device [Nrows] or NULL,
- * g_noR_scalar: used when g_noR is NULL.  Output element (row r, col c) is written at
+ * g_cls, g_bbox: device scalars (already divided by avg_factor); g_noR: device [Nrows] -- or ONE device scalar applied to every row when
+ * g_noR_is_scalar != 0 (the gradient of mean(loss_noR), Lambda_L2.py:112-121 + SSL_Lambda.py:136-141, without materialising it) -- or NULL,
+ * g_noR_scalar: host scalar used when g_noR is NULL.  Output element (row r, col c) is written at
  * (r / A) * pitch + (r % A) * C + c -- i.e. straight into the prediction conv's [pixels, pitch] dZ
  * buffer (pitch = A*C rounded up to 8, pad columns pre-zeroed by the caller) -- as bf16 or fp32. */
 int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, const float* label_w,
                          const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
                          int64_t nrows, int C, float gamma, float alpha,
-                         const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar,
+                         const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar, int g_noR_is_scalar,
                          void* grad_cls, void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box,
                          aod_stream_t stream);
 /* MEH loss (Lambda_L2.py:235-241): out_sum[0] += sum(((|lam+1e-9-loss|)*w)^2), w = bbox_w4[i*4];
