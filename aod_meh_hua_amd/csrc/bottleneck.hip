@@ -57,6 +57,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// filter images: the paired-block row permutation (wrow) makes the 16 lanes of a fragment read rows {0-3, 8-11, 16-19, 24-27} (+4): rows r and
+// r + 16 share (r >> 1) & 7 and lie 2048 B apart -- the same banks.  One more row bit in the XOR key separates them (PMC before: 35 % of
+// the LDS cycles of the kernel were bank conflicts).
+__device__ __forceinline__ int wswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7) ^ (((row >> 4) & 1) << 1)) << 4); }
 // Which output channel sits in MFMA row `lr` of 16-row block j.  The blocks are PAIRED: rows 4q .. 4q + 3 of block 2p are channels
 // 32p + 8q + 0..3 and of block 2p + 1 channels 32p + 8q + 4..7, so that in the transposed accumulators lane group q holds the 8
 // CONSECUTIVE channels 32p + 8q .. + 7 across the pair: intermediates, residual and output move in 16-B pieces.
@@ -83,6 +87,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // slot ^ ((row >> 1) & 7) -- the row groups a wave serves are 8 apart, so that chunk is the same for all of them
   const int drow = lane >> 3;
   const int kc = (lane & 7) ^ ((4 * (uw & 1) + (lane >> 4)) & 7);
+  const int kcw = kc ^ (((uw >> 1) & 1) << 1);          // filter images: wswz key (row >> 4) & 1 = (uw >> 1) & 1 for rows 8 (uw + 8 i) + drow
 
   // validity of halo pixel h (0 .. 323) of this tile: inside the image
   auto halo_pix = [&](int h, int& y, int& x) -> bool {
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int y, x;
     xoff[i] = halo_pix(h, y, x) ? (unsigned)(((img0 + (long long)y * p.W + x) * p.Cin + kc * 8) * 2) : OOB;
   }
-  unsigned w1off = (unsigned)(((8 * uw + drow) * p.Cin + kc * 8) * 2);
+  unsigned w1off = (unsigned)(((8 * uw + drow) * p.Cin + kcw * 8) * 2);
   const int nk1 = p.Cin >> 6;
   auto issue1 = [&](int buf) {
     char* xs = smem + buf * XBUF;
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 wf[4], xf[3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + swz(wrow(j, lr), ks * 4 + lq));
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(j, lr), ks * 4 + lq));
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         if (uw + 8 * i < M1 / 16) xf[i] = *reinterpret_cast<const bf16x8*>(xs + swz((uw + 8 * i) * 16 + lr, ks * 4 + lq));
@@ -170,14 +175,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // the x / w1 buffers are dead: the whole conv2 filter (9 taps) and the conv3 filter stream in under the epilogue, and the first half of
   // the residual tile is requested (x was just read by this CU's XCD: L2 hits)
   {
-    const unsigned w2off = (unsigned)(((8 * uw + drow) * 576 + kc * 8) * 2);
+    const unsigned w2off = (unsigned)(((8 * uw + drow) * 576 + kcw * 8) * 2);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (__attribute__((address_space(3))) void*)(smem + OFF_W2 + tap * 8192 + uw * 1024), 16,
                                                w2off + (unsigned)tap * 128u, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned off = (unsigned)(((8 * (uw + 8 * i) + drow) * 64 + kc * 8) * 2);
+      const unsigned off = (unsigned)(((8 * (uw + 8 * i) + drow) * 64 + kcw * 8) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(smem + OFF_W3 + (uw + 8 * i) * 1024), 16, off, 0, 0, 0);
     }
   }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 wf[4], af[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + swz(wrow(j, lr), ks * 4 + lq));
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(j, lr), ks * 4 + lq));
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(t1 + swz((2 * uw + i + r) * HW_ + lr + s, ks * 4 + lq));
 #pragma unroll
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(t2 + swz((2 * uw + i) * 16 + lr, ks * 4 + lq));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + swz(half * 128 + wrow(j, lr), ks * 4 + lq));
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + wswz(half * 128 + wrow(j, lr), ks * 4 + lq));
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc3[i][j], 0, 0, 0);
       }

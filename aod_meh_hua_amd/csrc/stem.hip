@@ -37,6 +37,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// filter images: the paired-block row permutation (wrow) makes the 16 lanes of a fragment read rows {0-3, 8-11, 16-19, 24-27} (+4): rows r and
+// r + 16 share (r >> 1) & 7 and lie 2048 B apart -- the same banks.  One more row bit in the XOR key separates them (PMC before: 35 % of
+// the LDS cycles of the kernel were bank conflicts).
+__device__ __forceinline__ int wswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7) ^ (((row >> 4) & 1) << 1)) << 4); }
 __device__ __forceinline__ int wrow(int j, int lr) { return (j >> 1) * 32 + (lr >> 2) * 8 + (j & 1) * 4 + (lr & 3); }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_pool_kernel(const StemArgs p) {
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   {
     const int drow = lane >> 3;
-    const int kc = (lane & 7) ^ ((4 * (uw & 1) + (lane >> 4)) & 7);
+    const int kc = (lane & 7) ^ ((4 * (uw & 1) + (lane >> 4)) & 7) ^ (((uw >> 1) & 1) << 1);      // wswz key of rows 8 uw + drow
 #pragma unroll
     for (int R = 0; R < 4; ++R) {
       const unsigned off = (unsigned)(((8 * uw + drow) * 256 + R * 64 + kc * 8) * 2);
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 wf[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + swz(wrow(j, lr), ks * 4 + lq));
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(j, lr), ks * 4 + lq));
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         if (uw + 8 * i < CBLK) {
