@@ -67,9 +67,10 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 
 // OPS: which optional epilogue operands the instance supports -- 0 none, 1 ReLU mask only, 2 residual and mask (their prefetch registers
 // are what pushes the 8-wave form into spills, so it exists without them)
-template <int BM, int BN, int NT, int OPS, bool GROUPED>
+template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+  static_assert(ST == 2 || (ST == 3 && NT == 256), "LDS stages: 2, or 3 for the 4-wave forms");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
   constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // destination row of every tile row, parked in LDS behind the staging / epilogue area (read by the general epilogue, and by the
   // fast one on tiles that straddle a segment boundary)
   constexpr int EPI_BYTES = EBM * CP * 4;
-  constexpr int DROW_OFF = (2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES);
+  constexpr int DROW_OFF = (ST * STAGE > EPI_BYTES ? ST * STAGE : EPI_BYTES);
   long long* s_drow = reinterpret_cast<long long*>(smem + DROW_OFF);
   if (t < BM) {
     const int m = m0 + t;
@@ -440,6 +441,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
   };
+  if (ST == 3) {
+    // Three-stage ring (4-wave forms whose K-step is shorter than a load: one stage ahead, every K-step waits out the rest of a
+    // load latency).  Stage s + 2 is issued at step s, the wait before the barrier names how many younger LDS-DMA instructions may
+    // stay in flight (stage s + 2's: A_IT + B_IT per wave; loads, stores and LDS-DMA complete in issue order), and the barrier is a raw
+    // s_barrier -- a __syncthreads() drains the queue.  The barrier also says that every wave is done reading stage s, whose buffer
+    // stage s + 3 overwrites one step later.  Same K order as the two-stage loop: identical results.
+    constexpr int LPS = A_IT + B_IT;
+    bool have1 = have && __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
+    if (have1) gload(1);
+    int cur = 0;
+    while (have) {
+      const bool more2 = have1 && __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
+      if (more2) gload(cur == 0 ? 2 : cur - 1);
+      const char* sa = smem + cur * STAGE;
+      const char* sb = sa + A_BYTES;
+      frag_read(sa, sb, 0);
+      mfma_block();
+      frag_read(sa, sb, 1);
+      mfma_block();
+      if (!have1) break;
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == 2 ? 0 : cur + 1;
+      have1 = more2;
+    }
+    __syncthreads();      // the epilogue image overlays the ring
+  } else {
   for (int cur = 0; have; cur ^= 1) {
     const bool more = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;
     if (late && carried) mfma_block();
@@ -455,6 +486,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier: next tile is resident afterwards
   }
   if (late && carried) mfma_block();
+  }
 
   if (p.ksplit > 1) {
     // split-K: this slice's fp32 partial tile goes to its own slab, straight from the accumulators (one dword per lane, 16
@@ -641,21 +673,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #undef g_colsum
 #undef AOD_GSEL
 
-template <int BM, int BN, int NT = 256, int OPS = 2, bool GROUPED = false>
+template <int BM, int BN, int NT = 256, int OPS = 2, bool GROUPED = false, int ST = 2>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
   ConvKParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.N + BN - 1) / BN;
-  const size_t stage = (size_t)(BM + BN) * 128 * 2;
+  const size_t stage = (size_t)(BM + BN) * 128 * ST;
   const size_t epi_full = (size_t)BM * (BN + 4) * 4;
   const size_t epi = epi_full > 144 * 1024 ? epi_full / 2 : epi_full;      // (two epilogue passes for the 256 x 256 tile)
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
   return 0;
 }
 
@@ -884,12 +916,15 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     AOD_LAUNCH_CHECK();
     return 0;
   }
-  if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
-  else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);
-  else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128>(p, st);
-  else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
-  else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) launch_conv<128, 64>(p, st);
-  else launch_conv<64, 64>(p, st);
+  // (three LDS stages for the 4-wave tiles of at most 24 KB per stage, when the K loop is long enough to matter: AOD_RING3=0 disables)
+  static const char* dbg_r3 = getenv("AOD_RING3");
+  const bool r3 = !(dbg_r3 && dbg_r3[0] == '0') && p.K >= 256;
+  if (ragged && ntiles(128, 64) >= want) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
+  else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);      // (three stages = 96 KB = one workgroup per CU: measured +0.55 ms per step; 64 x 128 x 3 stages instead: +0.3 ms)
+  else if (p.N > 64 && ntiles(64, 128) >= want) { if (r3) launch_conv<64, 128, 256, 2, false, 3>(p, st); else launch_conv<64, 128>(p, st); }
+  else if (p.N <= 64 && ntiles(128, 64) >= want) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
+  else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
+  else { if (r3) launch_conv<64, 64, 256, 2, false, 3>(p, st); else launch_conv<64, 64>(p, st); }
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -449,3 +449,23 @@ def test_pointwise_streaming_kernel_equals_the_general_kernel(ho, shape):
     assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
     assert float(outs[1][0].float().abs().mean()) > 0.05
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-2)
+
+
+def test_three_stage_ring_equals_the_two_stage_loop(tmp_path):
+    """The small 4-wave conv tiles keep two LDS stages in flight (counted s_waitcnt vmcnt + raw s_barrier instead of __syncthreads();
+    AOD_RING3=0 restores the two-stage loop): same K order per output element, so every result is identical -- forward with BN, residual and
+    ReLU, stride 2, ragged N, dgrad with mask; K from 1 to 72 K-steps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ('0', '1'):
+        f = str(tmp_path / f'ring{flag}.pt')
+        p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dbg', 'ring3_check.py'), f], env=dict(os.environ, AOD_RING3=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[flag] = torch.load(f)
+    assert set(outs['0']) == set(outs['1']) and len(outs['0']) >= 12
+    for k in outs['0']:
+        assert torch.equal(outs['0'][k], outs['1'][k]), k
+        assert float(outs['1'][k].float().abs().mean()) > 1e-3, k
