@@ -916,14 +916,15 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     AOD_LAUNCH_CHECK();
     return 0;
   }
-  // (three LDS stages for the 4-wave tiles of at most 24 KB per stage, when the K loop is long enough to matter: AOD_RING3=0 disables)
+  // (three LDS stages for the 64-row 4-wave tiles when the K loop is long enough to matter: AOD_RING3=0 disables; the 128 x 64 tile keeps
+  // two -- three stages cost it its third workgroup per CU: 61 -> 69 us on the narrow prediction convs)
   static const char* dbg_r3 = getenv("AOD_RING3");
   const bool r3 = !(dbg_r3 && dbg_r3[0] == '0') && p.K >= 256;
-  if (ragged && ntiles(128, 64) >= want) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
+  if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
   else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128>(p, st);      // (three stages = 96 KB = one workgroup per CU: measured +0.55 ms per step; 64 x 128 x 3 stages instead: +0.3 ms)
   else if (p.N > 64 && ntiles(64, 128) >= want) { if (r3) launch_conv<64, 128, 256, 2, false, 3>(p, st); else launch_conv<64, 128>(p, st); }
-  else if (p.N <= 64 && ntiles(128, 64) >= want) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
-  else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) { if (r3) launch_conv<128, 64, 256, 2, false, 3>(p, st); else launch_conv<128, 64>(p, st); }
+  else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64>(p, st);
+  else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) launch_conv<128, 64>(p, st);
   else { if (r3) launch_conv<64, 64, 256, 2, false, 3>(p, st); else launch_conv<64, 64>(p, st); }
   AOD_LAUNCH_CHECK();
   return 0;
