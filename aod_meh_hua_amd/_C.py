@@ -67,6 +67,7 @@ _SIGS = {
     'aod_loss_partials_len': (SZ, [I64]),
     'aod_edl_focal_l1_fwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, P]),
     'aod_edl_focal_l1_bwd': (C.c_int, [P, P, P, P, P, P, I64, I32, F32, F32, P, P, P, F32, I32, P, P, I32, I32, I32, I32, P]),
+    'aod_edl_focal_elem': (C.c_int, [P, P, I64, I32, F32, F32, P, P, P]),
     'aod_meh_loss_fwd': (C.c_int, [P, P, P, I64, P, P, P]),
     'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
     'aod_softmax_rowmax': (C.c_int, [P, I32, I64, I32, F32, P, P, I32, P]),

@@ -66,11 +66,13 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
         from ..graphs import GraphedScore
         # one captured graph per (model, options): a pool is scored once per AL cycle with a freshly built model, but callers that score
         # several pools with one model (bench, tests) must not pay the capture again
-        cache = model.__dict__.setdefault('_aod_gscore_cache', {})
-        key = tuple(sorted((k, str(v)) for k, v in kwargs.items()))
-        gscore = cache.get(key)
-        if gscore is None:
-            gscore = cache[key] = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
+        # (the key holds hashable primitives only; any other option value -> no caching, no graph: str() of a tensor / object could collide)
+        if all(isinstance(v, (bool, int, float, str, type(None))) for v in kwargs.values()):
+            cache = model.__dict__.setdefault('_aod_gscore_cache', {})
+            key = tuple(sorted((k, type(v).__name__, v) for k, v in kwargs.items()))
+            gscore = cache.get(key)
+            if gscore is None:
+                gscore = cache[key] = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
     dev = next(model.parameters()).device
     device_side = hasattr(dataset, 'device_batch')       # images produced on the device (datasets.DevicePhiloxPool): no host collate / H2D
     all_ids = torch.arange(lo, max(hi, lo), dtype=torch.int64).to(dev) if device_side else None

@@ -14,6 +14,18 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
 
 
+def source_digest():
+    """sha256[:16] over the kernel sources + the C-ABI header: the tag that ties a committed PMC summary (profiles/pmc_*.json, written by
+    tools/profile/pmc_passes.sh) to the build it was measured on -- bench.py merges such a file into its line only when the tags agree."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pointwise.h'), os.path.join(HERE, '..', 'include', 'aod_hip.h')]:
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -70,11 +70,13 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
       for (int u = 0; u < 5; ++u) d5[u] = dt[t * 5 + u];
       keep = d5[4] > p.obj_score_thr;
     }
-    if (t < HMAXO) {
-      const unsigned long long m = __ballot(keep);
-      if ((t & 63) == 0) s_warp[t >> 6] = __popcll(m);
-      const int within = __popcll(m & ((1ull << (t & 63)) - 1ull));
-      __syncthreads();
+    // (one barrier outside the predicate: every thread of the workgroup reaches it)
+    const bool head = t < HMAXO;
+    const unsigned long long m = __ballot(keep);
+    if (head && (t & 63) == 0) s_warp[t >> 6] = __popcll(m);
+    const int within = __popcll(m & ((1ull << (t & 63)) - 1ull));
+    __syncthreads();
+    if (head) {
       int off = 0;
       for (int k = 0; k < (t >> 6); ++k) off += s_warp[k];
       if (keep) {
@@ -83,8 +85,6 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
         obox[o][4] = (d5[2] - d5[0]) * (d5[3] - d5[1]);
       }
       if (t == 0) { const int no = s_warp[0] + s_warp[1] + s_warp[2] + s_warp[3]; s_no = no; p.nobj[b] = no; }
-    } else {
-      __syncthreads();
     }
     __syncthreads();      // (s_warp is reused by the pair scan below)
   }

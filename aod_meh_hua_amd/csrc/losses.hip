@@ -320,3 +320,64 @@ extern "C" int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const f
   AOD_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Elementwise form [rows, C] of the EDL softmax-focal loss: what EDL_Softmax_FocalLoss.forward(reduction='none') returns in the
+// reference (EDL_Softmax_FocalLoss.py:51-69 -> mmcv sigmoid_focal_loss(..., 'none')).  Lambda_L2Net.loss_single never needs it (its
+// 'none' caller sums over the classes at once, Lambda_L2.py:116: the fused row kernel above) -- this serves stand-alone drop-in callers.
+// One lane per row, classes streamed from global memory in three passes (same formulas and order as edl_row_fwd); not a hot kernel.
+__device__ __forceinline__ float edl_elem_terms(float pr, bool pos, float gamma, float alpha, float* gz_out) {
+  const float om = 1.f - pr + 1e-9f;
+  const float u = l_div(pr, om);
+  const float z = l_log(u + 1e-9f);
+  const float q = l_div(1.f, 1.f + l_exp(-z));
+  const float lg = l_log(fmaxf(pos ? q : 1.f - q, FLT_MIN_F));
+  if (gz_out) {
+    float gz;
+    if (pos) gz = -alpha * focal_pow(1.f - q, gamma) * (1.f - q - gamma * q * lg);
+    else gz = -(1.f - alpha) * focal_pow(q, gamma) * (gamma * (1.f - q) * lg - q);
+    *gz_out = l_div(gz * (1.f + 1e-9f), om * om * (u + 1e-9f));       // d l / d p
+  }
+  return pos ? -alpha * focal_pow(1.f - q, gamma) * lg : -(1.f - alpha) * focal_pow(q, gamma) * lg;
+}
+
+__global__ __launch_bounds__(256) void edl_elem_kernel(const float* __restrict__ cls, const long long* __restrict__ labels, long long nrows, int C,
+                                                      float gamma, float alpha, const float* __restrict__ g, float* __restrict__ out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  const float* x = cls + r * C;
+  float m = -INFINITY;
+  for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+  float S = 0.f;
+  for (int c = 0; c < C; ++c) S += l_exp(x[c] - m);
+  const long long label = labels[r];
+  if (!g) {                    // forward: out[r][c] = l_c
+    for (int c = 0; c < C; ++c) out[r * C + c] = edl_elem_terms(l_div(l_exp(x[c] - m), S), label == c, gamma, alpha, nullptr);
+    return;
+  }
+  // backward: out[r][k] = p_k * (G_k - sum_c p_c G_c),  G_c = g[r][c] * d l_c / d p_c
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float pr = l_div(l_exp(x[c] - m), S);
+    float dl;
+    edl_elem_terms(pr, label == c, gamma, alpha, &dl);
+    dot += pr * (g[r * C + c] * dl);
+  }
+  for (int c = 0; c < C; ++c) {
+    const float pr = l_div(l_exp(x[c] - m), S);
+    float dl;
+    edl_elem_terms(pr, label == c, gamma, alpha, &dl);
+    out[r * C + c] = pr * (g[r * C + c] * dl - dot);
+  }
+}
+
+extern "C" int aod_edl_focal_elem(const float* cls, const int64_t* labels, int64_t nrows, int C, float gamma, float alpha,
+                                  const float* grad_out, float* out, aod_stream_t stream) {
+  if (nrows == 0) return 0;
+  AOD_CHECK_ARG(cls && labels && out, "edl_elem: null pointer");
+  AOD_CHECK_ARG(C >= 1, "edl_elem: C=%d out of range", C);
+  hipLaunchKernelGGL(edl_elem_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cls, (const long long*)labels,
+                     (long long)nrows, C, gamma, alpha, grad_out, out);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

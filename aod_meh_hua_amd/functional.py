@@ -79,6 +79,10 @@ class ParamPrep:
 
     def __init__(self):
         self.items, self.order, self.table, self.dirty, self.tables = {}, [], None, True, {}
+        self.stems = []                   # weak references to stem convs whose derived space-to-depth filter is a registered weight
+
+    def watch_stem(self, conv):
+        self.stems = [r for r in self.stems if r() is not None and r() is not conv] + [_weakref.ref(conv)]
 
     def _versions(self, it):
         return tuple(-1 if t is None else t._version for t in (r() if r is not None else None for r in it.srcs))
@@ -115,6 +119,10 @@ class ParamPrep:
         return it
 
     def refresh_if_stale(self):
+        for r in self.stems:              # derived weights first: an in-place rewrite bumps the version the items below watch
+            conv = r()
+            if conv is not None and not torch.cuda.is_current_stream_capturing():
+                _stem_w4(conv)
         if any(it.ver != self._versions(it) for it in self.items.values()):
             self.refresh()
 
@@ -515,15 +523,22 @@ def bottleneck64_fwd(x, blk, identity):
 
 def _stem_w4(conv):
     """[O, C, 7, 7] stem filter regrouped for the space-to-depth input: [O, 4C, 4, 4] with w4[o, (dy*2+dx)*C + c, R, S] =
-    w7[o, c, 2R + dy - 1, 2S + dx - 1] (zero where that tap index is -1); cached on the module until the weight changes."""
+    w7[o, c, 2R + dy - 1, 2S + dx - 1] (zero where that tap index is -1).  ONE persistent tensor per conv module, rewritten IN PLACE when
+    the 7x7 weight's version changes: captured HIP graphs and the parameter-preparation table keep pointing at valid memory, and
+    PREP.refresh_if_stale() (which runs before every graph replay) re-checks the watched convs, so a load_state_dict / resume / broadcast
+    into the frozen stem after a capture reaches the replays."""
     w7 = conv.weight
     ent = conv.__dict__.get('_aod_w4')
-    if ent is None or ent[0] != w7._version or ent[1].device != w7.device:
+    if ent is None or ent[1].device != w7.device or ent[2]() is not conv:        # (a deep-copied module carries its source's entry)
+        O, Cc = w7.shape[:2]
+        ent = conv.__dict__['_aod_w4'] = [None, torch.empty(O, 4 * Cc, 4, 4, dtype=torch.float32, device=w7.device), _weakref.ref(conv)]
+        PREP.watch_stem(conv)
+    if ent[0] != w7._version:
         O, Cc = w7.shape[:2]
         wp = torch.zeros(O, Cc, 8, 8, dtype=torch.float32, device=w7.device)
         wp[:, :, 1:, 1:] = w7.detach().float()                                   # index r + 1 = 2R + dy
-        w4 = wp.view(O, Cc, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(O, 4 * Cc, 4, 4).contiguous()    # [o, dy, dx, c, R, S]
-        ent = conv.__dict__['_aod_w4'] = (w7._version, w4)
+        ent[1].copy_(wp.view(O, Cc, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(O, 4 * Cc, 4, 4))     # [o, dy, dx, c, R, S]
+        ent[0] = w7._version
     return ent[1]
 
 

@@ -50,10 +50,10 @@ class GraphedTrainStep:
     """Capture-once / replay of run_iter.  Captured graphs are cached per input signature (a few shapes alternate with aspect-ratio
     grouped VOC batches).  Building a graph needs eager warm-up iterations (allocator pools, row tables, parameter-preparation
     registration): parameters, momentum buffers and BN buffers are snapshotted before and restored after, so the batch that triggers a
-    capture is applied exactly ONCE (by the first replay), like every other batch.  Under data parallelism the capture-or-eager decision
-    is collective (every rank must issue the same sequence of all-reduces), gradients live in the static slices of GradSync's flat buffer
-    and the all-reduces run eagerly between the captured segments."""
-    MAX_GRAPHS = 4
+    capture is applied exactly ONCE (by the first replay), like every other batch.  Under data parallelism gradients live in the static
+    slices of GradSync's flat buffer and the all-reduces run eagerly between the captured segments; building a graph issues NO collective
+    (warm-up runs without communication), so capture / replay / eager are interchangeable per rank and per iteration."""
+    MAX_GRAPHS = 16
 
     def __init__(self, model, optimizer, optimizer_L, grad_sync=None, gmax=64, warmup=2, **step_kwargs):
         self.model, self.module = model, _unwrap(model)
@@ -147,10 +147,16 @@ class GraphedTrainStep:
         elif i == 2:
             self.sync.start(self._params(self.opt_L), sources=cur.get('src_L')).wait()
 
-    def _run_eager(self):
+    def _run_eager(self, comm=True):
+        """comm=False (warm-up before a capture): NO collective is issued -- the iteration is undone afterwards anyway (_restore), and a
+        rank that captures must issue exactly the collectives of a rank that replays or runs eagerly (ranks see different batch shapes
+        with keep-ratio VOC data and keep their own graph caches: one rank may capture while its peers replay)."""
         for i, f in enumerate((self._seg_a, self._seg_b, self._seg_c, self._seg_d)):
             f()
-            self._between(i)
+            if comm:
+                self._between(i)
+            elif self.sync is not None and i < 2:         # hand the flat-buffer slices back to the next backward (what start() does)
+                self.sync.release(self._params(self.opt if i == 0 else self.opt_L))
 
     # ------------------------------------------------------------------ state snapshot around warm-up
     def _snapshot(self):
@@ -192,7 +198,7 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup):
-                self._run_eager()
+                self._run_eager(comm=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ho.reset_zero_arena()                     # accumulators handed out during capture must be zeroed INSIDE the graph
@@ -222,25 +228,17 @@ class GraphedTrainStep:
         return self.cur
 
     # ------------------------------------------------------------------ call
-    def _agree(self, want):
-        """Data parallelism: replay / capture only when EVERY rank wants to (ranks see different batch shapes with keep-ratio VOC data;
-        a rank that captured while its peers ran eagerly would issue a different number of all-reduces)."""
-        from .parallel import is_dist
-        if self.sync is None or not is_dist():
-            return want
-        import torch.distributed as dist
-        t = torch.tensor([int(want)], device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t))
-
     def maybe(self, data_batch):
         """Replay when this input shape is cached, capture when it was also the previous call's shape (second consecutive appearance);
-        otherwise return None and let the caller run the iteration eagerly (multi-scale data would re-capture on every batch)."""
+        otherwise return None and let the caller run the iteration eagerly (multi-scale data would re-capture on every batch).
+        The decision is RANK-LOCAL under data parallelism: an eager iteration, a replay and a capture + first replay all issue the same
+        sequence of bucket all-reduces (main buckets after the main backward, MEH buckets after the MEH backward; building a graph sends
+        nothing), so ranks need not agree and no per-iteration flag all-reduce / host sync is paid."""
         d = _plain(data_batch, self.dev)
         sig = self._signature(d)
         want = sig in self.cache or sig == self.last_sig
         self.last_sig = sig
-        if not self._agree(want):
+        if not want:
             return None
         return self(data_batch)
 
@@ -274,10 +272,20 @@ class GraphedScore:
     """One HUA scoring batch: model(img=[img], img_metas=[metas], image_ids=ids, **kw) under no_grad -> unc [B] (a copy)."""
 
     def __init__(self, model, warmup=2, **score_kwargs):
-        self.model, self.module = model, _unwrap(model)
+        import weakref
+        # the model is held WEAKLY: single_gpu_uncertainty caches this object on the model itself, and a strong reference back would be a
+        # cycle that keeps a dead cycle's graph memory pool + static image buffers alive until the cyclic collector happens to run
+        self._model = weakref.ref(_unwrap(model))
         self.kw, self.warmup = score_kwargs, warmup
         self.sig, self.graph = None, None
-        self.dev = next(self.module.parameters()).device
+        self.dev = next(_unwrap(model).parameters()).device
+
+    @property
+    def module(self):
+        m = self._model()
+        if m is None:
+            raise RuntimeError('GraphedScore outlived its model')
+        return m
 
     def _run(self):
         with torch.no_grad():

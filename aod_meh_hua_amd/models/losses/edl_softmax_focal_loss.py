@@ -33,6 +33,28 @@ class _EDLFocalFn(Function):
         return gc, None, None, None
 
 
+class _EDLFocalElemFn(Function):
+    """[N, C] elementwise loss (reduction='none' / weighted reductions with per-element weights), aod_edl_focal_elem"""
+
+    @staticmethod
+    def forward(ctx, pred, target, gamma, alpha):
+        pred, target = pred.contiguous(), target.contiguous()
+        out = torch.empty_like(pred)
+        ho.call('aod_edl_focal_elem', ho.ptr(pred), ho.ptr(target), pred.shape[0], pred.shape[1], float(gamma), float(alpha), None, ho.ptr(out), ho.stream())
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (gamma, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        gamma, alpha = ctx.cfg
+        g = g.float().contiguous()
+        out = torch.empty_like(pred)
+        ho.call('aod_edl_focal_elem', ho.ptr(pred), ho.ptr(target), pred.shape[0], pred.shape[1], float(gamma), float(alpha), ho.ptr(g), ho.ptr(out), ho.stream())
+        return out, None, None, None
+
+
 @LOSSES.register_module()
 class EDL_Softmax_FocalLoss(nn.Module):
     def __init__(self, num_classes, annealing_step, last_activation='sigmoid', gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
@@ -41,16 +63,28 @@ class EDL_Softmax_FocalLoss(nn.Module):
         self.gamma, self.alpha, self.reduction, self.loss_weight = gamma, alpha, reduction, loss_weight
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
-        """Returns the per-ROW loss (sum over classes) for reduction 'none' -- the reference returns [N, C] and
-        its only 'none' caller immediately sums over classes (Lambda_L2.py:116) -- else the reduced scalar."""
+        """EDL_Softmax_FocalLoss.py:51-69 + the wrapper :9-27 + weight_reduce_loss (losses/utils.py:28-54).  reduction 'none' returns the
+        elementwise [N, C] loss like the reference; the reduced forms with a per-row (or no) weight use the fused row kernel (the sum over
+        classes commutes with a per-row weight), per-element weights go through the elementwise kernel."""
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
+        N, C = pred.shape
+        per_elem_w = weight is not None and weight.numel() == N * C and C > 1
+        if reduction == 'none' or per_elem_w:
+            loss = _EDLFocalElemFn.apply(pred.float(), target, self.gamma, self.alpha)
+            if weight is not None:
+                loss = loss * (weight.reshape(N, -1) if weight.numel() != N else weight.reshape(N, 1))
+            loss = self.loss_weight * loss
+            if reduction == 'none':
+                return loss
+            if avg_factor is not None:
+                assert reduction == 'mean', 'avg_factor can not be used with reduction="sum"'
+                return loss.sum() / avg_factor
+            return loss.sum() if reduction == 'sum' else loss.mean()
         row = self.loss_weight * _EDLFocalFn.apply(pred.float(), target, self.gamma, self.alpha)
         if weight is not None:
             row = row * weight.reshape(-1)
-        if reduction == 'none':
-            return row.unsqueeze(-1)
         if avg_factor is not None:
-            assert reduction == 'mean'
+            assert reduction == 'mean', 'avg_factor can not be used with reduction="sum"'
             return row.sum() / avg_factor
-        return row.sum() if reduction == 'sum' else row.sum() / (pred.shape[0] * pred.shape[1])
+        return row.sum() if reduction == 'sum' else row.sum() / (N * C)

@@ -110,6 +110,12 @@ class GradSync:
                 for d, s_ in zip(dsts, srcs):
                     d.copy_(s_)
 
+    def release(self, params):
+        """Hand the parameters' flat-buffer slices back to the next backward pass WITHOUT communicating (graph warm-up iterations):
+        the bookkeeping half of start()."""
+        for p in params:
+            p.__dict__.pop('_aod_view_busy', None)
+
     def start(self, params, sources=None):
         """Launch the bucketed all-reduce of the parameters' gradients WITHOUT waiting (RCCL runs it on its own stream).  Returns a
         handle whose wait() must be called before the gradients are read.  `sources`: gradient tensors to read instead of p.grad (the

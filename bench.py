@@ -143,12 +143,22 @@ def hua_stats(model, pool, score_kw, dev, reps=20):
     out = dict(bound='valu', pairs_per_img=round(pairs / B, 1), objects_per_img=round(float(nobj.float().mean()), 1),
                nonzero_scores=int((unc > 0).sum()), hua_us_per_batch=round(us, 1), us_per_pair=round(us / max(pairs, 1), 4),
                gamma_variates_per_s=round(pairs * 500 * nd / (us * 1e-6), 0) if pairs else 0.0, samples_per_pair=500, dirichlet_columns=nd)
-    try:      # VALU utilisation of hua_sample_kernel from the separate rocprofv3 --pmc pass (tools/dbg/pmc_hua.sh), committed under profiles/
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_hua_pmc.json')))
-        out.update(valu_util=pm.get('valu_util'), valu_util_source='profiles/r02_hua_pmc.json')
-    except Exception:      # noqa: BLE001
-        out.update(valu_util=None)
+    pm = pmc_summary('pmc_hua.json')        # separate rocprofv3 --pmc pass of THIS build (tools/profile/pmc_passes.sh), else null
+    out.update(valu_util=pm.get('valu_util') if pm else None, valu_issue_frac_of_peak=pm.get('valu_issue_frac_of_peak') if pm else None,
+               valu_util_source=f'profiles/pmc_hua.json @ kernels {pm["kernels_sha16"]}' if pm else None)
     return out
+
+
+def pmc_summary(name):
+    """A committed PMC summary (profiles/<name>, written by tools/profile/pmc_passes.sh: rocprofv3 --pmc cannot run inside a timed bench) is
+    merged into the line ONLY when it was measured on this very build: its `kernels_sha16` must equal the digest of the kernel sources.
+    Otherwise the field is null -- a stale counter in a live line is worse than none."""
+    try:
+        from aod_meh_hua_amd.build import source_digest
+        pm = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        return pm if pm.get('kernels_sha16') == source_digest() else None
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def make_optimizers(model, cfg):
@@ -166,8 +176,24 @@ SCORE_KW = dict(return_loss=False, rescale=True, isEval=False, isUnc='Epistemic'
                 scaleUnc=False, showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU, the way the
+    reference's launcher does: tools/train_RetinaNet.py:119-121 init_dist(args.launcher, ...)).  Runs BEFORE anything touches the GPU and as
+    a CHILD process (a process that has initialised HIP must never exec another program); returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     cd = dict(CONFIGS[args.config])
     if args.size:
         cd.update(H=args.size, W=args.size, name=cd['name'] + f' [resized to {args.size}x{args.size}]')
@@ -179,6 +205,8 @@ def main():
     # single-GPU box); the driver's multi-GPU runs use one GPU per rank over RCCL
     one_gpu = os.environ.get('AOD_BENCH_ONE_GPU') == '1'
     local = 0 if one_gpu else local
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (a line must not measure fewer ranks than it names)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
@@ -187,6 +215,10 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+    comm = dict(backend=None, ranks=1)
+    if world > 1:
+        comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=dist.get_world_size())
+        assert comm['ranks'] == args.gpus
     from aod_meh_hua_amd import hipops as ho
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
     import aod_meh_hua_amd.scoring  # noqa: F401      (the HIP scoring pass is part of the product: no fallback)
@@ -201,7 +233,7 @@ def main():
     broadcast_model(pool_model)               # every rank scores with rank 0's calibrated head
 
     if args.mode == 'pool':
-        return pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac)
+        return pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac, comm)
 
     opt, opt_L = make_optimizers(model, cfg)
     gsync = GradSync()
@@ -345,24 +377,22 @@ def main():
         ho.PROFILE = ho.BYTES_PROFILE = None
         kind = max(agg, key=lambda k: agg[k][1])
         n, tsec, fl = agg[kind]
-        # HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass (tools/dbg/pmc_bench.sh), corrected as
-        # MI355X_MICROARCH.md prescribes (128 B per non-32B read request on gfx950); measured offline, committed under profiles/
-        traffic = None
-        for pf in ('r02_pmc_hbm_traffic_per_launch.json', 'r01n_pmc_hbm_traffic_per_launch.json'):
-            try:
-                pm = json.load(open(os.path.join(ROOT, 'profiles', pf)))
-                # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants of the 128 x 128 tile)
-                # forward / dgrad: every instance of the implicit-GEMM kernel plus the fused forward kernels (bottleneck, stem, pointwise)
-                pref = ('conv_wgrad_kernel',) if kind == 'wgrad' else ('conv_igemm_kernel', 'bottleneck64_fwd_kernel', 'stem_pool_kernel', 'pw_gemm_kernel')
-                ks = [k for k in pm if any(q in k for q in pref)]
-                nl = sum(pm[k]['launches'] for k in ks)
-                traffic = round(sum((pm[k]['read_MB_per_launch'] + pm[k]['write_MB_per_launch']) * pm[k]['launches'] for k in ks) / nl * 1e6)
-                break
-            except Exception:      # noqa: BLE001
-                pass
+        # HBM-side bytes per launch of the dominant kernel class: separate rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass of THIS build
+        # (tools/profile/pmc_passes.sh; corrected as MI355X_MICROARCH.md prescribes: 128 B per non-32B read request on gfx950), null when the
+        # committed summary belongs to another build
+        traffic, traffic_src = None, None
+        pm = pmc_summary('pmc_traffic.json')
+        if pm:
+            # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants, fused forward kernels)
+            pref = ('conv_wgrad_kernel',) if kind == 'wgrad' else ('conv_igemm_kernel', 'bottleneck', 'stem_pool_kernel', 'pw_gemm_kernel', 'pred_conv')
+            ks = [k for k in pm['kernels'] if any(q in k for q in pref)]
+            nl = sum(pm['kernels'][k]['launches'] for k in ks)
+            if nl:
+                traffic = round(sum((pm['kernels'][k]['read_MB_per_launch'] + pm['kernels'][k]['write_MB_per_launch']) * pm['kernels'][k]['launches'] for k in ks) / nl * 1e6)
+                traffic_src = f'profiles/pmc_traffic.json @ kernels {pm["kernels_sha16"]}'
         roof = dict(bound='mfma', kernel={'fwd': 'conv_igemm_kernel (forward)', 'dgrad': 'conv_igemm_kernel (dgrad)', 'wgrad': 'conv_wgrad_kernel'}[kind],
                     achieved=round(fl / tsec / 1e12, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4),
-                    traffic=traffic, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
+                    traffic=traffic, traffic_source=traffic_src, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
                     flops_rule='algorithmic: 2*M*R*S*Cin*Cout of the reference layer (channel pads of the stem / prediction convs excluded)',
                     all={k: dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in agg.items()},
                     # the HBM-bound row kernels of the same step: algorithmic bytes / summed launch time (HIP events), fraction of 8 TB/s
@@ -409,7 +439,8 @@ def main():
                                                   'images/GPU (pool scored by a frozen copy with a calibrated, trained-like head)') if phases == 2
                                 else f'images per second through the {args.mode} phase',
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
-                                parallelism=f'dp{world}', phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
+                                parallelism=f'dp{world}', collective_ranks=comm['ranks'], collective_backend=comm['backend'],
+                                phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
                                 arithmetic='bf16 x bf16 -> fp32 MFMA convolutions; fp32 losses / geometry / scoring / optimizer'),
                     phase_rates=phase, hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
@@ -418,7 +449,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac):
+def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac, comm):
     """BASELINE configs[3]: HUA scoring of an unlabeled pool of --pool synthetic images, generated ON the device from
     Philox(seed=20, image id), through the product's own pool loop (apis/test.py single_gpu_uncertainty: contiguous shard per rank,
     HIP-graph replay per batch, ONE all-gather of the scores at the end).  A step = one batch of B images of this rank's shard."""
@@ -474,6 +505,7 @@ def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac):
                     config=dict(workload=f'{cd["name"]}: HUA unlabeled-pool scoring only, {args.pool} on-device Philox(seed=20, image id) images, '
                                          f'contiguous shard per rank, batches of {B}, one score all-gather',
                                 pool=args.pool, global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], parallelism=f'dp{world}',
+                                collective_ranks=comm['ranks'], collective_backend=comm['backend'],
                                 launch='hip-graph replay inside apis/test.py single_gpu_uncertainty'),
                     pool=dict(nonzero_scores=int((unc_h > 0).sum()), mean_score=round(float(unc_h.mean()), 5), gpu_ms=round(e0.elapsed_time(e1), 2),
                               wall_ms=round(dt * 1e3, 2), host_gap_ms=round(dt * 1e3 - e0.elapsed_time(e1), 2), selection=sel,

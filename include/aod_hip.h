@@ -212,6 +212,11 @@ int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, const float* l
                          const float* g_cls, const float* g_bbox, const float* g_noR, float g_noR_scalar, int g_noR_is_scalar,
                          void* grad_cls, void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box,
                          aod_stream_t stream);
+/* Elementwise form [Nrows, C] of the same loss: what EDL_Softmax_FocalLoss.forward(reduction='none') returns
+ * (EDL_Softmax_FocalLoss.py:51-69 -> mmcv.ops.sigmoid_focal_loss(..., 'none'), :17).  grad_out == NULL: out[r][c] = l_c (forward);
+ * grad_out = upstream gradient [Nrows, C]: out = gradient w.r.t. the logits (backward through softmax -> logit -> focal term). */
+int aod_edl_focal_elem(const float* cls, const int64_t* labels, int64_t nrows, int C, float gamma, float alpha,
+                       const float* grad_out, float* out, aod_stream_t stream);
 /* MEH loss (Lambda_L2.py:235-241): out_sum[0] += sum(((|lam+1e-9-loss|)*w)^2), w = bbox_w4[i*4];
  * grad = g[0]*2*w^2*(lam+1e-9-loss) written at (i / A) * pitch + i % A.  partials: >= aod_loss_partials_len(n) floats */
 int aod_meh_loss_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n,

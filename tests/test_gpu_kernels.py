@@ -353,6 +353,36 @@ def test_losses_match_reference_golden(ho):
     assert np.allclose(gl.cpu().numpy().reshape(-1), gold['grad_lam'], rtol=1e-4, atol=1e-9)
 
 
+def test_edl_module_reduction_none_is_elementwise_like_the_reference(ho):
+    """EDL_Softmax_FocalLoss.forward(reduction='none') returns the [N, C] elementwise loss (EDL_Softmax_FocalLoss.py:51-69): its class sum is
+    the reference's golden loss_noR (tools/golden/make_golden.py: `head.loss_cls(x, labels, reduction_override='none').sum(-1)`), values and
+    gradients match the oracle's autograd, and the weighted / averaged reductions agree with the fused row kernel."""
+    from aod_meh_hua_amd.models.losses.edl_softmax_focal_loss import EDL_Softmax_FocalLoss
+    gold = np.load(os.path.join(G, 'losses.npz'))
+    li = synth.loss_inputs()
+    mod = EDL_Softmax_FocalLoss(num_classes=20, annealing_step=1, last_activation='relu')
+    x = li['logits'].cuda().requires_grad_(True)
+    lab = li['labels'].cuda()
+    el = mod(x, lab, reduction_override='none')
+    assert el.shape == (1024, 20)
+    assert np.allclose(el.sum(-1).detach().cpu().numpy(), gold['loss_noR'], rtol=2e-5, atol=1e-7)
+    xr = li['logits'].clone().requires_grad_(True)
+    ref = olosses.edl_softmax_focal_none(xr, li['labels'])
+    assert close(el.detach(), ref.detach(), 2e-5, 1e-7)
+    g = torch.rand(1024, 20, generator=synth.gen(3))
+    (el * g.cuda()).sum().backward()
+    (ref * g).sum().backward()
+    assert close(x.grad, xr.grad, 1e-3, 1e-7)
+    # per-row weights + avg_factor (the reference's loss_cls call, Lambda_L2.py:118): fused row kernel == elementwise kernel
+    w = li['label_weights'].cuda()
+    a = mod(x, lab, w, avg_factor=li['num_total_samples'])
+    b = (mod(x, lab, reduction_override='none') * w[:, None]).sum() / li['num_total_samples']
+    assert np.allclose(float(a), float(b), rtol=1e-5) and np.allclose(float(a), gold['loss_cls'], rtol=1e-5)
+    we = torch.rand(1024, 20, generator=synth.gen(4)).cuda()          # per-element weights (weight_reduce_loss, losses/utils.py:28-54)
+    c = mod(x, lab, we, reduction_override='sum')
+    assert np.allclose(float(c), float((ref.detach() * we.cpu()).sum()), rtol=1e-4)
+
+
 def test_losses_edge_cases(ho):
     """All-background rows, extreme logits (softmax saturation -> clamps), zero rows."""
     x = torch.tensor([[50., -50.] + [0.] * 18, [-80.] * 19 + [80.], [0.] * 20], device='cuda')

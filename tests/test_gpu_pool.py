@@ -1,0 +1,98 @@
+"""GPU: BASELINE configs[3] -- HUA scoring of an on-device Philox pool through the product's own pool loop
+(apis/test.py single_gpu_uncertainty <- mmdet/apis/test.py:90-135; caller tools/train_RetinaNet.py:221-246).
+
+  * datasets.DevicePhiloxPool images == the numpy restatement of the Philox stream (oracle/pool.py): a pool image is a pure function of
+    (seed, image id);
+  * the scores of a 200-image 512x512 pool are BIT-equal for batch sizes 16 and 5 (ragged last batch, eager and HIP-graph replay paths
+    mixed) and for a 2-shard split (what two ranks would score: shard_range blocks scored separately and concatenated -- the
+    all-gather itself is covered by tests/test_distributed_cpu.py), so `update_X_L` selects identical images."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+N_POOL, SIZE = 200, 512
+KW = dict(isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', scaleUnc=False, showNMS=False, saveUnc=False,
+          saveMaxConf=False, clsW=False)
+
+
+class Loader:
+    """what single_gpu_uncertainty reads from a DataLoader"""
+
+    def __init__(self, ds, bs):
+        self.dataset, self.batch_size, self.collate_fn = ds, bs, None
+
+
+@pytest.fixture(scope='module')
+def pool_model():
+    import bench
+    dev = torch.device('cuda', 0)
+    model, _ = bench.build_model(dev, dict(bench.CONFIGS['voc512']))
+    from aod_meh_hua_amd.datasets import DevicePhiloxPool
+    cal = DevicePhiloxPool(4, (SIZE, SIZE), seed=21).device_batch([0, 1, 2, 3], dev)['img'][0].clone()
+    bench.calibrate_head(model, cal)           # trained-like head: ~0.5 % of the anchors above the 0.3 foreground threshold
+    return model.eval()
+
+
+def test_pool_images_equal_the_numpy_philox_restatement():
+    from aod_meh_hua_amd.datasets import DevicePhiloxPool
+    from oracle.pool import philox_normal_image
+    dev = torch.device('cuda', 0)
+    ds = DevicePhiloxPool(1 << 40, (64, 96), seed=20)
+    ids = [0, 7, 123456, (1 << 33) + 5]
+    img = ds.device_batch(ids, dev)['img'][0].cpu().numpy()
+    assert img.shape == (4, 3, 64, 96)
+    for k, i in enumerate(ids):
+        ref = philox_normal_image(20, i, 3 * 64 * 96).reshape(3, 64, 96)
+        np.testing.assert_allclose(img[k], ref, rtol=2e-5, atol=2e-5)
+    # a different seed / id is a different image; the same (seed, id) inside another batch is the same image, bit for bit
+    again = ds.device_batch([5, 123456], dev)['img'][0].cpu().numpy()
+    assert np.array_equal(again[1], img[2]) and not np.array_equal(again[0], img[0])
+    other = DevicePhiloxPool(8, (64, 96), seed=21).device_batch([0], dev)['img'][0].cpu().numpy()
+    assert not np.array_equal(other[0], img[0])
+    full = np.concatenate([img[k].ravel() for k in range(4)])
+    assert abs(full.mean()) < 0.02 and abs(full.std() - 1.0) < 0.02
+
+
+def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch):
+    from aod_meh_hua_amd.apis import test as apis_test
+    from aod_meh_hua_amd.apis.test import single_gpu_uncertainty
+    from aod_meh_hua_amd.datasets import DevicePhiloxPool
+    from aod_meh_hua_amd.parallel import shard_range
+    from aod_meh_hua_amd.utils.active_datasets import update_X_L
+    ds = DevicePhiloxPool(N_POOL, (SIZE, SIZE), seed=20)
+    with torch.no_grad():
+        u16 = single_gpu_uncertainty(pool_model, Loader(ds, 16), **KW).cpu().numpy()           # 12 full batches (graph replay) + one of 8
+        u5 = single_gpu_uncertainty(pool_model, Loader(ds, 5), **KW).cpu().numpy()             # 40 batches of 5
+        # what rank r of a 2-rank run scores: the loop's own shard_range block with GLOBAL image ids (the all-gather is replaced by
+        # the identity here and covered by tests/test_distributed_cpu.py)
+        parts = []
+        monkeypatch.setattr(apis_test, 'gather_scores', lambda local, n_total: local)
+        for r in range(2):
+            monkeypatch.setattr(apis_test, 'get_dist_info', lambda r=r: (r, 2))
+            parts.append(single_gpu_uncertainty(pool_model, Loader(ds, 16), **KW).cpu().numpy())
+            lo, hi, _ = shard_range(N_POOL, r, 2)
+            assert parts[-1].shape == (hi - lo,)
+        monkeypatch.undo()
+    assert u16.shape == (N_POOL,) and np.isfinite(u16).all()
+    assert (u16 > 0).sum() >= N_POOL // 2, 'degenerate pool: the calibrated head should give most images a non-zero score'
+    assert np.array_equal(u16, u5), np.abs(u16 - u5).max()
+    assert np.array_equal(u16, np.concatenate(parts))
+    sel = []
+    for u in (u16, u5, np.concatenate(parts)):
+        np.random.seed(20)
+        sel.append(update_X_L(u.astype(np.float64), np.arange(N_POOL), np.arange(10), 20, zeroRate=0.15))
+    for a, b in sel[1:]:
+        assert np.array_equal(a, sel[0][0]) and np.array_equal(b, sel[0][1])
+    # a deep copy scores identically (the captured scoring graph is per model, the Philox stream is keyed by the image id only)
+    m2 = copy.deepcopy(pool_model)
+    with torch.no_grad():
+        u2 = single_gpu_uncertainty(m2, Loader(ds, 16), **KW).cpu().numpy()
+    assert np.array_equal(u2, u16)

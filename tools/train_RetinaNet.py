@@ -47,7 +47,7 @@ def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size
     p.add_argument('--resume-from')
     p.add_argument('--load-from')
     p.add_argument('--bbox-head')
-    p.add_argument('--no-validate', default=True)
+    p.add_argument('--no-validate', default=False, help='whether not to evaluate during training')
     p.add_argument('--gpu-ids', type=int, default=[0], nargs='+')
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     p.add_argument('--local_rank', type=int, default=0)
@@ -99,6 +99,7 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
         ds = dict(type='SyntheticVOCDataset', size=(args.synthetic_size, args.synthetic_size), ann_file=[ann])
         cfg.data.train = dict(type='RepeatDataset', times=cfg.X_L_repeat, dataset=dict(ds))
         cfg.data.test = dict(ds)
+        cfg.data.val = dict(ds, ann_file=None, indices=list(range(min(n, 8))))        # (no VOC2007 test split offline: a few pool images)
         cfg.X_L_0_size, cfg.X_S_size = max(n // 8, 1), max(n // 16, 1)
     if args.cycles is not None:
         cfg.cycles = list(range(args.cycles))
@@ -138,18 +139,23 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
             load_checkpoint(model, f'{cfg.save_dir}/{cfg_name}_Cycle{load_cycle}_Epoch{cfg.runner.max_epochs}_mycode.pth')
         datasets = [build_dataset(cfg.data.train)]
         model.CLASSES = datasets[0].CLASSES
+        validate = not args.no_validate                                       # :60,193,210 (the reference evaluates unless told not to)
         for epoch in range(cfg.outer_epoch):
             cfg.lr_config.step = [1000]
+            if epoch != cfg.outer_epoch - 1:                                  # :179-183
+                cfg.evaluation.interval = 100
             cfg.optimizer['lr'] = 0.001
             if epoch == 0:
                 logger.info(f'Epoch = {epoch}, First Label Set Training')
                 cfg.total_epochs = cfg.epoch_ratio[0]
-                train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=False, timestamp=timestamp, meta=meta)
+                train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=validate, timestamp=timestamp, meta=meta)
+            cfg.evaluation.interval = 100                                     # :198-201: evaluate only at the end of the last outer epoch
             if epoch == cfg.outer_epoch - 1:
                 cfg.lr_config.step = [2]
+                cfg.evaluation.interval = cfg.epoch_ratio[0]
             logger.info(f'Epoch = {epoch}, Fully-Supervised Learning')
             cfg.total_epochs = cfg.epoch_ratio[0]
-            train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=False, timestamp=timestamp, meta=meta)
+            train_detector_SSL(model, [build_dataset(cfg.data.train)], cfg, distributed=distributed, validate=validate, timestamp=timestamp, meta=meta)
         if isSave and rank == 0:
             for f in os.listdir(cfg.save_dir):
                 if '_mycode' not in f:
