@@ -36,6 +36,12 @@ class Uncertainty_fns:
         raise NotImplementedError('uncertainty_pool=Entropy_NoNMS is not runnable in the reference either (L_scores is None there)')
 
 
+# captured scoring graphs, per model (weak keys; a GraphedScore holds its model weakly too, so a dead model frees its graph memory pool by
+# reference counting -- and nothing unpicklable hangs in the module's __dict__: copy.deepcopy(model) keeps working after a pool was scored)
+import weakref as _weakref
+_GSCORE = _weakref.WeakKeyDictionary()
+
+
 def calculate_uncertainty(cfg, *args, **kwargs):
     """test.py:65-70."""
     return getattr(Uncertainty_fns, cfg.uncertainty_pool)(cfg, *args, **kwargs)
@@ -68,7 +74,7 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
         # several pools with one model (bench, tests) must not pay the capture again
         # (the key holds hashable primitives only; any other option value -> no caching, no graph: str() of a tensor / object could collide)
         if all(isinstance(v, (bool, int, float, str, type(None))) for v in kwargs.values()):
-            cache = model.__dict__.setdefault('_aod_gscore_cache', {})
+            cache = _GSCORE.setdefault(model, {})
             key = tuple(sorted((k, type(v).__name__, v) for k, v in kwargs.items()))
             gscore = cache.get(key)
             if gscore is None:
