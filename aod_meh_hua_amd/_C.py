@@ -59,6 +59,8 @@ _SIGS = {
     'aod_maxpool3x3s2': (C.c_int, [P, P, I32, I32, I32, I32, P]),
     'aod_upsample2x_add': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
     'aod_upsample2x_add_bwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_upsample2x_add_to': (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_upsample2x_add_bwd_set': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
     'aod_act_bwd': (C.c_int, [P, P, P, P, P, P, P, P, P, P, I64, I32, I32, I32, P]),
     'aod_add_relu': (C.c_int, [P, P, P, I64, P]),
     'aod_pad_cast_colsum': (C.c_int, [P, P, P, P, I64, I32, I32, I32, P]),

@@ -102,7 +102,8 @@ extern "C" int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W,
 
 // ---------------------------------------------------------------- FPN nearest-upsample add (F.interpolate(size=..., 'nearest'))
 // src index = floor(dst * h / H) (torch nearest); exact 2x when H == 2h.
-__global__ void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int h, int w, int C8, int H, int W) {
+// (`lat` = the lateral the upsampled top is added to; it may alias `dst` -- element i is read before it is written by the same thread)
+__global__ void upsample_add_kernel(const bf16_t* __restrict__ src, const bf16_t* lat, bf16_t* dst, int B, int h, int w, int C8, int H, int W) {
   const long long n = (long long)B * H * W * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int c = i % C8; long long r = i / C8;
@@ -110,7 +111,7 @@ __global__ void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __re
     const int y = r % H; const int b = r / H;
     const int sy = min((int)(((long long)y * h) / H), h - 1), sx = min((int)(((long long)x * w) / W), w - 1);
     const bf16x8 s = *reinterpret_cast<const bf16x8*>(src + ((((long long)b * h + sy) * w + sx) * C8 + c) * 8);
-    bf16x8 d = *reinterpret_cast<bf16x8*>(dst + i * 8);
+    bf16x8 d = *reinterpret_cast<const bf16x8*>(lat + i * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) d[j] = (bf16_t)((float)d[j] + (float)s[j]);
     *reinterpret_cast<bf16x8*>(dst + i * 8) = d;
@@ -119,11 +120,21 @@ __global__ void upsample_add_kernel(const bf16_t* __restrict__ src, bf16_t* __re
 extern "C" int aod_upsample2x_add(const void* src, void* dst, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
   AOD_CHECK_ARG(src && dst && C % 8 == 0, "upsample_add: C must be a multiple of 8");
   hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((long long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, (bf16_t*)dst, B, h, w, C / 8, H, W);
+                     (const bf16_t*)src, (const bf16_t*)dst, (bf16_t*)dst, B, h, w, C / 8, H, W);
   AOD_LAUNCH_CHECK();
   return 0;
 }
-// adjoint: g_src[b,sy,sx,c] += sum over dst pixels mapping to (sy,sx) of g_dst
+// out-of-place form: out = lateral + upsample(top) -- the in-place form above needs a copy of the lateral first (autograd must keep the
+// lateral conv's output): one pass less over the level
+extern "C" int aod_upsample2x_add_to(const void* top, const void* lateral, void* out, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(top && lateral && out && C % 8 == 0, "upsample_add_to: C must be a multiple of 8");
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((long long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)top, (const bf16_t*)lateral, (bf16_t*)out, B, h, w, C / 8, H, W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+// adjoint: g_src[b,sy,sx,c] (+)= sum over dst pixels mapping to (sy,sx) of g_dst   (ACC: add to what g_src holds; else overwrite it)
+template <bool ACC>
 __global__ void upsample_add_bwd_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gs, int B, int h, int w, int C8, int H, int W) {
   const long long n = (long long)B * h * w * C8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -134,9 +145,10 @@ __global__ void upsample_add_bwd_kernel(const bf16_t* __restrict__ gd, bf16_t* _
     const int y0 = (int)(((long long)sy * H + h - 1) / h), y1 = min(H, (int)(((long long)(sy + 1) * H + h - 1) / h));
     const int x0 = (int)(((long long)sx * W + w - 1) / w), x1 = min(W, (int)(((long long)(sx + 1) * W + w - 1) / w));
     float a[8];
-    bf16x8 cur = *reinterpret_cast<bf16x8*>(gs + i * 8);
+    bf16x8 cur;
+    if (ACC) cur = *reinterpret_cast<bf16x8*>(gs + i * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (float)cur[j];
+    for (int j = 0; j < 8; ++j) a[j] = ACC ? (float)cur[j] : 0.f;
     for (int y = y0; y < y1; ++y)
       for (int x = x0; x < x1; ++x) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(gd + ((((long long)b * H + y) * W + x) * C8 + c) * 8);
@@ -150,7 +162,15 @@ __global__ void upsample_add_bwd_kernel(const bf16_t* __restrict__ gd, bf16_t* _
 }
 extern "C" int aod_upsample2x_add_bwd(const void* g_dst, void* g_src, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
   AOD_CHECK_ARG(g_dst && g_src && C % 8 == 0, "upsample_add_bwd: C must be a multiple of 8");
-  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for((long long)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(upsample_add_bwd_kernel<true>, dim3(grid_for((long long)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)g_dst, (bf16_t*)g_src, B, h, w, C / 8, H, W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+// ... writing g_src instead of accumulating into it (no zero fill of the destination needed)
+extern "C" int aod_upsample2x_add_bwd_set(const void* g_dst, void* g_src, int B, int h, int w, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(g_dst && g_src && C % 8 == 0, "upsample_add_bwd_set: C must be a multiple of 8");
+  hipLaunchKernelGGL(upsample_add_bwd_kernel<false>, dim3(grid_for((long long)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)g_dst, (bf16_t*)g_src, B, h, w, C / 8, H, W);
   AOD_LAUNCH_CHECK();
   return 0;

@@ -203,6 +203,43 @@ class ActSlot:
         self.res_ok, self.res_grad = False, None
 
 
+class GradAcc:
+    """Gradient junction of a tensor that feeds SEVERAL convs (a ResNet stage output: the next stage's conv1 and downsample conv, and the
+    neck's lateral conv).  Autograd would run the three dgrads into three tensors and add them with two elementwise passes (62 us for C3 at
+    16 x 64 x 64 x 512).  Instead every consumer's dgrad takes the running sum as its epilogue's residual operand (dX = conv_T(dZ, W) + partial)
+    and hands back None until the last registered consumer has run, which returns the total.  Consumers register in forward
+    (conv_bn_act(shared_input=True)), so the count is exactly the convs that were applied to the tensor; `check_junctions()` (called when the
+    next iteration starts) fails loudly if a registered consumer never ran its backward and a partial sum was left behind."""
+    __slots__ = ('n', 'arrived', 'partial', '__weakref__')
+
+    def __init__(self):
+        self.n, self.arrived, self.partial = 0, 0, None
+
+
+_JUNCTIONS = []
+
+
+def share_input_grad(x):
+    """mark `x` (a tensor that requires grad, about to feed several convs) as a gradient junction"""
+    if torch.is_grad_enabled() and x.requires_grad and _PREC == 'bf16' and _os.environ.get('AOD_GRAD_JUNCTIONS', '1') != '0':
+        x._aod_acc = GradAcc()
+        _JUNCTIONS.append(_weakref.ref(x._aod_acc))
+    return x
+
+
+def check_junctions():
+    """every junction of the previous backward pass delivered its sum (or never started one)"""
+    global _JUNCTIONS
+    for r in _JUNCTIONS:
+        a = r()
+        if a is not None and a.partial is not None:
+            a.partial = None
+            _JUNCTIONS = []
+            raise RuntimeError('a shared-input gradient junction was left with a partial sum: one of the convs registered on a tensor never '
+                               'ran its backward (its output did not reach the loss); gradients behind that tensor were lost')
+    _JUNCTIONS = []
+
+
 def _grad_rows(gouts, y_segs, O, device):
     """the upstream gradient of a (level-batched) conv as one dense row tensor [M, O]"""
     if len(gouts) == 1 and gouts[0] is not None:
@@ -328,16 +365,27 @@ class ConvFn(Function):
             res_g = in_slot.res_grad if in_slot is not None else None
             if res_g is not None and not fuse:
                 raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')
+            acc = meta.get('in_acc')
+            if acc is not None:                 # gradient junction: the running sum of the other consumers' dX rides on this dgrad's epilogue
+                assert not fuse and len(xd) == 1
+                res_g = acc.partial
             dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
                                       res=res_g, mask=x_rows if fuse else None, colsum=s1_in, alg=(I, O))
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
                    for i, s in enumerate(xd)]
+            if acc is not None:
+                acc.arrived += 1
+                if acc.arrived < acc.n:
+                    acc.partial, gxs = dx, [None]           # not the last consumer: autograd gets nothing yet
+                else:
+                    acc.partial, acc.arrived = None, 0
         return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
 
 
-def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False):
+def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False,
+                shared_input=False):
     """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps.
     sole_consumer: the caller guarantees that every x is the ReLU output of a conv_bn_act call and feeds NOTHING but this conv, which
     lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot).  sole_consumer='res': x additionally feeds
@@ -358,6 +406,11 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
                 if sole_consumer != 'res' or len(xl) == 1:
                     meta['in_slot'] = slots[0]
                     slots[0].res_ok = sole_consumer == 'res'
+        if shared_input and len(xl) == 1:
+            acc = getattr(xl[0], '_aod_acc', None)
+            if acc is not None and 'in_slot' not in meta:
+                meta['in_acc'] = acc
+                acc.n += 1
         rs = getattr(res, '_aod_slot', None) if res is not None else None
         if rs is not None and rs.res_ok:
             meta['res_slot'] = rs
@@ -601,8 +654,7 @@ class UpsampleAddFn(Function):
     def forward(ctx, lateral, top):
         B, C, H, W = lateral.shape
         h, w = top.shape[2:]
-        out = as_rows(lateral).clone()
-        ho.upsample_add_(out, Seg(B, H, W), as_rows(top), Seg(B, h, w))
+        out = ho.upsample_add(as_rows(lateral), Seg(B, H, W), as_rows(top), Seg(B, h, w))
         ctx.dims = (B, C, H, W, h, w)
         return as_nchw(out, B, H, W)
 
@@ -612,9 +664,7 @@ class UpsampleAddFn(Function):
         g_rows = as_rows(g)
         gt = None
         if ctx.needs_input_grad[1]:
-            gt_rows = torch.zeros(B * h * w, C, device=g.device, dtype=torch.bfloat16)
-            ho.upsample_add_bwd_(gt_rows, Seg(B, h, w), g_rows, Seg(B, H, W))
-            gt = as_nchw(gt_rows, B, h, w)
+            gt = as_nchw(ho.upsample_add_bwd(g_rows, Seg(B, H, W), Seg(B, h, w)), B, h, w)
         return (g if ctx.needs_input_grad[0] else None), gt
 
 
@@ -648,14 +698,35 @@ class PackedLosses(list):
         self.packed = packed
 
 
+class GradArena:
+    """The per-level gradients of one prediction conv's output (retina_cls / retina_reg / retina_L: one loss launch per level,
+    Lambda_L2.py:112-121,235-241) land in adjacent row ranges of ONE buffer per conv: the conv's level-batched backward then reads them in
+    place (`_grad_rows` sees adjacent slices) instead of concatenating five tensors first (63 MB of fp32 class-logit gradients per step)."""
+
+    def __init__(self, rows_per_level):
+        self.row0, r = [], 0
+        for n in rows_per_level:
+            self.row0.append(r)
+            r += int(n)
+        self.rows, self.bufs = r, {}
+
+    def slice(self, name, level, rows, width, device):
+        buf = self.bufs.get(name)
+        if buf is None:
+            buf = self.bufs[name] = torch.empty(self.rows, width, dtype=torch.float32, device=device)
+        assert buf.shape[1] == width and rows == (self.row0[level + 1] if level + 1 < len(self.row0) else self.rows) - self.row0[level]
+        return buf[self.row0[level]:self.row0[level] + rows]
+
+
 class RetinaLossFn(Function):
     """Per level: (loss_cls_sum, loss_bbox_sum, loss_noR[N]) = fused EDL softmax-focal + L1
     (Lambda_L2.py:112-121).  Sums are NOT yet divided by avg_factor (done by the caller with a
     device scalar so that no host sync is needed)."""
 
     @staticmethod
-    def forward(ctx, cls_score, bbox_pred, labels, label_w, bbox_t, bbox_w, gamma, alpha, num_classes):
+    def forward(ctx, cls_score, bbox_pred, labels, label_w, bbox_t, bbox_w, gamma, alpha, num_classes, arena=None, level=0):
         B, AC, H, W = cls_score.shape
+        ctx.arena, ctx.level = arena, level
         A = AC // num_classes
         cls_rows = as_rows(cls_score).view(-1, num_classes)
         box_rows = as_rows(bbox_pred).view(-1, 4)
@@ -682,18 +753,23 @@ class RetinaLossFn(Function):
                 g_noR_t, scalar = g_sum.reshape(1).float().contiguous(), True
             else:
                 g_noR_t = g_noR_t + g_sum.float()
-        gc, gb = ho.edl_focal_l1_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, g_cls, g_box, g_noR_t, 0.0, gamma, alpha,
-                                     g_noR_is_scalar=scalar)
         B, AC, H, W = cshape
+        dst_c = dst_b = None
+        if ctx.arena is not None:              # this level's rows of the level-batched gradient buffers
+            dst_c = ctx.arena.slice('cls', ctx.level, B * H * W, AC, dev).view(-1, cls_rows.shape[1])
+            dst_b = ctx.arena.slice('box', ctx.level, B * H * W, bshape[1], dev).view(-1, 4)
+        gc, gb = ho.edl_focal_l1_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, g_cls, g_box, g_noR_t, 0.0, gamma, alpha,
+                                     g_noR_is_scalar=scalar, grad_cls=dst_c, grad_bbox=dst_b)
         return (as_nchw(gc.view(B * H * W, AC), B, H, W), as_nchw(gb.view(B * H * W, bshape[1]), B, H, W),
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 class MEHLossFn(Function):
     """sum(((|lambda + 1e-9 - loss_noR|) * w)^2) for one level (Lambda_L2.py:235-241)."""
 
     @staticmethod
-    def forward(ctx, L_score, loss_noR, bbox_w):
+    def forward(ctx, L_score, loss_noR, bbox_w, arena=None, level=0):
+        ctx.arena, ctx.level = arena, level
         lam = as_rows(L_score).view(-1)
         bw = bbox_w.reshape(-1, 4).contiguous()
         loss_noR = loss_noR.contiguous()
@@ -706,5 +782,6 @@ class MEHLossFn(Function):
     def backward(ctx, g):
         lam, loss_noR, bw = ctx.saved_tensors
         B, A, H, W = ctx.shape
-        gl = ho.meh_loss_bwd(lam, loss_noR, bw, g.reshape(1).float().contiguous())
-        return as_nchw(gl.view(B * H * W, A), B, H, W), None, None
+        dst = ctx.arena.slice('lam', ctx.level, B * H * W, A, lam.device).view(-1, 1) if ctx.arena is not None else None
+        gl = ho.meh_loss_bwd(lam, loss_noR, bw, g.reshape(1).float().contiguous(), grad=dst)
+        return as_nchw(gl.view(B * H * W, A), B, H, W), None, None, None, None

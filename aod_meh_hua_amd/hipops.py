@@ -359,6 +359,20 @@ def upsample_add_(dst_rows, dst_seg: Seg, src_rows, src_seg: Seg):
     return dst_rows
 
 
+def upsample_add(lat_rows, dst_seg: Seg, top_rows, src_seg: Seg):
+    """out = lateral + nearest_upsample(top), out of place (aod_upsample2x_add_to)"""
+    out = torch.empty_like(lat_rows)
+    call('aod_upsample2x_add_to', ptr(top_rows), ptr(lat_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, lat_rows.shape[1], dst_seg.H, dst_seg.W, stream())
+    return out
+
+
+def upsample_add_bwd(g_dst_rows, dst_seg: Seg, src_seg: Seg):
+    """g_top = adjoint of the nearest upsample applied to g (written, not accumulated: no zero fill)"""
+    out = torch.empty(src_seg.rows, g_dst_rows.shape[1], dtype=torch.bfloat16, device=g_dst_rows.device)
+    call('aod_upsample2x_add_bwd_set', ptr(g_dst_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, g_dst_rows.shape[1], dst_seg.H, dst_seg.W, stream())
+    return out
+
+
 def upsample_add_bwd_(g_src_rows, src_seg: Seg, g_dst_rows, dst_seg: Seg):
     call('aod_upsample2x_add_bwd', ptr(g_dst_rows), ptr(g_src_rows), dst_seg.B, src_seg.H, src_seg.W,
          g_dst_rows.shape[1], dst_seg.H, dst_seg.W, stream())

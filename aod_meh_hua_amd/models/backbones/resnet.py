@@ -45,9 +45,12 @@ class Bottleneck(BaseModule):
         if AF.bottleneck64_applies(self, x):       # frozen / inference 64-channel block: one launch, intermediates stay in LDS
             identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])
             return AF.bottleneck64_fwd(x, self, identity)
-        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if self.downsample is None else False)
+        # (a block WITH a downsample branch reads a stage input: conv1 and the downsample conv share it -- and with the neck's lateral conv --
+        # through the gradient junction ResNet.forward put on it)
+        ds = self.downsample is not None
+        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if not ds else False, shared_input=ds)
         out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True)      # conv1's / conv2's outputs feed only the next conv:
-        identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])
+        identity = x if not ds else self.downsample[0](x, bn=self.downsample[1], shared_input=True)
         return self.conv3(out, bn=self.norm3, res=identity, relu=True, sole_consumer=True)   # their ReLU backward rides on its dgrad
 
 
@@ -142,9 +145,11 @@ class ResNet(BaseModule):
             x = self.conv1(x, bn=self.norm1, relu=True)
             x = AF.max_pool_3x3_s2(x)
         outs = []
+        AF.check_junctions()
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
                 x = blk(x)
+            AF.share_input_grad(x)            # a stage output feeds the next stage's conv1 + downsample conv and the neck (functional.GradAcc)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

@@ -151,6 +151,9 @@ class L_AnchorHead(BaseModule):
         head_info = ['cls_scores', 'bbox_preds', 'all_anchor_list', 'labels_list', 'label_weights_list', 'bbox_targets_list',
                      'bbox_weights_list', 'num_total_samples']
         head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
+        if self._can_defer_avg:             # (heads on the HIP loss kernels) one gradient buffer per prediction conv, a row range per level
+            from ... import functional as AF
+            kwargs = dict(kwargs, grad_arena=AF.GradArena([c.shape[0] * c.shape[2] * c.shape[3] for c in cls_scores]))
         outs = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list,
                            list(range(len(cls_scores))), num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
                            defer_avg=self._can_defer_avg, **kwargs)
@@ -186,7 +189,9 @@ class L_AnchorHead(BaseModule):
         """L_anchor_head.py:322-327."""
         if self._can_defer_avg:
             from ... import functional as AF
-            sums, scales = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], defer_scale=True, **kwargs)
+            arena = AF.GradArena([l.shape[0] * l.shape[2] * l.shape[3] for l in L_scores])
+            sums, scales = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], list(range(len(L_scores))),
+                                       defer_scale=True, grad_arena=arena, **kwargs)
             Q = torch.stack(list(sums)) * self._level_counts([float(v) for v in scales], sums[0].device)     # 5 * mean(.) per level
             return dict(loss_L=AF.PackedLosses(Q.unbind(0), Q))
         losses_L, _ = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], **kwargs)

@@ -97,7 +97,8 @@ class Lambda_L2Net(L_AnchorHead):
             raise NotImplementedError('pseudo-label branch (Lambda_L2.py:122-232) is dead code in the reference driver')
         assert type(self.loss_bbox).__name__ == 'L1Loss' and type(self.loss_cls).__name__ == 'EDL_Softmax_FocalLoss'
         sum_cls, sum_box, loss_noR, sum_noR = AF.RetinaLossFn.apply(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
-                                                                    float(self.loss_cls.gamma), float(self.loss_cls.alpha), self.cls_out_channels)
+                                                                    float(self.loss_cls.gamma), float(self.loss_cls.alpha), self.cls_out_channels,
+                                                                    kwargs.get('grad_arena'), int(sIdx))
         wc, wb = self.loss_cls.loss_weight, self.loss_bbox.loss_weight
         scaled = lambda w, t: t if w == 1.0 else w * t          # (1.0 * t == t exactly: no launch for the default weights)
         if kwargs.get('defer_avg'):                               # loss() divides all levels by their counts in one launch
@@ -107,9 +108,9 @@ class Lambda_L2Net(L_AnchorHead):
         return loss_cls, loss_bbox, scaled(wc, loss_noR)
 
     @force_fp32(apply_to=('L_score'))
-    def loss_single_L(self, L_score, loss, label_weights, bbox_weights, **kwargs):
+    def loss_single_L(self, L_score, loss, label_weights, bbox_weights, sIdx=0, **kwargs):
         """Lambda_L2.py:235-241: mean(((|lambda + 1e-9 - loss|) * bbox_weights[...,0])^2) * 5."""
-        s = AF.MEHLossFn.apply(L_score, loss, bbox_weights)
+        s = AF.MEHLossFn.apply(L_score, loss, bbox_weights, kwargs.get('grad_arena'), int(sIdx))
         if kwargs.get('defer_scale'):                             # loss_L() scales all levels in one launch
             return s, 5.0 / loss.numel()
         return s * (5.0 / loss.numel()), 0

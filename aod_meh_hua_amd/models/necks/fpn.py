@@ -46,7 +46,8 @@ class FPN(BaseModule):
     def forward(self, inputs):
         """fpn.py:151-202."""
         assert len(inputs) == len(self.in_channels)
-        laterals = [lc(inputs[i + self.start_level]) for i, lc in enumerate(self.lateral_convs)]
+        # (shared_input: a backbone stage output also feeds the next stage -- and C5 the first extra conv --: functional.GradAcc)
+        laterals = [lc(inputs[i + self.start_level], shared_input=True) for i, lc in enumerate(self.lateral_convs)]
         n = len(laterals)
         for i in range(n - 1, 0, -1):
             laterals[i - 1] = AF.upsample_add(laterals[i - 1], laterals[i])
@@ -69,7 +70,7 @@ class FPN(BaseModule):
                 src = laterals[-1]
             else:
                 src = outs[-1]
-            outs.append(self.fpn_convs[n](src, out=slots[n]))
+            outs.append(self.fpn_convs[n](src, out=slots[n], shared_input=self.add_extra_convs == 'on_input'))
             for i in range(n + 1, self.num_outs):
                 outs.append(self.fpn_convs[i](outs[-1], out=slots[i]))
         return tuple(outs)

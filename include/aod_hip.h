@@ -174,6 +174,10 @@ int aod_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod
 /* FPN top-down: dst[b,y,x,c] += src[b,y/2,x/2,c] (nearest 2x, fpn.py:163-172) and its adjoint */
 int aod_upsample2x_add(const void* src, void* dst, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
 int aod_upsample2x_add_bwd(const void* g_dst, void* g_src_accum, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+/* out = lateral + nearest_upsample(top) without touching the lateral (fpn.py:163-172: `laterals[i-1] += F.interpolate(laterals[i])`
+ * whose in-place add autograd turns into a copy), and the adjoint that WRITES g_top (no zero fill of the destination). */
+int aod_upsample2x_add_to(const void* top, const void* lateral, void* out, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+int aod_upsample2x_add_bwd_set(const void* g_dst, void* g_src, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
 /* Backward of y = act(z*scale+shift [+res]) in eval-mode BN (resnet.py:262-301):
  * gm = g * (a > 0 if relu);  dz = gm * scale[n];  dbeta[n] += sum_m gm;  dgamma[n] += sum_m gm * (z - mean[n]) * invstd[n].
  * gmask_out (optional) receives gm (gradient for the residual branch); z/mean/invstd NULL -> bias-only mode

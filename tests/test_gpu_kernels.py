@@ -290,12 +290,16 @@ def test_elementwise_ops(ho):
         d = nhwc_rows(dst).cuda().bfloat16()
         ho.upsample_add_(d, ho.Seg(B, Hh, Ww), nhwc_rows(src).cuda().bfloat16(), ho.Seg(B, h, w))
         assert torch.equal(rows_nchw(d, B, Hh, Ww).float().cpu(), ref)
+        lat = nhwc_rows(dst).cuda().bfloat16()
+        o2 = ho.upsample_add(lat, ho.Seg(B, Hh, Ww), nhwc_rows(src).cuda().bfloat16(), ho.Seg(B, h, w))       # out of place: the lateral is untouched
+        assert torch.equal(o2, d) and torch.equal(lat.float().cpu(), nhwc_rows(dst))
         gd = bf(torch.randn(B, C, Hh, Ww, generator=g))
         s_ = src.clone().requires_grad_(True)
         F.interpolate(s_, size=(Hh, Ww), mode='nearest').backward(gd)
         gs = torch.zeros(B * h * w, C, device='cuda', dtype=torch.bfloat16)
         ho.upsample_add_bwd_(gs, ho.Seg(B, h, w), nhwc_rows(gd).cuda().bfloat16(), ho.Seg(B, Hh, Ww))
         assert close(rows_nchw(gs, B, h, w), s_.grad, 1e-2, 2e-2)
+        assert torch.equal(ho.upsample_add_bwd(nhwc_rows(gd).cuda().bfloat16(), ho.Seg(B, Hh, Ww), ho.Seg(B, h, w)), gs)      # written, not accumulated
     a, b = bf(torch.randn(1000, 64, generator=g)), bf(torch.randn(1000, 64, generator=g))
     assert torch.equal(ho.add_relu(a.cuda().bfloat16(), b.cuda().bfloat16()).float().cpu(), bf(F.relu(a + b)))
 

@@ -32,19 +32,18 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.device_time_total <= 0 or not ev.key.startswith('aten::'):
+rows = []
+for ka in prof.key_averages(group_by_input_shape=True, group_by_stack_n=24):
+    if not ka.key.startswith('aten::') or ka.device_time_total <= 0:
         continue
-    if any(c.key.startswith('aten::') and c.device_time_total > 0 for c in ev.cpu_children):
-        continue                                    # count leaf aten ops only
-    st = [s for s in (ev.stack or []) if 'aod_meh_hua_amd' in s or 'bench.py' in s or 'glue_all' in s]
-    site = st[0].strip()[-110:] if st else ((ev.stack or ['?'])[0].strip()[-110:])
-    a = agg[(ev.key, site)]
-    a[0] += 1; a[1] += ev.device_time_total
-tot = sum(v[1] for v in agg.values())
-print(f'aten device time per step: {tot:.0f} us in {sum(v[0] for v in agg.values())} ops')
-for (k, site), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
-    print(f'{n:3d} {us:8.1f} us  {k:26s} {site}')
+    if ka.key in ('aten::to', 'aten::_to_copy', 'aten::contiguous', 'aten::clone', 'aten::reshape', 'aten::item', 'aten::zeros', 'aten::zeros_like',
+                  'aten::stack', 'aten::zero_', 'aten::sub', 'aten::rsub'):
+        continue                                    # wrappers: their leaf op (copy_, fill_, cat, ...) is listed
+    st = [x for x in ka.stack if 'aod_meh_hua_amd' in x or 'bench.py' in x or 'glue_all' in x]
+    site = ' <- '.join(x.strip().split('/')[-1][:60] for x in st[:3]) if st else (ka.stack[0].strip()[-100:] if ka.stack else '?')
+    rows.append((ka.count, ka.key, ka.device_time_total, str(ka.input_shapes)[:60], site))
+print(f'aten device time per step: {sum(r[2] for r in rows):.0f} us')
+for n, name, us, shp, site in sorted(rows, key=lambda r: -r[2])[:120]:
+    print(f'{n:3d} {us:8.1f} us  {name:16s} {shp:60s} {site}')
