@@ -42,6 +42,8 @@ _SIGS = {
     'aod_conv2d_ws_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv2d_ws': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, P, SZ, P]),
     'aod_conv2d_grouped': (C.c_int, [C.POINTER(ConvDesc), I32, P, P, P, P, P, P, P]),
+    'aod_halo_conv3x3_applies': (C.c_int, [C.POINTER(ConvDesc)]),
+    'aod_halo_conv3x3': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     'aod_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     'aod_conv2d_wgrad_splits': (C.c_int, [C.POINTER(ConvDesc)]),
     'aod_conv2d_wgrad_slabs': (C.c_int, [C.POINTER(ConvDesc), P, P, P, I32, I64, P, P]),

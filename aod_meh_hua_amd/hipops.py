@@ -134,6 +134,15 @@ def _splitk_ws(d, device):
     return torch.empty(n // 4, dtype=torch.float32, device=device), n
 
 
+HALO_CONV = os.environ.get('AOD_HALO_CONV', '1') != '0'   # debug switch: 0 = the narrow 3x3 convs (prediction heads) go through the general kernel
+
+
+def _halo_applies(d, narrow, *unsupported):
+    """the halo-tile kernel (aod_halo_conv3x3) takes 3x3 / stride-1 / pad-1 convs whose narrow side has < 256 channels and that need none
+    of the epilogue operands it does not implement"""
+    return HALO_CONV and narrow < 256 and all(u is None for u in unsupported) and bool(lib.aod_halo_conv3x3_applies(C.byref(d)))
+
+
 def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, pre_scale=None, pre_shift=None,
                 res=None, mask=None, post_scale=None, relu=False, out_f32=False, save_z=False, out=None,
                 dst_segs=None, out_rows=None, alg=None):
@@ -145,6 +154,9 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
         out = torch.empty(rows, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
     z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
+    if R == 3 and not save_z and _halo_applies(d, N, pre_scale, res, mask, post_scale):
+        _prof('fwd', d, lambda: call('aod_halo_conv3x3', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_shift), None, None, stream()), alg)
+        return out, dst_segs
     ws, wsb = _splitk_ws(d, x_rows.device)
     _prof('fwd', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
                                  ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, ptr(ws), wsb, stream()), alg)
@@ -204,6 +216,9 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     if out is None:
         out = torch.empty(rows, Cin, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, out_f32)
+    if R == 3 and _halo_applies(d, Npad, res, post_scale):
+        _prof('dgrad', d, lambda: call('aod_halo_conv3x3', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, ptr(mask), ptr(colsum), stream()), alg)
+        return out
     ws, wsb = _splitk_ws(d, dz_rows.device)
     _prof('dgrad', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, None, ptr(res), ptr(mask),
                                    ptr(post_scale), None, ptr(colsum), ptr(ws), wsb, stream()), alg)

@@ -192,6 +192,15 @@ int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, void* dz, floa
 /* out = relu(a + b) bf16 and backward mask (bottleneck join, resnet.py:292-299) */
 int aod_add_relu(const void* a, const void* b, void* out, int64_t n, aod_stream_t stream);
 
+/* 3x3 / stride-1 / pad-1 conv with the input halo tile resident in LDS (csrc/halo_conv.hip) for the layers whose output is narrow next to
+ * their input: the prediction convs retina_cls / retina_reg / retina_L over all pyramid levels (mmdet/models/dense_heads/Lambda_L2.py:52-54,
+ * 92-103) and their dgrads (desc->transposed = 1 with the aod_pack_weight_dgrad packing: taps mirrored).  Same descriptor as aod_conv2d;
+ * v = acc + pre_shift[n]; if (mask) v = mask[m][n] > 0 ? v : 0; if (relu) v = max(v, 0); colsum[n] += sum_m v.  desc->C <= 256, N <= 256.
+ * aod_halo_conv3x3_applies() tells whether a descriptor qualifies. */
+int aod_halo_conv3x3_applies(const aod_conv_desc_t* desc);
+int aod_halo_conv3x3(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst, const float* pre_shift,
+                     const void* mask, float* colsum, aod_stream_t stream);
+
 /* ------------------------------------------------------------------ losses (K6-K8)
  * replaces: mmcv.ops.sigmoid_focal_loss fwd/bwd CUDA kernels + softmax/log chain at
  *   mmdet/models/losses/EDL_Softmax_FocalLoss.py:9-27,51-69, L1 at smooth_l1_loss.py:33-45,

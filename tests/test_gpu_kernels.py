@@ -130,6 +130,81 @@ def test_conv_pyramid_segments_share_weights(ho):
         assert close(ho.rows_to_nchw(y, s), ref, 1e-2, 1e-2)
 
 
+@pytest.mark.parametrize('N,out_f32,relu', [(180, True, False), (36, True, False), (9, True, True), (72, False, True), (200, False, False)])
+def test_halo_tile_conv_over_pyramid_levels(ho, N, out_f32, relu):
+    """csrc/halo_conv.hip (prediction convs, Lambda_L2.py:52-54,92-103): five ragged pyramid levels in one launch -- tiles that straddle the
+    image border, levels smaller than one 8 x 16 tile, N with a 4- / 1-channel tail -- against fp32 torch on the bf16-rounded operands, and
+    against the general implicit-GEMM kernel (AOD_HALO_CONV=0 path)."""
+    B, C = 3, 256
+    sizes = [(19, 21), (10, 11), (8, 16), (5, 3), (1, 2)]
+    g = synth.gen(300 + N)
+    xs = [bf(torch.randn(B, C, h, w, generator=g)) for h, w in sizes]
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9))
+    bias = torch.randn(N, generator=g)
+    segs, r = [], 0
+    for h, w_ in sizes:
+        segs.append(ho.Seg(B, h, w_, r))
+        r += B * h * w_
+    rows = torch.cat([nhwc_rows(x) for x in xs]).cuda().bfloat16()
+    wp = ho.pack_weight_fwd(w.cuda())
+    assert ho.HALO_CONV
+    y, osegs = ho.conv2d_rows(rows, segs, wp, N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=relu, out_f32=out_f32)
+    ho.HALO_CONV = False
+    try:
+        y0, _ = ho.conv2d_rows(rows, segs, wp, N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=relu, out_f32=out_f32)
+    finally:
+        ho.HALO_CONV = True
+    torch.cuda.synchronize()
+    tol = 2e-4 if out_f32 else 1e-2
+    for x, s_ in zip(xs, osegs):
+        ref = F.conv2d(x, w, bias, 1, 1)
+        ref = F.relu(ref) if relu else ref
+        assert close(ho.rows_to_nchw(y, s_), ref, tol, tol)
+    assert close(y, y0, tol, tol)                 # (different K order: chunk-major here, tap-major there)
+
+
+@pytest.mark.parametrize('N', [180, 36, 9])
+def test_halo_tile_dgrad_with_fused_relu_mask_and_bias_sums(ho, N):
+    """dgrad of a prediction conv through the halo-tile kernel (mirrored taps on the dgrad packing) with the producer's ReLU mask and the
+    column sums of the masked gradient fused (functional.ActSlot): vs fp32 autograd and vs the general kernel."""
+    B, C = 2, 256
+    sizes = [(13, 18), (7, 9), (4, 4)]
+    g = synth.gen(330 + N)
+    Npad = (N + 7) // 8 * 8
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / np.sqrt(C * 9))
+    wd = ho.pack_weight_dgrad(w.cuda(), Npad)
+    segs, r = [], 0
+    for h, w_ in sizes:
+        segs.append(ho.Seg(B, h, w_, r))
+        r += B * h * w_
+    dzs = [bf(torch.randn(B, N, h, w_, generator=g)) for h, w_ in sizes]
+    acts = [bf(torch.randn(B, C, h, w_, generator=g)) for h, w_ in sizes]         # the producer's ReLU output (mask = act > 0)
+    dz_rows = torch.zeros(r, Npad)
+    dz_rows[:, :N] = torch.cat([nhwc_rows(d) for d in dzs])
+    dz_rows = dz_rows.cuda().bfloat16()
+    mask = torch.cat([nhwc_rows(a) for a in acts]).cuda().bfloat16()
+    outs = []
+    for halo in (True, False):
+        ho.HALO_CONV = halo
+        try:
+            cs = torch.zeros(C, device='cuda')
+            dx = ho.conv2d_dgrad_rows(dz_rows, segs, segs, wd, C, 3, 3, 1, 1, 1, mask=mask, colsum=cs)
+            outs.append((dx, cs))
+        finally:
+            ho.HALO_CONV = True
+    torch.cuda.synchronize()
+    ref_cs = torch.zeros(C)
+    for dz, a, s_ in zip(dzs, acts, segs):
+        x = torch.zeros(B, C, s_.H, s_.W, requires_grad=True)
+        F.conv2d(x, w, None, 1, 1).backward(dz)
+        ref = x.grad * (a > 0)
+        ref_cs += ref.sum((0, 2, 3))
+        sc = float(ref.abs().max())
+        assert close(ho.rows_to_nchw(outs[0][0], s_), ref, 1e-2, 1e-2 * sc)
+    assert close(outs[0][1], ref_cs, 1e-2, 1e-2 * float(ref_cs.abs().max()))
+    assert close(outs[0][0], outs[1][0], 1e-2, 1e-2 * sc) and close(outs[0][1], outs[1][1], 1e-3, 1e-3 * float(ref_cs.abs().max()))
+
+
 @pytest.mark.parametrize('N,out_f32', [(256, False), (180, True), (9, True), (72, False)])
 def test_conv_split_k_matches_the_direct_kernel(ho, N, out_f32):
     """Small-output / deep-K convolutions run split-K (aod_conv2d_ws: fp32 partial sums in a workspace + a finalize pass).  Same
