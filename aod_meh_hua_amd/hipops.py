@@ -135,12 +135,22 @@ def _splitk_ws(d, device):
 
 
 HALO_CONV = os.environ.get('AOD_HALO_CONV', '1') != '0'   # debug switch: 0 = the narrow 3x3 convs (prediction heads) go through the general kernel
+# Which launches take the halo-tile kernel (csrc/halo_conv.hip).  Measured on MI355X at 16 x 512^2 (profiles/r03_halo_conv_ab.txt): it wins on
+# the INPUT-bound forward convs (retina_reg 67.6 -> 60 us, retina_L 62.9 -> 45 us: the 10 x 18 halo crosses HBM once instead of 7.8 times) and
+# only draws level on retina_cls (N = 180: 128-133 vs 128-143 us) and loses on the dgrads (N = 256 outputs: 145-187 vs 139 us, 79-94 vs
+# 60 us): at one workgroup per CU its 24-MFMA K-steps are too short for two waves per SIMD.  AOD_HALO_CONV=all routes every qualifying
+# launch (the kernel tests do), the default takes the forward launches with at most 64 output channels.
+HALO_ALL = os.environ.get('AOD_HALO_CONV', '1') == 'all'
 
 
-def _halo_applies(d, narrow, *unsupported):
+def _halo_applies(d, narrow, *unsupported, dgrad=False):
     """the halo-tile kernel (aod_halo_conv3x3) takes 3x3 / stride-1 / pad-1 convs whose narrow side has < 256 channels and that need none
     of the epilogue operands it does not implement"""
-    return HALO_CONV and narrow < 256 and all(u is None for u in unsupported) and bool(lib.aod_halo_conv3x3_applies(C.byref(d)))
+    if not HALO_CONV or narrow >= 256 or any(u is not None for u in unsupported):
+        return False
+    if not HALO_ALL and (dgrad or narrow > 64):
+        return False
+    return bool(lib.aod_halo_conv3x3_applies(C.byref(d)))
 
 
 def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, pre_scale=None, pre_shift=None,
@@ -216,7 +226,7 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     if out is None:
         out = torch.empty(rows, Cin, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, out_f32)
-    if R == 3 and _halo_applies(d, Npad, res, post_scale):
+    if R == 3 and _halo_applies(d, Npad, res, post_scale, dgrad=True):
         _prof('dgrad', d, lambda: call('aod_halo_conv3x3', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, ptr(mask), ptr(colsum), stream()), alg)
         return out
     ws, wsb = _splitk_ws(d, dz_rows.device)

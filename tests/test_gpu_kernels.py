@@ -148,12 +148,13 @@ def test_halo_tile_conv_over_pyramid_levels(ho, N, out_f32, relu):
     rows = torch.cat([nhwc_rows(x) for x in xs]).cuda().bfloat16()
     wp = ho.pack_weight_fwd(w.cuda())
     assert ho.HALO_CONV
-    y, osegs = ho.conv2d_rows(rows, segs, wp, N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=relu, out_f32=out_f32)
-    ho.HALO_CONV = False
+    keep_all, ho.HALO_ALL = ho.HALO_ALL, True            # every qualifying launch (the default routes N <= 64 forward launches only)
     try:
+        y, osegs = ho.conv2d_rows(rows, segs, wp, N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=relu, out_f32=out_f32)
+        ho.HALO_CONV = False
         y0, _ = ho.conv2d_rows(rows, segs, wp, N, 3, 3, 1, 1, 1, pre_shift=bias.cuda(), relu=relu, out_f32=out_f32)
     finally:
-        ho.HALO_CONV = True
+        ho.HALO_CONV, ho.HALO_ALL = True, keep_all
     torch.cuda.synchronize()
     tol = 2e-4 if out_f32 else 1e-2
     for x, s_ in zip(xs, osegs):
@@ -184,14 +185,15 @@ def test_halo_tile_dgrad_with_fused_relu_mask_and_bias_sums(ho, N):
     dz_rows = dz_rows.cuda().bfloat16()
     mask = torch.cat([nhwc_rows(a) for a in acts]).cuda().bfloat16()
     outs = []
+    keep_all = ho.HALO_ALL
     for halo in (True, False):
-        ho.HALO_CONV = halo
+        ho.HALO_CONV, ho.HALO_ALL = halo, True
         try:
             cs = torch.zeros(C, device='cuda')
             dx = ho.conv2d_dgrad_rows(dz_rows, segs, segs, wd, C, 3, 3, 1, 1, 1, mask=mask, colsum=cs)
             outs.append((dx, cs))
         finally:
-            ho.HALO_CONV = True
+            ho.HALO_CONV, ho.HALO_ALL = True, keep_all
     torch.cuda.synchronize()
     ref_cs = torch.zeros(C)
     for dz, a, s_ in zip(dzs, acts, segs):
