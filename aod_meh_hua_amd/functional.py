@@ -240,6 +240,53 @@ def check_junctions():
     _JUNCTIONS = []
 
 
+# --------------------------------------------------------------------------- gradient cuts (segmented backward, data parallelism)
+_CUTS = None
+
+
+class grad_cuts:
+    """`with grad_cuts() as cuts: out = model.train_step(...)`: the backbone marks its stage outputs with cut() and the autograd graph of the
+    iteration falls apart into SEGMENTS that backward_segments() runs one after the other -- head + neck first, then the backbone stages
+    from the deepest to the shallowest.  Between two segments the gradients of the finished one are complete, so their bucket all-reduce
+    (parallel.GradSync.start(..., segment=k)) is launched while the next segment still computes: SURVEY 8(e) 'all-reduce overlapped with
+    the main backward'.  Each segment is one Python call, hence one HIP-graph segment in graphs.GraphedTrainStep."""
+
+    def __enter__(self):
+        global _CUTS
+        self.prev, _CUTS = _CUTS, []
+        return _CUTS
+
+    def __exit__(self, *exc):
+        global _CUTS
+        _CUTS = self.prev
+        return False
+
+
+def cut(x):
+    """inside grad_cuts(): a detached copy of `x` (same memory) that requires grad; (x, copy) is recorded so that backward_segments() can
+    resume the backward pass at `x` with the gradient that arrived at the copy.  Outside: x itself."""
+    if _CUTS is None or not torch.is_grad_enabled() or not x.requires_grad or _PREC != 'bf16':
+        return x
+    xc = x.detach().requires_grad_()
+    _CUTS.append((x, xc))
+    return xc
+
+
+def backward_segments(loss, cuts, after=None):
+    """loss.backward() in len(cuts) + 1 pieces: segment 0 ends at the cut copies, segment k continues from the k-th deepest cut.  `after(k)`
+    is called when segment k's gradients are final (the caller starts their all-reduce there).  Same gradients as one backward() call: a
+    cut copy is a leaf whose .grad receives exactly what would have flowed on (the junction protocol, GradAcc, spans the cut)."""
+    loss.backward()
+    if after is not None:
+        after(0)
+    for k, (x, xc) in enumerate(reversed(cuts)):
+        g, xc.grad = xc.grad, None
+        if g is not None:
+            x.backward(g)
+        if after is not None:
+            after(k + 1)
+
+
 def _grad_rows(gouts, y_segs, O, device):
     """the upstream gradient of a (level-batched) conv as one dense row tensor [M, O]"""
     if len(gouts) == 1 and gouts[0] is not None:

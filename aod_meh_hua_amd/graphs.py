@@ -92,21 +92,34 @@ class GraphedTrainStep:
                     gts=torch.zeros(B, G, 4, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
                     labs=torch.zeros(B, G, dtype=torch.long, device=dev), metas=[dict(m) for m in d['img_metas']])
 
-    # ------------------------------------------------------------------ the four segments of run_iter
-    def _seg_a(self):
+    # ------------------------------------------------------------------ the segments of run_iter
+    def _seg_a(self, cuts=False):
         st = self.cur['static']
         data = dict(img=st['img'], img_metas=st['metas'], gt_bboxes=PackedGT((st['gts'], st['counts'], st['labs'])), gt_labels=None)
-        out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
+        if cuts:            # data parallelism: the backward pass falls into segments at the backbone's stage outputs (functional.grad_cuts)
+            with AF.grad_cuts() as cl:
+                out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
+            self.cur['cuts'] = list(reversed(cl))
+            assert len(cl) == self.nseg - 1, f'{len(cl)} gradient cuts for {self.nseg} bucket segments'
+        else:
+            out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
         self.opt.zero_grad()
-        out['loss'].backward()
+        out['loss'].backward()          # (with cuts: segment 0 -- heads and neck; it ends at the cut copies)
         self.cur['live'] = (out, head_out, feat_out, prev)
         # every 0-dim value the caller gets back, packed into ONE static vector inside the graph: a step then hands out copies with one
         # device copy per segment instead of one per log entry (~60 launches of 4 us each, serialised behind the replay)
         self.cur['pack'] = torch.stack([out['loss'].detach().float().reshape(())] + [v.detach().float().reshape(()) for v in out['log_vars'].values()])
 
+    def _seg_ak(self, k):
+        """backward segment k >= 1: the backbone stage behind the k-th deepest cut"""
+        x, xc = self.cur['cuts'][k - 1]
+        g, xc.grad = xc.grad, None
+        if g is not None:
+            x.backward(g)
+
     def _seg_b(self):
         # the MEH step only reads detached features / losses and its own parameters, so the main update (segment C) may follow it:
-        # with data parallelism the main gradients' all-reduce then runs under this whole segment
+        # with data parallelism the main gradients' last all-reduce buckets then run under this whole segment
         out, head_out, feat_out, prev = self.cur['live']
         loss_L = self.module.train_step_L(prev, head_out, feat_out, **self.kw)
         self.opt_L.zero_grad()
@@ -123,40 +136,59 @@ class GraphedTrainStep:
     def _params(self, opt):
         return [p for g in opt.param_groups for p in g['params']]
 
-    def _between(self, i, capturing=False):
-        """Communication between segment i and i+1 (data parallelism only).  While CAPTURING nothing is sent: only the hand-over the
-        later segments' captured pointers depend on happens (.grad -> the slices of the flat buffer the reduced values arrive in)."""
+    def _segments(self, dist_mode):
+        """(tag, callable) in execution order.  One process: everything is ONE graph.  Data parallelism: a0 (forward + heads / neck
+        backward), a1 .. aK (backbone stages, deepest first), b (MEH forward / backward), c, d (the two SGD steps) are graphs of their
+        own with the eager bucket all-reduces between them."""
+        if not dist_mode:
+            return [('a', self._seg_a), ('b', self._seg_b), ('c', self._seg_c), ('d', self._seg_d)]
+        segs = [('a0', lambda: self._seg_a(cuts=True))]
+        segs += [(f'a{k}', (lambda k=k: self._seg_ak(k))) for k in range(1, self.nseg)]
+        return segs + [('b', self._seg_b), ('c', self._seg_c), ('d', self._seg_d)]
+
+    def _between(self, tag, capturing=False):
+        """Communication behind segment `tag` (data parallelism only).  While CAPTURING nothing is sent: only the hand-over the later
+        segments' captured pointers depend on happens (.grad -> the slices of the flat buffer the reduced values arrive in)."""
         if self.sync is None:
             return
         cur = self.cur
-        if capturing:
-            if i == 0:
-                cur['src'] = [p.grad for p in self._params(self.opt)]           # what segment A's captured kernels write
-            elif i == 1:
-                cur['src_L'] = [p.grad for p in self._params(self.opt_L)]
+        main, meh = self._params(self.opt), self._params(self.opt_L)
+        if tag.startswith('a'):
+            k = int(tag[1:] or 0)
+            ent = self.sync.attach(main)
+            idx = [i for i in range(len(main)) if ent['seg_of'] is None or ent['seg_of'][i] == k]
+            if capturing:
+                src = cur.setdefault('src', [None] * len(main))
+                for i in idx:
+                    src[i] = main[i].grad                                     # what this segment's captured kernels write
+            else:
+                self.inflight.append(self.sync.start(main, sources=cur.get('src'), segment=k if ent['seg_of'] is not None else None))
+        elif tag == 'b':
+            if capturing:
+                cur['src_L'] = [p.grad for p in meh]
                 for opt in (self.opt, self.opt_L):                              # segments C / D read the reduced slices
                     ent = self.sync.attach(self._params(opt))
                     for p, v in zip(ent['params'], ent['views']):
                         if p.grad is not None:
                             p.grad = v
-            return
-        if i == 0:
-            self.inflight = self.sync.start(self._params(self.opt), sources=cur.get('src'))         # overlaps segment B
-        elif i == 1:
-            self.inflight.wait()
-        elif i == 2:
-            self.sync.start(self._params(self.opt_L), sources=cur.get('src_L')).wait()
+            else:
+                for h in self.inflight:
+                    h.wait()
+                self.inflight = []
+        elif tag == 'c' and not capturing:
+            self.sync.start(meh, sources=cur.get('src_L')).wait()
 
     def _run_eager(self, comm=True):
         """comm=False (warm-up before a capture): NO collective is issued -- the iteration is undone afterwards anyway (_restore), and a
         rank that captures must issue exactly the collectives of a rank that replays or runs eagerly (ranks see different batch shapes
         with keep-ratio VOC data and keep their own graph caches: one rank may capture while its peers replay)."""
-        for i, f in enumerate((self._seg_a, self._seg_b, self._seg_c, self._seg_d)):
+        self.inflight = []
+        for tag, f in self._segments(getattr(self, 'dist_mode', False)):
             f()
             if comm:
-                self._between(i)
-            elif self.sync is not None and i < 2:         # hand the flat-buffer slices back to the next backward (what start() does)
-                self.sync.release(self._params(self.opt if i == 0 else self.opt_L))
+                self._between(tag)
+            elif self.sync is not None and tag in ('b', 'c'):       # hand the flat-buffer slices back to the next backward (what start() does)
+                self.sync.release(self._params(self.opt if tag == 'b' else self.opt_L))
 
     # ------------------------------------------------------------------ state snapshot around warm-up
     def _snapshot(self):
@@ -186,9 +218,12 @@ class GraphedTrainStep:
 
     def _build(self, d):
         from .parallel import is_dist
-        dist_mode = self.sync is not None and is_dist()
+        dist_mode = self.dist_mode = self.sync is not None and is_dist()
+        self.nseg = 1
         if dist_mode:                      # gradients must land in the flat buffer's slices from the first captured backward on
-            self.sync.attach(self._params(self.opt)), self.sync.attach(self._params(self.opt_L))
+            main = self._params(self.opt)
+            self.nseg = self.sync.attach(main, segments=self.module.grad_segments(main) if hasattr(self.module, 'grad_segments') else None)['nseg']
+            self.sync.attach(self._params(self.opt_L))
         self.cur = dict(static=self._alloc(d), live=None, live_L=None)
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
@@ -205,22 +240,23 @@ class GraphedTrainStep:
         # packed weights / folded BN are re-derived EAGERLY before every replay (one launch, only when a parameter changed): the graph
         # itself must not contain the refresh, or its position would depend on which layers happened to be stale at capture time
         AF.PREP.refresh_if_stale()
-        segs = [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
+        segs = self._segments(dist_mode)
         graphs = []
         if not dist_mode:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):      # other threads (RCCL watchdog) may touch the runtime
-                for f in segs:
+                for _, f in segs:
                     f()
             graphs.append(g)
         else:
             pool = torch.cuda.graph_pool_handle()
-            for i, f in enumerate(segs):
+            for tag, f in segs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                     f()
                 graphs.append(g)
-                self._between(i, capturing=True)
+                self._between(tag, capturing=True)
+            self.cur['tags'] = [tag for tag, _ in segs]
         ho.reset_zero_arena()
         self._restore(snap)                       # warm-up iterations were real updates: undo them, the first replay applies this batch
         AF.PREP.refresh_if_stale()
@@ -254,10 +290,11 @@ class GraphedTrainStep:
         self._load(d)
         self.opt.device_lr(), self.opt_L.device_lr()
         AF.PREP.refresh_if_stale()
+        self.inflight = []
         for i, g in enumerate(ent['graphs']):
             g.replay()
             if len(ent['graphs']) > 1:
-                self._between(i)
+                self._between(ent['tags'][i])
         tp = [p for p in ent['touched'] if p.grad is not None]
         torch._C._autograd._unsafe_set_version_counter(tp, [p._version + 1 for p in tp])
         out, loss_L = ent['live'][0], ent['live_L']

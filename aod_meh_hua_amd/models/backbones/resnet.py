@@ -149,10 +149,22 @@ class ResNet(BaseModule):
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
                 x = blk(x)
+            x = AF.cut(x)                     # (inside functional.grad_cuts(): the backward pass of this stage becomes a segment of its own)
             AF.share_input_grad(x)            # a stage output feeds the next stage's conv1 + downsample conv and the neck (functional.GradAcc)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)
+
+    def grad_segments(self):
+        """Parameter groups in the order their gradients become final in functional.backward_segments(): one per trainable stage, deepest
+        first; everything in front of the first trainable stage's output (stem, frozen or not, and earlier stages) belongs to the last."""
+        stages = [getattr(self, n) for n in self.res_layers]
+        first = next((i for i, st in enumerate(stages) if any(q.requires_grad for q in st.parameters())), len(stages))
+        groups = []
+        for i in range(len(stages) - 1, first - 1, -1):
+            mods = [stages[i]] if i > first else [self.conv1, self.norm1] + stages[:first + 1]
+            groups.append([q for m in mods for q in m.parameters() if q.requires_grad])
+        return groups
 
     def train(self, mode=True):
         """resnet.py:647-656: keep BN in eval mode, keep frozen stages frozen."""

@@ -99,6 +99,16 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
         loss, log_vars = self._parse_losses(losses, device=prev_loss[0].device)
         return dict(loss=loss, log_vars=log_vars, num_samples=2)
 
+    def grad_segments(self, params):
+        """`params` (one optimizer's parameter list) split into the groups whose gradients become final together in
+        functional.backward_segments(): [everything behind no cut (neck, heads), deepest backbone stage, ..., shallowest].  A backbone without
+        cut points (SSD's VGG) gives one group."""
+        ids = {id(q) for q in params}
+        groups = [[q for q in g if id(q) in ids] for g in (self.backbone.grad_segments() if hasattr(self.backbone, 'grad_segments') else [])]
+        groups = [g for g in groups if g]
+        behind = {id(q) for g in groups for q in g}
+        return [[q for q in params if id(q) not in behind]] + groups
+
     def val_step(self, data, optimizer=None, **kwargs):
         losses = self(**data)
         loss, log_vars = self._parse_losses(losses[0] if isinstance(losses, tuple) else losses)

@@ -27,11 +27,11 @@ def get_dist_info():
 
 
 class _PendingSync:
-    """In-flight bucketed all-reduce of one flat gradient buffer: wait() finishes the collectives, turns the sums into means and makes
-    every parameter's .grad the averaged slice of the flat buffer (a re-pointing, not a copy)."""
+    """In-flight bucketed all-reduce of (a segment of) one flat gradient buffer: wait() finishes the collectives, turns the sums into means
+    and makes every covered parameter's .grad the averaged slice of the flat buffer (a re-pointing, not a copy)."""
 
-    def __init__(self, ent, works, world, avg_done):
-        self.ent, self.works, self.world, self.avg_done = ent, works, world, avg_done
+    def __init__(self, ent, works, world, avg_done, idx=None, ranges=None):
+        self.ent, self.works, self.world, self.avg_done, self.idx, self.ranges = ent, works, world, avg_done, idx, ranges
 
     def wait(self):
         if self.ent is None:
@@ -40,11 +40,24 @@ class _PendingSync:
             if w is not None:
                 w.wait()
         if not self.avg_done and self.world > 1:
-            self.ent['flat'].mul_(1.0 / self.world)
-        for p, v in zip(self.ent['params'], self.ent['views']):
+            for lo, hi in self.ranges:
+                self.ent['flat'][lo:hi].mul_(1.0 / self.world)
+        idx = self.idx if self.idx is not None else range(len(self.ent['params']))
+        for i in idx:
+            p, v = self.ent['params'][i], self.ent['views'][i]
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 p.grad = v
         self.ent = None
+
+
+class _PendingList:
+    def __init__(self, items):
+        self.items = items
+
+    def wait(self):
+        for it in self.items:
+            it.wait()
+        self.items = []
 
 
 class GradSync:
@@ -53,8 +66,10 @@ class GradSync:
     (functional.ConvFn), so for 99.8 % of the bytes .grad IS the slice and the all-reduce runs in place: no torch.cat, no copy back
     (round 1 moved ~3 x 146 MB per iteration for that).  The few small vectors autograd hands over in their own tensors (BN gamma / beta,
     biases: ~60 K floats) are copied into their slices by one batched launch.  The buffer is reduced in a few large buckets -- xGMI rings
-    are per-link bound -- issued in REVERSE parameter order: the order in which a backward pass finishes them (`bucket_ready` hooks use
-    that to start a bucket's all-reduce while the rest of the backward is still running)."""
+    are per-link bound -- that never straddle a backward SEGMENT (attach(..., segments=...): head + neck, then the backbone stages from the
+    deepest to the shallowest -- the order functional.backward_segments() finishes them in): start(..., segment=k) launches the buckets of
+    segment k as soon as its gradients are final, while the next segment's backward runs (the reference's own pattern for
+    gradient buckets: mmdet/core/utils/dist_utils.py:10-51)."""
 
     ALIGN = 64          # elements: every slice starts on a 256-B boundary (vector stores of the unpack kernel)
 
@@ -62,40 +77,49 @@ class GradSync:
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._ents = {}
 
-    def attach(self, params):
+    def attach(self, params, segments=None):
+        """segments: list of parameter lists (completion order of the backward segments); None keeps what an earlier attach() fixed."""
         params = [p for p in params if p.requires_grad]
         key = tuple(id(p) for p in params)
+        seg_of = None
+        if segments is not None and len(segments) > 1:
+            where = {id(q): k for k, g in enumerate(segments) for q in g}
+            seg_of = tuple(where[id(p)] for p in params)
         ent = self._ents.get(key)
-        if ent is not None and all(r() is p for r, p in zip(ent['refs'], params)):
+        if ent is not None and all(r() is p for r, p in zip(ent['refs'], params)) and (segments is None or ent['seg_of'] == seg_of):
             return ent
         import weakref
         offs, n = [], 0
         for p in params:
             offs.append(n)
             n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-        flat = torch.zeros(max(n, 1), dtype=torch.float32, device=params[0].device)
+        flat = ent['flat'] if ent is not None and ent['flat'].numel() == max(n, 1) and ent['flat'].device == params[0].device else \
+            torch.zeros(max(n, 1), dtype=torch.float32, device=params[0].device)
         views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
         for p, v in zip(params, views):
             p._aod_grad_view = v
-        # buckets = contiguous element ranges, cut at parameter boundaries, walking the parameters backwards
+        # buckets = contiguous element ranges, cut at parameter boundaries -- and at segment boundaries --, walking the parameters backwards
+        sg = seg_of if seg_of is not None else (0,) * len(params)
         buckets, hi, i = [], n, len(params) - 1
         while i >= 0:
             lo = hi
             first = i
-            while i >= 0 and (lo == hi or hi - offs[i] <= self.bucket_elems):
+            while i >= 0 and sg[i] == sg[first] and (lo == hi or hi - offs[i] <= self.bucket_elems):
                 lo = offs[i]
                 i -= 1
-            buckets.append(dict(lo=lo, hi=hi, first_param=i + 1, last_param=first))
+            buckets.append(dict(lo=lo, hi=hi, first_param=i + 1, last_param=first, seg=sg[first]))
             hi = lo
-        ent = dict(flat=flat, views=views, params=params, refs=[weakref.ref(p) for p in params], offs=offs, buckets=buckets)
+        ent = dict(flat=flat, views=views, params=params, refs=[weakref.ref(p) for p in params], offs=offs, buckets=buckets, seg_of=seg_of,
+                   nseg=(max(sg) + 1) if params else 1)
         self._ents[key] = ent
         return ent
 
-    def _gather_small(self, ent, sources=None):
+    def _gather_small(self, ent, sources=None, idx=None):
         """Copy the gradients that do not already live in their slices into them (one batched launch); zero the slices of parameters
         without a gradient this iteration."""
         srcs, dsts = [], []
-        for i, (p, v) in enumerate(zip(ent['params'], ent['views'])):
+        for i in (idx if idx is not None else range(len(ent['params']))):
+            p, v = ent['params'][i], ent['views'][i]
             g = sources[i] if sources is not None else p.grad
             if g is None:
                 v.zero_()
@@ -116,23 +140,44 @@ class GradSync:
         for p in params:
             p.__dict__.pop('_aod_view_busy', None)
 
-    def start(self, params, sources=None):
+    def num_segments(self, params):
+        return self.attach(params)['nseg']
+
+    def start(self, params, sources=None, segment=None):
         """Launch the bucketed all-reduce of the parameters' gradients WITHOUT waiting (RCCL runs it on its own stream).  Returns a
         handle whose wait() must be called before the gradients are read.  `sources`: gradient tensors to read instead of p.grad (the
-        static tensors a captured HIP graph writes, graphs.GraphedTrainStep).  The runner overlaps the main network's all-reduce with the
-        whole MEH forward/backward (disjoint parameters)."""
+        static tensors a captured HIP graph writes, graphs.GraphedTrainStep; indexed like the parameter list).  `segment`: only the buckets
+        of that backward segment (its gradients are final; later segments are still being computed).  The runner also overlaps the main
+        network's last buckets with the whole MEH forward/backward (disjoint parameters)."""
         if not is_dist():
             return _PendingSync(None, [], 1, True)
         ent = self.attach(params)
-        self._gather_small(ent, sources)
+        idx = None
+        if segment is not None and ent['seg_of'] is not None:
+            idx = [i for i, k in enumerate(ent['seg_of']) if k == segment]
+        self._gather_small(ent, sources, idx)
         world = dist.get_world_size()
         avg = dist.get_backend() == 'nccl'
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        works = [dist.all_reduce(ent['flat'][b['lo']:b['hi']], op=op, async_op=True) for b in ent['buckets'] if b['hi'] > b['lo']]
-        return _PendingSync(ent, works, world, avg)
+        bks = [b for b in ent['buckets'] if b['hi'] > b['lo'] and (idx is None or b['seg'] == segment)]
+        works = [dist.all_reduce(ent['flat'][b['lo']:b['hi']], op=op, async_op=True) for b in bks]
+        return _PendingSync(ent, works, world, avg, idx, [(b['lo'], b['hi']) for b in bks])
 
     def all_reduce_grads(self, params):
         self.start(params).wait()
+
+
+def backward_and_sync(gsync, params, loss, cuts):
+    """loss.backward() in segments (functional.backward_segments) with each segment's bucket all-reduce launched as soon as its gradients
+    are final -- the later segments' backward kernels then run beside RCCL.  Returns a handle: wait() before the optimizer step."""
+    from . import functional as AF
+    pend = []
+    if not is_dist() or gsync.num_segments(params) != len(cuts) + 1:
+        AF.backward_segments(loss, cuts)
+        pend.append(gsync.start(params))
+    else:
+        AF.backward_segments(loss, cuts, after=lambda k: pend.append(gsync.start(params, segment=k)))
+    return _PendingList(pend)
 
 
 def shard_range(n_total, rank=None, world=None):
@@ -159,7 +204,20 @@ def gather_scores(local_scores, n_total):
 
 
 def broadcast_model(model, src=0):
+    """rank `src`'s parameters and buffers to every rank: ONE broadcast per dtype of a flat copy (a ResNet-50 detector has ~540 tensors;
+    one collective each is ~540 launches per active-learning cycle), scattered back by a batched copy"""
     if not is_dist():
         return
+    by = {}
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src)
+        by.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():                 # (in-place on the tensors themselves, not .data: the version counters move, so packed-weight
+        for (dt, dev), ts in by.items():  # caches keyed on them -- functional.ParamPrep -- see the new values)
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src)
+            outs = [o.view_as(t) for o, t in zip(flat.split([t.numel() for t in ts]), ts)]
+            if hasattr(torch, '_foreach_copy_') and dt.is_floating_point:
+                torch._foreach_copy_(ts, outs)
+            else:
+                for t, o in zip(ts, outs):
+                    t.copy_(o)

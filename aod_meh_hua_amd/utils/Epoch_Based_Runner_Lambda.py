@@ -32,13 +32,27 @@ class MyEpochBasedRunnerLambda(BaseRunner):
         elif train_mode and self._graphed_iter(data_batch, kwargs):
             outputs = self.outputs
         elif train_mode:
-            loss, head_out, feat_out, prev_loss = self.model.train_step(data_batch, **kwargs)
-            self.optimizer.zero_grad()
-            loss['loss'].backward()
+            from .. import functional as AF
+            from ..parallel import backward_and_sync, is_dist
+            if is_dist():
+                # data parallelism: the backward pass runs in segments (head + neck, then the backbone stages, deepest first) and each
+                # segment's gradient buckets are all-reduced while the next segment computes (parallel.GradSync)
+                if not hasattr(self, '_gsync'):
+                    self._gsync = GradSync()
+                params = [p for g in self.optimizer.param_groups for p in g['params']]
+                self._gsync.attach(params, segments=self._module().grad_segments(params))
+                with AF.grad_cuts() as cuts:
+                    loss, head_out, feat_out, prev_loss = self.model.train_step(data_batch, **kwargs)
+                self.optimizer.zero_grad()
+                pending = backward_and_sync(self._gsync, params, loss['loss'], cuts)
+            else:
+                loss, head_out, feat_out, prev_loss = self.model.train_step(data_batch, **kwargs)
+                self.optimizer.zero_grad()
+                loss['loss'].backward()
+                pending = self._sync_start(self.optimizer)
             # The MEH step reads only detached features / losses and its own parameters (train_step_L), so the main update may be
-            # applied after it: the main all-reduce then runs under the whole MEH forward/backward.  Same values as the reference order
-            # (optimizer.step() before train_step_L, Epoch_Based_Runner_Lambda.py:27-35).
-            pending = self._sync_start(self.optimizer)
+            # applied after it: the main network's last all-reduce buckets then run under the whole MEH forward/backward.  Same values as
+            # the reference order (optimizer.step() before train_step_L, Epoch_Based_Runner_Lambda.py:27-35).
             loss_L = self._module().train_step_L(prev_loss, head_out, feat_out, _data=data_batch, **kwargs)
             self.optimizer_L.zero_grad()
             loss_L['loss'].backward()

@@ -36,10 +36,11 @@ def build():
     return model, opt, opt_L
 
 
-def batch(step, rank, B=2, H=128):
+def batch(step, rank, B=2, H=128, W=None):
+    W = W or H
     seed = 100 + 10 * step + rank
-    gtb, gtl = synth.random_gts(B, H, H, seed=seed, gmin=1, gmax=3)
-    return dict(img=synth.images(B, H, H, seed=seed).cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=gtb, gt_labels=gtl)
+    gtb, gtl = synth.random_gts(B, H, W, seed=seed, gmin=1, gmax=3)
+    return dict(img=synth.images(B, H, W, seed=seed).cuda(), img_metas=synth.metas(B, H, W), gt_bboxes=gtb, gt_labels=gtl)
 
 
 def digest(model):
@@ -50,11 +51,17 @@ def digest(model):
 
 
 def eager_dp_iter(model, opt, opt_L, gsync, data):
-    """the runner's eager order (utils/Epoch_Based_Runner_Lambda.py run_iter)"""
-    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    """the runner's eager order under data parallelism (utils/Epoch_Based_Runner_Lambda.py run_iter): segmented backward, every segment's
+    buckets all-reduced while the next segment computes"""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.parallel import backward_and_sync
+    main = opt.param_groups[0]['params']
+    gsync.attach(main, segments=model.grad_segments(main))
+    with AF.grad_cuts() as cuts:
+        out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    assert len(cuts) == 3 and gsync.num_segments(main) == 4          # layer2 / layer3 / layer4 outputs; heads + neck, layer4, layer3, layer2
     opt.zero_grad()
-    out['loss'].backward()
-    pending = gsync.start(opt.param_groups[0]['params'])
+    pending = backward_and_sync(gsync, main, out['loss'], cuts)
     lossL = model.train_step_L(prev, head_out, feat_out)
     opt_L.zero_grad()
     lossL['loss'].backward()
@@ -89,6 +96,29 @@ def main():
         res[mode + '_grad_is_flat_slice'] = all(p.grad is not None and p.grad.data_ptr() == p._aod_grad_view.data_ptr() for p in opt.param_groups[0]['params'])
         if rank == 0:
             res[mode] = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    # ranks that see DIFFERENT batch-shape sequences (keep-ratio VOC batches): each decides on its own whether it replays, captures or runs
+    # eagerly (graphs.GraphedTrainStep.maybe); all three issue the same collectives, so the replicas must stay bit-equal and nothing may hang
+    model, opt, opt_L = build()
+    broadcast_model(model)
+    gsync = GradSync(bucket_mb=16)
+    gs = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync, warmup=1, Labeled=True, Pseudo=False)
+    shapes = {0: [(128, 128), (128, 128), (128, 160), (128, 128), (128, 128), (128, 160)],
+              1: [(128, 128), (128, 160), (128, 160), (128, 160), (128, 128), (128, 160)]}[rank]
+    modes = []
+    for step, (H, W) in enumerate(shapes):
+        d = batch(step, rank, H=H, W=W)
+        if gs.maybe(d) is None:
+            eager_dp_iter(model, opt, opt_L, gsync, d)
+            modes.append('eager')
+        else:
+            modes.append('graph')
+    torch.cuda.synchronize()
+    hs = [None] * world
+    dist.all_gather_object(hs, digest(model))
+    res['mixed_replicas_equal'] = len(set(hs)) == 1
+    ms = [None] * world
+    dist.all_gather_object(ms, modes)
+    res['mixed_modes'] = ms
     if rank == 0:
         # one process, both ranks' batches, mean gradient
         model, opt, opt_L = build()

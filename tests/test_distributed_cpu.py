@@ -29,7 +29,23 @@ def _worker(rank, world, port, n_total, q):
     m = torch.nn.Linear(2, 2)
     with torch.no_grad():
         m.weight.fill_(float(rank))
+    v0 = m.weight._version
     broadcast_model(m)
+    assert m.weight._version > v0                       # packed-weight caches keyed on the version see the broadcast values
+    # segmented start: buckets never straddle a backward segment; each segment is reduced on its own, in completion order
+    qs = [torch.nn.Parameter(torch.zeros(n)) for n in (4, 70, 3, 5)]
+    gs2 = GradSync(bucket_mb=1)
+    ent = gs2.attach(qs, segments=[[qs[3]], [qs[1], qs[2]], [qs[0]]])      # (heads), (deep stage), (shallow stage)
+    assert gs2.num_segments(qs) == 3 and sorted(b['seg'] for b in ent['buckets']) == [0, 1, 2]
+    for k, idx in ((0, [3]), (1, [1, 2]), (2, [0])):
+        for i in idx:
+            qs[i].grad = torch.full_like(qs[i], float((rank + 1) * (i + 1)))
+        gs2.start(qs, segment=k).wait()
+        for i in idx:
+            assert qs[i].grad.data_ptr() == qs[i]._aod_grad_view.data_ptr() and torch.equal(qs[i].grad, torch.full_like(qs[i], 1.5 * (i + 1)))
+        for i in range(4):                                # later segments are untouched so far
+            if i not in idx and qs[i].grad is None:
+                assert float(qs[i]._aod_grad_view.abs().sum()) == 0.0
     q.put((rank, lo, hi, full.tolist(), p1.grad.tolist(), p2.grad.flatten().tolist(), m.weight.flatten().tolist()))
     dist.destroy_process_group()
 

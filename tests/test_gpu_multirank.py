@@ -38,5 +38,9 @@ def test_two_rank_replicas_stay_equal_and_match_a_mean_gradient_run():
     assert out['graph_replicas_equal'] and out['eager_replicas_equal'], out
     assert out['graph_grad_is_flat_slice'] and out['eager_grad_is_flat_slice'], out
     assert out['moved'] > 0
-    # fp32 atomics in wgrad / column sums make single runs differ in the last bits; three small SGD steps stay within 1e-4 relative
-    assert out['graph_vs_mean_gradient_run'] < 1e-3 and out['eager_vs_mean_gradient_run'] < 1e-3, out
+    # weight gradients are slab-deterministic; only the bias / BN column sums still go through fp32 atomics (arrival order), so the
+    # data-parallel result equals the one-process mean-gradient run to the last few bits of three small SGD steps
+    assert out['graph_vs_mean_gradient_run'] < 1e-5 and out['eager_vs_mean_gradient_run'] < 1e-5, out
+    # per-rank shape sequences differ: the ranks mixed eager / capture / replay differently and still agree (graphs.py)
+    assert out['mixed_replicas_equal'], out
+    assert out['mixed_modes'][0] != out['mixed_modes'][1] and any(m == 'graph' for ms in out['mixed_modes'] for m in ms), out
