@@ -264,6 +264,12 @@ def bbox_flip(bboxes, img_shape, direction):
         h = img_shape[0]
         flipped[..., 1::4] = h - bboxes[..., 3::4]
         flipped[..., 3::4] = h - bboxes[..., 1::4]
+    elif direction == 'diagonal':
+        w, h = img_shape[1], img_shape[0]
+        flipped[..., 0::4] = w - bboxes[..., 2::4]
+        flipped[..., 1::4] = h - bboxes[..., 3::4]
+        flipped[..., 2::4] = w - bboxes[..., 0::4]
+        flipped[..., 3::4] = h - bboxes[..., 1::4]
     else:
         raise ValueError(f"Invalid flipping direction '{direction}'")
     return flipped
@@ -294,7 +300,8 @@ class RandomFlip:
         if results['flip']:
             for key in results.get('img_fields', ['img']):
                 img = results[key]
-                results[key] = np.ascontiguousarray(img[:, ::-1] if results['flip_direction'] == 'horizontal' else img[::-1])
+                fd = results['flip_direction']
+                results[key] = np.ascontiguousarray(img[:, ::-1] if fd == 'horizontal' else (img[::-1] if fd == 'vertical' else img[::-1, ::-1]))
             for key in results.get('bbox_fields', []):
                 results[key] = bbox_flip(results[key], results['img_shape'], results['flip_direction'])
         return results

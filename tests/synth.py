@@ -137,3 +137,37 @@ def detection_eval_case(seed=50, n_img=24, num_classes=20, with_ignore=True):
             ann.update(bboxes_ignore=gtb[ign], labels_ignore=gtl[ign])
         anns.append(ann)
     return dets, anns
+
+
+# ---------------------------------------------------------------- tiny VOC tree (real data path: tests/test_voc_data.py, tools/golden/make_golden_data.py)
+TINY_VOC = [('000001', 500, 375, [('dog', 0, (48, 240, 195, 371)), ('person', 0, (8, 12, 352, 498 - 200)), ('cat', 1, (100, 100, 200, 200))]),
+            ('000002', 333, 500, [('car', 0, (10.6, 20, 300, 480))]),
+            ('000003', 480, 360, [('unicorn', 0, (1, 1, 50, 50))]),                     # no VOC class -> filtered in train mode
+            ('000004', 20, 300, [('bird', 0, (1, 1, 15, 100))]),                        # too small (min side < 32)
+            ('000005', 400, 300, [('sofa', 0, (30, 40, 200, 220)), ('chair', 0, (5, 5, 40, 60))])]
+
+
+def voc_xml(w, h, objs, with_size=True):
+    o = ''.join(f'<object><name>{n}</name><difficult>{d}</difficult><bndbox><xmin>{b[0]}</xmin><ymin>{b[1]}</ymin><xmax>{b[2]}</xmax>'
+                f'<ymax>{b[3]}</ymax></bndbox></object>' for n, d, b in objs)
+    size = f'<size><width>{w}</width><height>{h}</height><depth>3</depth></size>' if with_size else ''
+    return f'<annotation>{size}{o}</annotation>'
+
+
+def write_tiny_voc(root):
+    """VOC2007-shaped tree under `root` (a directory that ends in 'VOC2007'): five images (random pixels, seeded), annotations with a
+    difficult object, a float coordinate, a non-VOC class, a too-small image and one XML without a <size> element.  Returns root + '/'."""
+    import os
+
+    from PIL import Image
+    root = str(root)
+    for d in ('JPEGImages', 'Annotations', 'ImageSets/Main'):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    rng = np.random.RandomState(0)
+    for i, (iid, w, h, objs) in enumerate(TINY_VOC):
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, 'JPEGImages', f'{iid}.jpg'), quality=95)
+        with open(os.path.join(root, 'Annotations', f'{iid}.xml'), 'w') as f:
+            f.write(voc_xml(w, h, objs, with_size=i != 4))
+    with open(os.path.join(root, 'ImageSets/Main/trainval.txt'), 'w') as f:
+        f.write('\n'.join(i[0] for i in TINY_VOC) + '\n')
+    return root + '/'

@@ -21,30 +21,10 @@ TEST = [dict(type='LoadImageFromFile'),
                          dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']), dict(type='Collect', keys=['img'])])]
 
 
-def _xml(w, h, objs, with_size=True):
-    o = ''.join(f'<object><name>{n}</name><difficult>{d}</difficult><bndbox><xmin>{b[0]}</xmin><ymin>{b[1]}</ymin><xmax>{b[2]}</xmax>'
-                f'<ymax>{b[3]}</ymax></bndbox></object>' for n, d, b in objs)
-    size = f'<size><width>{w}</width><height>{h}</height><depth>3</depth></size>' if with_size else ''
-    return f'<annotation>{size}{o}</annotation>'
-
-
 @pytest.fixture(scope='module')
 def voc(tmp_path_factory):
-    from PIL import Image
-    root = tmp_path_factory.mktemp('VOCdevkit') / 'VOC2007'
-    for d in ('JPEGImages', 'Annotations', 'ImageSets/Main'):
-        os.makedirs(root / d)
-    rng = np.random.RandomState(0)
-    items = [('000001', 500, 375, [('dog', 0, (48, 240, 195, 371)), ('person', 0, (8, 12, 352, 498 - 200)), ('cat', 1, (100, 100, 200, 200))]),
-             ('000002', 333, 500, [('car', 0, (10.6, 20, 300, 480))]),
-             ('000003', 480, 360, [('unicorn', 0, (1, 1, 50, 50))]),                     # no VOC class -> filtered in train mode
-             ('000004', 20, 300, [('bird', 0, (1, 1, 15, 100))]),                        # too small (min side < 32)
-             ('000005', 400, 300, [('sofa', 0, (30, 40, 200, 220)), ('chair', 0, (5, 5, 40, 60))])]
-    for i, (iid, w, h, objs) in enumerate(items):
-        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(root / 'JPEGImages' / f'{iid}.jpg', quality=95)
-        (root / 'Annotations' / f'{iid}.xml').write_text(_xml(w, h, objs, with_size=i != 4))
-    (root / 'ImageSets/Main/trainval.txt').write_text('\n'.join(i[0] for i in items) + '\n')
-    return str(root) + '/'
+    from tests import synth
+    return synth.write_tiny_voc(tmp_path_factory.mktemp('VOCdevkit') / 'VOC2007')
 
 
 def test_xml_parsing_filtering_and_groups(voc):
@@ -173,3 +153,121 @@ def test_voc_evaluate_hooks_into_the_fork_metric(voc):
         results.append(per)
     out = test.evaluate(results, metric='mAP', logger='silent', show=False, isUnc=False, out_dir=None)
     assert out['mAP'] == 1.0 and out['AP50'] == 1.0                # perfect detections; VOC07 11-point mode (img_prefix has VOC2007)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the same rules against the REFERENCE's own classes (tests/golden/voc_data.npz, tools/golden/make_golden_data.py: XMLDataset / VOCDataset,
+# GroupSampler / DistributedGroupSampler, Resize / RandomFlip / Pad / Expand / MinIoURandomCrop / Collect run from /root/reference under the
+# mmcv shim on this very tree; geometry and random-draw order only -- the mmcv pixel functions are absent)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'voc_data.npz')
+
+
+def _base(h=375, w=500):
+    img = np.random.RandomState(1).randint(0, 255, (h, w, 3)).astype(np.float32)
+    boxes = np.array([[47, 239, 194, 370], [7, 11, 351, 297], [480, 5, 499, 60]], np.float32)
+    return dict(img=img, img_shape=img.shape, ori_shape=img.shape, img_fields=['img'], bbox_fields=['gt_bboxes'], gt_bboxes=boxes,
+                gt_labels=np.array([11, 14, 3], np.int64), filename='x.jpg', ori_filename='x.jpg')
+
+
+def test_xml_dataset_matches_the_reference_golden(voc):
+    g = np.load(GOLD)
+    ds = build_dataset(dict(type='VOCDataset', ann_file=voc + 'ImageSets/Main/trainval.txt', img_prefix=voc, pipeline=[]))
+    assert [d['id'] for d in ds.data_infos] == g['ids'].tolist() and ds.year == int(g['year'])
+    assert np.array_equal([[d['width'], d['height']] for d in ds.data_infos], g['wh']) and np.array_equal(ds.flag, g['flag'])
+    for i in range(len(ds)):
+        a = ds.get_ann_info(i)
+        for k in ('bboxes', 'labels', 'bboxes_ignore', 'labels_ignore'):
+            assert np.array_equal(a[k], g[f'ann{i}_{k}']) and a[k].dtype == g[f'ann{i}_{k}'].dtype, (i, k)
+        assert ds.get_cat_ids(i) == g[f'cat_ids{i}'].tolist()
+    test = build_dataset(dict(type='VOCDataset', ann_file=voc + 'ImageSets/Main/trainval.txt', img_prefix=voc, pipeline=[]), dict(test_mode=True))
+    assert [d['id'] for d in test.data_infos] == g['test_ids'].tolist()
+    dm = build_dataset(dict(type='VOCDataset', ann_file=voc + 'ImageSets/Main/trainval.txt', img_prefix=voc, pipeline=[], min_size=120))
+    assert np.array_equal(dm.get_ann_info(0)['bboxes'], g['minsize_ann0_bboxes']) and np.array_equal(dm.get_ann_info(0)['bboxes_ignore'], g['minsize_ann0_ignore'])
+
+
+def test_samplers_match_the_reference_golden():
+    from aod_meh_hua_amd.datasets import DistributedGroupSampler
+    g = np.load(GOLD)
+
+    class Flags:
+        def __init__(self, flag):
+            self.flag = np.asarray(flag, dtype=np.uint8)
+
+        def __len__(self):
+            return len(self.flag)
+    ds = Flags(g['sampler_flags'])
+    for spg in (2, 4):
+        np.random.seed(11)
+        assert list(GroupSampler(ds, samples_per_gpu=spg)) == g[f'group_sampler_spg{spg}'].tolist()
+    for rank in (0, 1):
+        for epoch in (0, 3):
+            s = DistributedGroupSampler(ds, samples_per_gpu=2, num_replicas=2, rank=rank, seed=5)
+            s.set_epoch(epoch)
+            assert list(s) == g[f'dist_sampler_r{rank}_e{epoch}'].tolist(), (rank, epoch)
+    assert len(DistributedGroupSampler(ds, samples_per_gpu=2, num_replicas=2, rank=0, seed=5)) == int(g['dist_sampler_len'])
+
+
+def test_transform_geometry_matches_the_reference_golden():
+    g = np.load(GOLD)
+    r = P.Resize(img_scale=(1000, 600), keep_ratio=True)(_base())
+    assert tuple(r['img_shape']) == tuple(g['resize_keep_shape']) and np.array_equal(r['scale_factor'], g['resize_keep_sf']) and np.array_equal(r['gt_bboxes'], g['resize_keep_boxes'])
+    r = P.Resize(img_scale=(300, 300), keep_ratio=False)(_base())
+    assert tuple(r['img_shape']) == tuple(g['resize_fix_shape']) and np.array_equal(r['scale_factor'], g['resize_fix_sf']) and np.array_equal(r['gt_bboxes'], g['resize_fix_boxes'])
+    r = P.Resize(img_scale=(1000, 600), keep_ratio=True)(_base(500, 333))
+    assert tuple(r['img_shape']) == tuple(g['resize_tall_shape']) and np.array_equal(r['scale_factor'], g['resize_tall_sf'])
+    np.random.seed(21)
+    rs, sc = P.Resize(img_scale=[(1333, 640), (1333, 800)], multiscale_mode='range', keep_ratio=True), []
+    for _ in range(8):
+        d = {}
+        rs._random_scale(d)
+        sc.append(d['scale'])
+    assert np.array_equal(np.array(sc), g['resize_range_scales'])
+    np.random.seed(22)
+    rs, sc = P.Resize(img_scale=[(1333, 640), (1333, 672), (1333, 800)], multiscale_mode='value', keep_ratio=True), []
+    for _ in range(8):
+        d = {}
+        rs._random_scale(d)
+        sc.append(list(d['scale']) + [d['scale_idx']])
+    assert np.array_equal(np.array(sc), g['resize_value_scales'])
+    code = {None: 0, 'horizontal': 1, 'vertical': 2, 'diagonal': 3}
+    np.random.seed(23)
+    fl = P.RandomFlip(flip_ratio=0.5)
+    dec = []
+    for _ in range(12):
+        r = fl(_base())
+        dec.append([int(bool(r['flip'])), code[r['flip_direction']]])
+    assert np.array_equal(np.array(dec), g['flip_decisions'])
+    np.random.seed(24)
+    fl3 = P.RandomFlip(flip_ratio=[0.3, 0.2, 0.2], direction=['horizontal', 'vertical', 'diagonal'])
+    dec, fb = [], []
+    for _ in range(12):
+        r = fl3(_base())
+        dec.append(code[r['flip_direction']] if r['flip'] else 0)
+        fb.append(r['gt_bboxes'])
+    assert np.array_equal(np.array(dec), g['flip3_decisions']) and np.array_equal(np.stack(fb), g['flip3_boxes'])
+    for d_ in ('horizontal', 'vertical', 'diagonal'):
+        assert np.array_equal(P.bbox_flip(_base()['gt_bboxes'], (375, 500, 3), d_), g[f'bbox_flip_{d_}'])
+    r = P.Pad(size_divisor=32)(dict(img=np.zeros((600, 800, 3), np.float32), img_fields=['img']))
+    assert tuple(r['pad_shape']) == tuple(g['pad_shape'])
+    np.random.seed(25)
+    ex = P.Expand(mean=(123.675, 116.28, 103.53), to_rgb=True, ratio_range=(1, 4))
+    shp, bx = [], []
+    for _ in range(10):
+        r = ex(_base(300, 400))
+        shp.append(r['img'].shape[:2])
+        bx.append(r['gt_bboxes'])
+    assert np.array_equal(np.array(shp), g['expand_shapes']) and np.array_equal(np.stack(bx), g['expand_boxes'])
+    np.random.seed(26)
+    mc = P.MinIoURandomCrop(min_ious=(0.1, 0.3, 0.5, 0.7, 0.9), min_crop_size=0.3)
+    for k in range(12):
+        r = mc(_base(300, 400))
+        assert tuple(r['img'].shape[:2]) == tuple(g['crop_shapes'][k]), k
+        assert np.array_equal(r['gt_bboxes'], g[f'crop{k}_boxes']) and np.array_equal(r['gt_labels'], g[f'crop{k}_labels']), k
+    np.random.seed(27)
+    res = _base()
+    for tr in (P.Resize(img_scale=(1000, 600), keep_ratio=True), P.RandomFlip(flip_ratio=0.5), P.Normalize(**IMG_NORM), P.Pad(size_divisor=32)):
+        res = tr(res)
+    meta = P.Collect(keys=['img', 'gt_bboxes', 'gt_labels'])(res)['img_metas'].data
+    assert sorted(meta.keys()) == g['meta_keys'].tolist()
+    assert tuple(meta['img_shape']) == tuple(g['meta_img_shape']) and tuple(meta['pad_shape']) == tuple(g['meta_pad_shape']) and tuple(meta['ori_shape']) == tuple(g['meta_ori_shape'])
+    assert np.array_equal(meta['scale_factor'], g['meta_scale_factor']) and bool(meta['flip']) == bool(g['meta_flip']) and np.array_equal(res['gt_bboxes'], g['meta_boxes'])
