@@ -1,11 +1,11 @@
-"""Oracle: SSD300-VGG16 + MEH/HUA (BASELINE config 0) as plain functional torch fp32 on CPU.
+"""Oracle: SSD300-VGG16 (and SSD512, `v=V512`: configs/ssd/ssd512_voc.py) + MEH/HUA (BASELINE config 0) as plain functional torch fp32 on CPU.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates
   mmdet/models/backbones/ssd_vgg.py:12-118 (+ mmcv.cnn.VGG layer order), mmdet/models/necks/ssd_neck.py (extra layers + L2Norm),
   mmdet/core/anchor/anchor_generator.py:460-564 (SSDAnchorGenerator),
   mmdet/models/dense_heads/My_L_ssd_head.py:102-137 (layers), :169-180 (forward / forward_L), :182-215 (loss_single),
   :217-224 + :302-313 (MEH loss), :226-300 (loss), :316-433 (_get_bboxes), :435-482 (ComputeObjUnc).
-Pinned by tests/golden/ssd_*.npz (tools/golden/make_golden_ssd.py runs the reference itself)."""
+Pinned by tests/golden/ssd_*.npz and ssd512_*.npz (tools/golden/make_golden_ssd.py runs the reference itself, SSD300 and SSD512)."""
 from collections import OrderedDict
 
 import numpy as np
@@ -15,11 +15,25 @@ import torch.nn.functional as F
 from . import detect, geometry, hua, losses
 
 VGG16 = (2, 2, 3, 3, 3)
-IN_CH = (512, 1024, 512, 256, 256, 256)
-NUM_ANCHORS = (4, 6, 6, 6, 4, 4)
-STRIDES = (8, 16, 32, 64, 100, 300)
-RATIOS = ([2], [2, 3], [2, 3], [2, 3], [2], [2])
-EXTRA = ((1024, 256, 512, 2, 1), (512, 128, 256, 2, 1), (256, 128, 256, 1, 0), (256, 128, 256, 1, 0))   # (in, mid, out, stride, pad)
+
+
+class Variant:
+    """one SSD input size: Config_SSD.py:23-62 (300) or that config with the overrides of configs/ssd/ssd512_voc.py (512)"""
+
+    def __init__(self, input_size, in_ch, num_anchors, strides, ratios, extra, basesize_ratio_range, sizes):
+        self.input_size, self.IN_CH, self.NUM_ANCHORS, self.STRIDES, self.RATIOS, self.EXTRA = input_size, in_ch, num_anchors, strides, ratios, extra
+        self.basesize_ratio_range, self.SIZES = basesize_ratio_range, sizes
+
+
+# EXTRA rows: (in, mid, out, kernel, stride, pad) of one extra level (ssd_neck.py:64-88: 1x1 reduce, then kernel x kernel)
+V300 = Variant(300, (512, 1024, 512, 256, 256, 256), (4, 6, 6, 6, 4, 4), (8, 16, 32, 64, 100, 300), ([2], [2, 3], [2, 3], [2, 3], [2], [2]),
+               ((1024, 256, 512, 3, 2, 1), (512, 128, 256, 3, 2, 1), (256, 128, 256, 3, 1, 0), (256, 128, 256, 3, 1, 0)), (0.15, 0.9),
+               (38, 19, 10, 5, 3, 1))
+V512 = Variant(512, (512, 1024, 512, 256, 256, 256, 256), (4, 6, 6, 6, 6, 4, 4), (8, 16, 32, 64, 128, 256, 512),
+               ([2], [2, 3], [2, 3], [2, 3], [2, 3], [2], [2]),
+               ((1024, 256, 512, 3, 2, 1), (512, 128, 256, 3, 2, 1), (256, 128, 256, 3, 2, 1), (256, 128, 256, 3, 2, 1), (256, 128, 256, 4, 1, 1)),
+               (0.1, 0.9), (64, 32, 16, 8, 4, 2, 1))
+IN_CH, NUM_ANCHORS, STRIDES, RATIOS = V300.IN_CH, V300.NUM_ANCHORS, V300.STRIDES, V300.RATIOS       # (SSD300 names kept for the existing tests)
 CODER_STDS = (0.1, 0.1, 0.2, 0.2)
 ASSIGNER = dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.0, gt_max_assign_all=False)
 
@@ -47,27 +61,27 @@ def vgg_layers():
     return out
 
 
-def state_dict_spec(num_classes=20):
+def state_dict_spec(num_classes=20, v=V300):
     spec = []
     for kind, idx, a in vgg_layers():
         if kind == 'conv':
             spec += [(f'backbone.features.{idx}.weight', (a[1], a[0], a[2], a[2])), (f'backbone.features.{idx}.bias', (a[1],))]
     spec.append(('neck.l2_norm.weight', (512,)))
-    for i, (cin, mid, cout, s, p) in enumerate(EXTRA):
+    for i, (cin, mid, cout, k, s, p) in enumerate(v.EXTRA):
         spec += [(f'neck.extra_layers.{i}.0.conv.weight', (mid, cin, 1, 1)), (f'neck.extra_layers.{i}.0.conv.bias', (mid,)),
-                 (f'neck.extra_layers.{i}.1.conv.weight', (cout, mid, 3, 3)), (f'neck.extra_layers.{i}.1.conv.bias', (cout,))]
+                 (f'neck.extra_layers.{i}.1.conv.weight', (cout, mid, k, k)), (f'neck.extra_layers.{i}.1.conv.bias', (cout,))]
     for name, per in (('cls_convs', num_classes + 1), ('reg_convs', 4), ('L_convs', 1)):
-        for l, (c, na) in enumerate(zip(IN_CH, NUM_ANCHORS)):
+        for l, (c, na) in enumerate(zip(v.IN_CH, v.NUM_ANCHORS)):
             spec += [(f'bbox_head.{name}.{l}.0.weight', (na * per, c, 3, 3)), (f'bbox_head.{name}.{l}.0.bias', (na * per,))]
     return spec
 
 
-def seeded_state_dict(num_classes=20):
+def seeded_state_dict(num_classes=20, v=V300):
     """Weight recipe shared by the golden generator and the build (the VGG16-caffe checkpoint is not available offline):
     tensor idx in state_dict order -> Generator(120+idx); backbone / neck conv weights Kaiming-normal, head conv weights N(0, 0.01),
     biases 0.02*N(0,1) (so bias gradients are exercised), L2Norm weight 20 (ssd_neck.py init)."""
     sd = OrderedDict()
-    for idx, (k, shp) in enumerate(state_dict_spec(num_classes)):
+    for idx, (k, shp) in enumerate(state_dict_spec(num_classes, v)):
         g = torch.Generator().manual_seed(120 + idx)
         if k == 'neck.l2_norm.weight':
             sd[k] = torch.full(shp, 20.0)
@@ -101,12 +115,12 @@ def l2norm(x, weight, eps=1e-10):
     return (weight[None, :, None, None].float().expand_as(xf) * xf / norm).type_as(x)
 
 
-def neck(sd, feats):
+def neck(sd, feats, v=V300):
     outs = [l2norm(feats[0], sd['neck.l2_norm.weight']), feats[1]]
     x = feats[1]
-    for i, (cin, mid, cout, s, p) in enumerate(EXTRA):
+    for i, (cin, mid, cout, k, s, p) in enumerate(v.EXTRA):
         x = F.relu(F.conv2d(x, sd[f'neck.extra_layers.{i}.0.conv.weight'], sd[f'neck.extra_layers.{i}.0.conv.bias']))
-        x = F.relu(F.conv2d(x, sd[f'neck.extra_layers.{i}.1.conv.weight'], sd[f'neck.extra_layers.{i}.1.conv.bias'], s, p))
+        x = F.relu(F.conv2d(x, sd[f'neck.extra_layers.{i}.1.conv.weight'], sd[f'neck.extra_layers.{i}.1.conv.bias'], s, p))      # (k x k from the weight)
         outs.append(x)
     return outs
 
@@ -122,9 +136,11 @@ def head_forward_L(sd, feats):
 
 
 # ---------------------------------------------------------------- anchors
-def ssd_base_anchors(input_size=300, basesize_ratio_range=(0.15, 0.9), strides=STRIDES, ratios=RATIOS):
+def ssd_base_anchors(input_size=None, basesize_ratio_range=None, strides=None, ratios=None, v=V300):
     """anchor_generator.py:476-564: min/max sizes, scales [1, sqrt(max/min)], ratios [1, 1/r, r ...], scale_major=False
     (anchor_generator.py:150-193 else-branch), centre = stride/2, then index_select [0, n, 1, .., n-1]."""
+    input_size, basesize_ratio_range = input_size or v.input_size, basesize_ratio_range or v.basesize_ratio_range
+    strides, ratios = strides or v.STRIDES, ratios or v.RATIOS
     nl = len(strides)
     mn, mx = int(basesize_ratio_range[0] * 100), int(basesize_ratio_range[1] * 100)
     step = int(np.floor(mx - mn) / (nl - 2))
@@ -155,10 +171,10 @@ def ssd_base_anchors(input_size=300, basesize_ratio_range=(0.15, 0.9), strides=S
     return out
 
 
-def anchors_for(featmap_sizes, pad_shapes):
-    base = ssd_base_anchors()
-    mlvl = geometry.grid_anchors(base, featmap_sizes, STRIDES)
-    flags = [geometry.valid_flags(featmap_sizes, STRIDES, ps, list(NUM_ANCHORS)) for ps in pad_shapes]
+def anchors_for(featmap_sizes, pad_shapes, v=V300):
+    base = ssd_base_anchors(v=v)
+    mlvl = geometry.grid_anchors(base, featmap_sizes, v.STRIDES)
+    flags = [geometry.valid_flags(featmap_sizes, v.STRIDES, ps, list(v.NUM_ANCHORS)) for ps in pad_shapes]
     return mlvl, flags
 
 
@@ -180,13 +196,13 @@ def ssd_loss_single(cls_score, bbox_pred, labels, label_weights, bbox_targets, b
     return loss_cls[None], loss_bbox, ce
 
 
-def train_step(sd, img, gt_bboxes, gt_labels, num_classes=20):
+def train_step(sd, img, gt_bboxes, gt_labels, num_classes=20, v=V300):
     """SSD_L_SingleStageDetector.forward_train -> MyLSSDHead.loss -> _parse_losses."""
     B, _, H, W = img.shape
-    feats = neck(sd, backbone(sd, img))
+    feats = neck(sd, backbone(sd, img), v)
     cls, reg = head_forward(sd, feats)
     sizes = [tuple(f.shape[-2:]) for f in feats]
-    mlvl, flags = anchors_for(sizes, [(H, W, 3)] * B)
+    mlvl, flags = anchors_for(sizes, [(H, W, 3)] * B, v)
     tg = geometry.get_targets(mlvl, flags, gt_bboxes, gt_labels, num_classes, assigner_cfg=ASSIGNER, coder_stds=CODER_STDS)
     n = tg['num_total_pos']
     all_cls = torch.cat([nhwc_flat(c, num_classes + 1) for c in cls], 1)
@@ -237,20 +253,20 @@ def pre_nms_softmax(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_
 
 
 def score_images(sd, img, img_shapes=None, scale_factors=None, sampler='torch', seed=20, image_ids=None, num_classes=20,
-                 uPool2='objectSum_scaleMax_classSum', heads=None, score_thr=0.02, max_per_img=200):
+                 uPool2='objectSum_scaleMax_classSum', heads=None, score_thr=0.02, max_per_img=200, v=V300):
     """simple_test(isEval=False, uPool='Entropy_NMS') for the SSD head (:598-..., :316-433, :435-482)."""
     B, _, H, W = img.shape
     img_shapes = img_shapes or [(H, W, 3)] * B
     scale_factors = scale_factors or [np.ones(4, np.float32)] * B
     if heads is None:
         with torch.no_grad():
-            feats = neck(sd, backbone(sd, img))
+            feats = neck(sd, backbone(sd, img), v)
             cls, reg = head_forward(sd, feats)
             Ls = head_forward_L(sd, feats)
     else:
         cls, reg, Ls = heads
     sizes = [tuple(c.shape[-2:]) for c in cls]
-    mlvl = geometry.grid_anchors(ssd_base_anchors(), sizes, STRIDES)
+    mlvl = geometry.grid_anchors(ssd_base_anchors(v=v), sizes, v.STRIDES)
     pre = pre_nms_softmax([nhwc_flat(c, num_classes + 1) for c in cls], [nhwc_flat(r, 4) for r in reg],
                           [nhwc_flat(l, 1)[..., 0] for l in Ls], mlvl, img_shapes, scale_factors)
     dets, pos = [], []

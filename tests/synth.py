@@ -86,12 +86,12 @@ SSD_SIZES = (38, 19, 10, 5, 3, 1)
 SSD_ANCHORS = (4, 6, 6, 6, 4, 4)
 
 
-def planted_heads_ssd(B=2, C1=21, seed=23, n_plant=5):
+def planted_heads_ssd(B=2, C1=21, seed=23, n_plant=5, sizes=None, anchors=None):
     """SSD300 head outputs with planted foreground logits: cls = 0.5*N(0,1) over C1 = 21 logits (background last, +2.0 so most
     anchors are background) with +9.0 on a few (anchor, class) 3x3 patches; reg = 0.3*N(0,1); L = U(.01,.31)."""
     g = gen(seed)
     cls, reg, Ls = [], [], []
-    for h, A in zip(SSD_SIZES, SSD_ANCHORS):
+    for h, A in zip(sizes or SSD_SIZES, anchors or SSD_ANCHORS):
         c = 0.5 * torch.randn(B, A * C1, h, h, generator=g)
         c.view(B, A, C1, h, h)[:, :, C1 - 1] += 2.0
         for b in range(B):

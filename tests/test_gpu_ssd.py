@@ -306,3 +306,87 @@ def test_ssd512_seven_levels_train_and_score_on_the_gpu():
                          clsW=False, batchIdx=0)
     unc = torch.as_tensor(unc).float().cpu()
     assert unc.shape == (B,) and torch.isfinite(unc).all() and (unc > -1e-3).all()      # (a Monte-Carlo epistemic estimate may be slightly negative)
+
+
+# ------------------------------------------------------------------------------------------------ SSD512 vs the reference's own outputs
+@pytest.fixture(scope='module')
+def built512():
+    from aod_meh_hua_amd.mmcv_lite import Config
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/ssd/ssd512_voc.py'))
+    cfg.model.backbone.pop('init_cfg', None)
+    model = build_detector(cfg.model)
+    model.load_state_dict(ossd.seeded_state_dict(20, ossd.V512), strict=True)
+    return model.cuda().train(), cfg
+
+
+def test_ssd512_train_step_vs_reference_golden(built512):
+    """configs/ssd/ssd512_voc.py on the HIP kernels against tests/golden/ssd512_*.npz (the REFERENCE's SSD512 run,
+    tools/golden/make_golden_ssd512.py): state_dict layout, anchors, integer-exact assignment over 24 564 anchors, losses, gradient norms."""
+    model, _ = built512
+    gs, g = np.load(os.path.join(G, 'ssd512_spec.npz')), np.load(os.path.join(G, 'ssd512_train_step.npz'))
+    assert list(model.state_dict().keys()) == list(gs['keys']) and [str(tuple(v.shape)) for v in model.state_dict().values()] == list(gs['shapes'])
+    ag = model.bbox_head.anchor_generator
+    assert np.array_equal(np.concatenate([b.cpu().numpy() for b in ag.base_anchors]), gs['base_anchors'])
+    mlvl = ag.grid_anchors([(s, s) for s in ossd.V512.SIZES], 'cuda')
+    assert np.array_equal(mlvl[4].cpu().numpy(), gs['anchors_l4']) and np.array_equal(mlvl[6].cpu().numpy(), gs['anchors_l6'])
+    img = synth.images(8, 512, 512, seed=61).cuda()
+    gtb, gtl = synth.random_gts(8, 512, 512, seed=62, gmin=1, gmax=3)
+    data = dict(img=img, img_metas=synth.metas(8, 512, 512), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    torch.cuda.synchronize()
+    lab = torch.cat(head_out[4], 1).cpu()
+    assert [f.shape[-1] for f in feat_out] == list(g['feat_sizes'])
+    assert [int(((l >= 0) & (l < 20)).sum()) for l in lab] == list(g['n_pos']) and [int(l.sum()) for l in lab] == list(g['labels_sum'])
+    fam = [float(f.float().abs().mean()) for f in feat_out]
+    assert np.allclose(fam, g['feat_absmean'], rtol=2e-2), (fam, g['feat_absmean'])
+    assert rel(feat_out[5][:2].float().cpu().numpy(), g['feat_l5']) < 3e-2 and rel(feat_out[6].float().cpu().numpy(), g['feat_l6']) < 3e-2
+    assert rel(head_out[1][5][:2].detach().float().cpu().numpy(), g['cls_l5']) < 3e-2
+    lv = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
+    assert np.allclose(lv, g['log_vars'], rtol=2e-2), (lv, g['log_vars'])
+    assert np.allclose(float(out['loss']), g['loss'], rtol=2e-2)
+    model.zero_grad()
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    pd = dict(model.named_parameters())
+    gn = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names']])
+    assert np.allclose(gn, g['grad_norms'], rtol=6e-2), (gn, g['grad_norms'])
+    lossL = model.train_step_L(prev, head_out, feat_out)
+    model.zero_grad()
+    lossL['loss'].backward()
+    torch.cuda.synchronize()
+    assert np.allclose(float(lossL['loss']), g['loss_L'], rtol=2e-2)
+    gnL = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names_L']])
+    assert np.allclose(gnL, g['grad_norms_L'], rtol=6e-2), (gnL, g['grad_norms_L'])
+
+
+def test_ssd512_scoring_vs_reference_golden(built512):
+    """seven-level scoring pass on planted head outputs: top-k order (through the gathered lambda), NMS keep / labels index-exact against
+    the reference, image scores within its Monte-Carlo spread (12 reseeded MC-500 runs)."""
+    from aod_meh_hua_amd import scoring
+    model, cfg = built512
+    head = model.bbox_head
+    g = np.load(os.path.join(G, 'ssd512_scoring.npz'))
+    cls_p, reg_p, L_p = synth.planted_heads_ssd(2, seed=int(g['planted_seed']), sizes=ossd.V512.SIZES, anchors=ossd.V512.NUM_ANCHORS)
+    mt = synth.metas(2, 512, 512, scale=1.25)
+    anchors = head.anchor_generator.grid_anchors([(s, s) for s in ossd.V512.SIZES], 'cuda')
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    det, unc, it = scoring.score_batch(head, [cl(c) for c in cls_p], [cl(r) for r in reg_p], anchors, [m['img_shape'] for m in mt],
+                                       [m['scale_factor'] for m in mt], head.test_cfg, rescale=True, with_nms=True, isUnc='Epistemic',
+                                       uPool='Entropy_NMS', uPool2=str(g['uPool2']), isEval=False, L_scores=[cl(l) for l in L_p],
+                                       _return_internals=True, batchIdx=0)
+    torch.cuda.synchronize()
+    cand = it['cand']
+    assert cand.level_start == [0, 1000, 2000, 3000, 3384, 3480, 3496, 3500]
+    assert np.array_equal(cand.lam.cpu().numpy(), g['lam'])                                   # identical top-k order + gather
+    assert np.allclose(cand.boxes.cpu().numpy(), g['boxes_cat'], rtol=1e-5, atol=1e-4)
+    num = it['num'].cpu().tolist()
+    for b in range(2):
+        gd = g[f'det{b}']
+        assert num[b] == gd.shape[0] and num[b] > 0
+        assert np.array_equal(it['keep'][b, :num[b]].cpu().numpy(), g[f'keep{b}'])
+        assert np.array_equal(it['labels'][b, :num[b]].cpu().numpy(), gd[:, 5].astype(np.int64))
+        assert np.allclose(it['dets'][b, :num[b]].cpu().numpy(), gd[:, :5], rtol=1e-5, atol=1e-4)
+    mu, sd = g['unc_runs'].mean(0), g['unc_runs'].std(0)
+    u = torch.as_tensor(unc).float().cpu().numpy()
+    assert (np.abs(u - mu) <= 4 * sd + 0.02 * mu).all(), (u, mu, sd)
