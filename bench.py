@@ -406,23 +406,41 @@ def main():
         assert hua['pairs_per_img'] > 0, 'degenerate HUA phase: no (candidate, object) pair in the scoring batch'
 
     prec = None
-    if rank == 0 and world == 1 and do_train and not args.no_precision_check:
-        # the same training iteration in the bf16x3 debug precision (operands split into bf16 head + tail, ~fp32 products on the same MFMA
-        # kernels; aod_meh_hua_amd/precision_x3.py, tests/test_gpu_precision_x3.py): what ~fp32-exact arithmetic would cost on this path
+    if rank == 0 and world == 1 and not args.no_precision_check:
+        # The SAME metric at the reference's arithmetic: both phases in the bf16x3 mode (every conv operand split into a bf16 head and tail,
+        # three MFMA products summed in the fp32 accumulator: ~fp32-exact products on the same implicit-GEMM / dgrad / wgrad kernels, fp32
+        # activations; aod_meh_hua_amd/precision_x3.py), captured into HIP graphs and replayed like the headline.  The golden train-step and
+        # scoring tests hold in this mode at 1e-4 (tests/test_gpu_precision_x3.py); the headline stays bf16.
         from aod_meh_hua_amd import functional as AF
         AF.set_precision('bf16x3')
+        g3 = s3 = None
         try:
-            ts = []
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                step(0, True, False, graph=False)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t1)
+            g3 = GraphedTrainStep(model, opt, opt_L, grad_sync=None, Labeled=True, Pseudo=False) if do_train else None
+            s3 = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'}) if do_score else None
+
+            def step3(i):
+                if g3 is not None:
+                    g3(data)
+                if s3 is not None:
+                    s3(pool['img'], pool['img_metas'], torch.arange(B, device=dev) + i * B)
+            step3(0)                                  # capture
+            step3(1)
+            torch.cuda.synchronize()
+            k3 = 4
+            t1 = time.perf_counter()
+            for i in range(k3):
+                step3(2 + i)
+            torch.cuda.synchronize()
+            d3 = (time.perf_counter() - t1) / k3
+            prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_value=round(imgs_per_step / world / d3, 1), bf16x3_ms_per_step=round(d3 * 1e3, 2),
+                        bf16x3_phases=args.mode, launch='hip-graph replay',
+                        note='same metric with ~fp32-exact conv products (operands split into bf16 head + tail, 3 MFMA products per term, fp32 '
+                             'activations): the reference-precision figure; residuals vs the fp32 reference fall from ~1e-2 to ~1e-5')
+        except Exception as e:      # noqa: BLE001
+            prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_value=None, error=f'{type(e).__name__}: {e}'[:300])
         finally:
             AF.set_precision('bf16')
-        prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_train_img_per_s=round(B / min(ts), 1),
-                    note='debug instrument (3x MFMA work, fp32 activations, torch glue): residuals vs the fp32 reference fall from ~1e-2 to ~1e-5')
+            del g3, s3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -97,3 +97,59 @@ def test_bf16x3_mode_collapses_the_deviation_from_the_reference_golden():
         assert e3 < 5e-3 and e3 < e16 / 5, (k, e3, e16)          # (the dropped tail x tail term and fp32 summation order remain)
     print('relative gradient error vs the fp32 oracle: bf16 worst', worst16, ' bf16x3 worst', worst3)
     assert worst3 < worst16 / 8
+
+
+def test_bf16x3_scoring_pass_matches_the_fp32_oracle_and_replays_as_a_graph():
+    """the reference-precision mode covers the SCORING phase too (forward, MEH forward, top-k, NMS, HUA) and both phases
+    replay as HIP graphs.  Full model on seeded weights with a trained-like (scaled) classification head: in bf16x3 the detections agree with
+    the fp32 CPU oracle to 1e-4 and the image scores to 1e-3 (Philox sampler on both sides); the bf16 product mode is printed beside it."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.graphs import GraphedScore
+    model, sd0 = _model()
+    H = W = 128
+    img = synth.images(2, H, W, seed=31)
+    torch.set_num_threads(8)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():       # calibrate on the ORACLE's logits: scale retina_cls until ~1 % of the anchors are foreground (> 0.3)
+        cls, _ = omodel.head_forward(sd, omodel.fpn(sd, omodel.backbone(sd, img)))
+        x = torch.cat([omodel.nhwc_flat(c, 20) for c in cls], 1)
+        lo, hi = 1.0, 1e5
+        for _ in range(40):
+            mid = (lo * hi) ** 0.5
+            lo, hi = (mid, hi) if float((torch.softmax(x * mid, -1).amax(-1) > 0.3).float().mean()) < 0.01 else (lo, mid)
+        k = float(np.float32(hi))
+        for key in ('bbox_head.retina_cls.weight', 'bbox_head.retina_cls.bias'):
+            sd[key] = sd[key] * k
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    mt = synth.metas(2, H, W)
+    o = omodel.score_images(sd, img, [m['img_shape'] for m in mt], [m['scale_factor'] for m in mt], sampler='philox', seed=20)
+    ref_unc = np.array(o['unc'])
+    assert (ref_unc > 0).all(), ref_unc
+    kw = dict(rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', scaleUnc=False,
+              showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
+    ids = torch.arange(2, device='cuda')
+    res = {}
+    for prec in ('bf16', 'bf16x3'):
+        AF.set_precision(prec)
+        try:
+            with torch.no_grad():
+                dets, unc = model(img=[img.cuda()], img_metas=[mt], return_loss=False, image_ids=ids, **kw)
+                gs = GraphedScore(model, **kw)
+                _, unc_g1 = gs(img.cuda(), mt, ids)
+                _, unc_g2 = gs(img.cuda(), mt, ids)          # replay
+            torch.cuda.synchronize()
+        finally:
+            AF.set_precision('bf16')
+        u = torch.as_tensor(unc).float().cpu().numpy()
+        assert np.array_equal(u, torch.as_tensor(unc_g1).float().cpu().numpy()) and np.array_equal(u, torch.as_tensor(unc_g2).float().cpu().numpy())
+        res[prec] = (u, dets)
+        print(prec, 'unc', u, 'oracle', ref_unc, 'rel dev', np.abs(u - ref_unc) / ref_unc)
+    u3, d3 = res['bf16x3']
+    assert np.allclose(u3, ref_unc, rtol=1e-3), (u3, ref_unc)
+    for b in range(2):
+        od, olab, _ = o['dets'][b]
+        gd, glab = d3[b]
+        gd, glab = torch.as_tensor(gd).float().cpu(), torch.as_tensor(glab).cpu()
+        assert gd.shape[0] == od.shape[0] and torch.equal(glab.long(), olab.long())                  # same detections, same order
+        assert np.allclose(gd.numpy(), od.numpy(), rtol=1e-4, atol=1e-3)
