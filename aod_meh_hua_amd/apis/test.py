@@ -51,6 +51,34 @@ def _unwrap(x):
     return x.data if isinstance(x, DataContainer) else x
 
 
+def _shard_batches(dataset, lo, hi, bs, collate, workers):
+    """(idxs, collated batch) over this rank's block [lo, hi) of the pool.  workers > 0: worker processes decode / resize / normalise the
+    images ahead of the GPU (the reference builds its pool loader with cfg.data.workers_per_gpu workers, tools/train_RetinaNet.py:224-225,
+    mmdet/datasets/builder.py:76-139) into PINNED host memory, `prefetch` batches deep, so that the H2D copy of batch i + 1 and the host work
+    of batches i + 2.. overlap the scoring graph of batch i; at ~4 000 images/s of GPU rate a single-process PIL decode + resize would bound
+    the pool loop by more than 10x.  workers == 0: the synchronous loop (same batches, same order)."""
+    starts = list(range(lo, hi, bs))
+    if workers <= 0 or not starts:
+        for s in starts:
+            idxs = list(range(s, min(s + bs, hi)))
+            yield idxs, collate([dataset[i] for i in idxs])
+        return
+    from torch.utils.data import DataLoader, Subset
+    dl = DataLoader(Subset(dataset, range(lo, hi)), batch_size=bs, shuffle=False, num_workers=workers, collate_fn=collate, pin_memory=False,
+                    prefetch_factor=4, drop_last=False)
+    for s, batch in zip(starts, dl):
+        yield list(range(s, min(s + bs, hi))), batch
+
+
+def _pin(x):
+    """pinned copy of a host tensor (asynchronous H2D source); DataContainers / lists are walked"""
+    if torch.is_tensor(x):
+        return x.pin_memory() if x.device.type == 'cpu' and not x.is_pinned() else x
+    if isinstance(x, (list, tuple)):
+        return type(x)(_pin(v) for v in x)
+    return x
+
+
 def single_gpu_uncertainty(model, data_loader, **kwargs):
     """test.py:90-135, sharded.  Returns a [N] fp32 tensor (N = len(dataset)) identical on every rank."""
     model.eval()
@@ -81,16 +109,19 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
                 gscore = cache[key] = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
     dev = next(model.parameters()).device
     device_side = hasattr(dataset, 'device_batch')       # images produced on the device (datasets.DevicePhiloxPool): no host collate / H2D
-    all_ids = torch.arange(lo, max(hi, lo), dtype=torch.int64).to(dev) if device_side else None
-    for s in range(lo, hi, bs):
-        idxs = list(range(s, min(s + bs, hi)))
+    all_ids = torch.arange(lo, max(hi, lo), dtype=torch.int64).to(dev)
+    workers = int(os.environ.get('AOD_POOL_WORKERS', getattr(data_loader, 'num_workers', 0) or 0))
+    batches = ((list(range(s, min(s + bs, hi))), None) for s in range(lo, hi, bs)) if device_side else \
+        _shard_batches(dataset, lo, hi, bs, collate, workers)
+    for idxs, data in batches:
+        s = idxs[0]
+        image_ids = all_ids[s - lo:s - lo + len(idxs)]
         if device_side:
-            image_ids = all_ids[s - lo:s - lo + len(idxs)]
             data = dataset.device_batch(idxs, dev, image_ids=image_ids)
         else:
-            data = collate([dataset[i] for i in idxs])
             data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
-            image_ids = torch.tensor(idxs, dtype=torch.int64).to(dev, non_blocking=True)
+            if dev.type == 'cuda':
+                data['img'] = _pin(data['img'])
         out = None
         if gscore is not None and isinstance(data['img'], (list, tuple)) and len(data['img']) == 1:
             out = gscore.maybe(data['img'][0], data['img_metas'][0], image_ids)

@@ -52,3 +52,26 @@ def test_voc_batches_through_train_score_eval(voc):  # noqa: F811
     res = single_gpu_test(model, vdl, isUnc=False)
     ev = val.evaluate(res, metric='mAP', logger='silent')
     assert len(res) == len(val) and 0.0 <= ev['mAP'] <= 1.0
+
+
+def test_pool_loader_with_worker_prefetch_scores_like_the_synchronous_loop(voc):  # noqa: F811
+    """apis/test.py _shard_batches: worker processes + pinned prefetch (the reference's pool loader has cfg.data.workers_per_gpu workers,
+    tools/train_RetinaNet.py:224-225) must hand the model the same batches in the same order as the synchronous loop."""
+    from aod_meh_hua_amd.apis.test import single_gpu_uncertainty
+    from aod_meh_hua_amd.datasets import build_dataloader, build_dataset
+    from aod_meh_hua_amd.mmcv_lite import Config, MMDataParallel
+    from aod_meh_hua_amd.models import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/_base_/Config_RetinaNet.py'))
+    cfg.model.backbone.pop('init_cfg')
+    model = build_detector(cfg.model)
+    model.load_state_dict(omodel.seeded_state_dict(cls_bias=1.0), strict=True)
+    model = MMDataParallel(model.cuda())
+    ann = voc + 'ImageSets/Main/trainval.txt'
+    noflip = [dict(t, flip_ratio=0.0) if t['type'] == 'RandomFlip' else t for t in TRAIN]
+    pool = build_dataset(dict(type='VOCDataset', ann_file=[ann] * 4, img_prefix=[voc] * 4, pipeline=noflip), dict(test_mode=False))
+    kw = dict(isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False)
+    outs = []
+    for workers in (0, 2):
+        pdl = build_dataloader(pool, samples_per_gpu=2, workers_per_gpu=workers, dist=False, shuffle=False)
+        outs.append(single_gpu_uncertainty(model, pdl, **kw).cpu())
+    assert outs[0].shape == (len(pool),) and torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

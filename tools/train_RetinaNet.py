@@ -109,7 +109,9 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
     timestamp = time.strftime('%Y%m%d_%H%M%S', time.localtime())
     logger = get_root_logger(log_file=osp.join(cfg.work_dir, f'{timestamp}.log'), log_level=cfg.log_level)
     meta = dict(exp_name=osp.basename(args.config))
-    cfg.data.workers_per_gpu = 0
+    # train_RetinaNet.py:139-141: 8 loader workers when started from a shell, else 0; here: 8 for real image data (AOD_WORKERS overrides), 0 for
+    # the synthetic pool (its samples are generated in-process)
+    cfg.data.workers_per_gpu = 0 if args.synthetic else int(os.environ.get('AOD_WORKERS', 8))
 
     X_L, X_U, X_all, all_anns = get_X_L_0_prev(cfg)
     if rank == 0:
@@ -164,7 +166,8 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
             torch.save(model.state_dict(), f'{cfg.save_dir}/{cfg_name}_Cycle{cycle}_Epoch{cfg.runner.max_epochs}_mycode.pth')
         if cycle != cfg.cycles[-1]:
             dataset_al = build_dataset(cfg.data.test)
-            data_loader = build_dataloader(dataset_al, samples_per_gpu=cfg.data.samples_per_gpu, workers_per_gpu=0, dist=False, shuffle=False)
+            data_loader = build_dataloader(dataset_al, samples_per_gpu=cfg.data.samples_per_gpu, workers_per_gpu=cfg.data.workers_per_gpu,
+                                           dist=False, shuffle=False)
             poolModel = MMDataParallel(model, device_ids=cfg.gpu_ids)
             with torch.no_grad():
                 uncertainty = calculate_uncertainty(cfg, poolModel, data_loader, return_box=False, showNMS=False, saveUnc=False,
