@@ -29,6 +29,15 @@ def _pin_caches():
     return (dict(ho._ROW_TABLES), dict(ho._DW), dict(ho._SLABS), list(AF.PREP.items.values()), AF.PREP.table, dict(scoring._META))
 
 
+def _low_memory(dev, frac=0.25):
+    """less than `frac` of the device memory is free (captured graphs keep their activations in private pools)"""
+    try:
+        free, total = torch.cuda.mem_get_info(dev)
+        return free < frac * total
+    except Exception:      # noqa: BLE001
+        return False
+
+
 def _unwrap(model):
     return model.module if hasattr(model, 'module') else model
 
@@ -66,7 +75,21 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------ input staging
     def _signature(self, d):
+        """(batch tensor shape, per-image pad shapes).  Heads that read their valid-anchor flags from the static buffer
+        (L_AnchorHead.get_targets_batch) make the second part irrelevant: __call__ then matches on the tensor shape alone, so the
+        aspect-ratio-grouped keep-ratio VOC batches -- a dozen padded shapes, thousands of per-image shape combinations -- replay."""
         return (tuple(d['img'].shape), tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in d['img_metas']))
+
+    def _lookup(self, sig):
+        ent = self.cache.pop(sig, None)
+        if ent is None:
+            for k in list(self.cache):
+                if k[0] == sig[0] and self.cache[k]['static'].get('valid_fn') is not None:
+                    return self.cache.pop(k)
+        return ent
+
+    def _known(self, sig):
+        return sig in self.cache or any(k[0] == sig[0] and e['static'].get('valid_fn') is not None for k, e in self.cache.items())
 
     def _load(self, d):
         st = self.cur['static']
@@ -85,6 +108,8 @@ class GraphedTrainStep:
                 hg[b, :n] = bb.detach().float().cpu() if bb.device.type != 'cpu' else bb.float()
                 hl[b, :n] = ll.detach().long().cpu() if ll.device.type != 'cpu' else ll.long()
         st['gts'].copy_(hg, non_blocking=True), st['counts'].copy_(hc, non_blocking=True), st['labs'].copy_(hl, non_blocking=True)
+        if st.get('valid_fn') is not None:            # valid-anchor flags of THIS batch's per-image pad shapes (cached per shape on the device)
+            st['valid'].copy_(st['valid_fn'](d['img_metas']), non_blocking=True)
 
     def _alloc(self, d):
         B, dev, G = d['img'].shape[0], self.dev, self.gmax
@@ -95,7 +120,9 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------ the segments of run_iter
     def _seg_a(self, cuts=False):
         st = self.cur['static']
-        data = dict(img=st['img'], img_metas=st['metas'], gt_bboxes=PackedGT((st['gts'], st['counts'], st['labs'])), gt_labels=None)
+        gt = PackedGT((st['gts'], st['counts'], st['labs']))
+        gt.static = st                                  # (the head parks its valid-anchor flags here: a static input like the boxes)
+        data = dict(img=st['img'], img_metas=st['metas'], gt_bboxes=gt, gt_labels=None)
         if cuts:            # data parallelism: the backward pass falls into segments at the backbone's stage outputs (functional.grad_cuts)
             with AF.grad_cuts() as cl:
                 out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
@@ -272,7 +299,7 @@ class GraphedTrainStep:
         nothing), so ranks need not agree and no per-iteration flag all-reduce / host sync is paid."""
         d = _plain(data_batch, self.dev)
         sig = self._signature(d)
-        want = sig in self.cache or sig == self.last_sig
+        want = self._known(sig) or sig[0] == (self.last_sig or (None,))[0]
         self.last_sig = sig
         if not want:
             return None
@@ -281,10 +308,14 @@ class GraphedTrainStep:
     def __call__(self, data_batch):
         d = _plain(data_batch, self.dev)
         sig = self._signature(d)
-        ent = self.cache.pop(sig, None)
+        ent = self._lookup(sig)
         if ent is None:
-            if len(self.cache) >= self.MAX_GRAPHS:
-                self.cache.pop(next(iter(self.cache)))          # least recently used
+            # least recently used graphs go when the cache is full -- or when their private memory pools leave too little room for one more
+            while self.cache and (len(self.cache) >= self.MAX_GRAPHS or _low_memory(self.dev)):
+                self.cache.pop(next(iter(self.cache)))
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
             ent = self._build(d)
         self.cache[sig] = self.cur = ent
         self._load(d)
@@ -306,7 +337,10 @@ class GraphedTrainStep:
 
 
 class GraphedScore:
-    """One HUA scoring batch: model(img=[img], img_metas=[metas], image_ids=ids, **kw) under no_grad -> unc [B] (a copy)."""
+    """One HUA scoring batch: model(img=[img], img_metas=[metas], image_ids=ids, **kw) under no_grad -> unc [B] (a copy).  One captured
+    graph per batch tensor shape (LRU): the per-image sizes and scale factors the decode step needs are STATIC device buffers refreshed
+    per call (scoring.static_meta), so keep-ratio pool batches of one padded shape share a graph."""
+    MAX_GRAPHS = 16
 
     def __init__(self, model, warmup=2, **score_kwargs):
         import weakref
@@ -314,7 +348,7 @@ class GraphedScore:
         # cycle that keeps a dead cycle's graph memory pool + static image buffers alive until the cyclic collector happens to run
         self._model = weakref.ref(_unwrap(model))
         self.kw, self.warmup = score_kwargs, warmup
-        self.sig, self.graph = None, None
+        self.cache, self.pending = {}, None          # shape -> entry (insertion order = LRU); shape seen once
         self.dev = next(_unwrap(model).parameters()).device
 
     @property
@@ -324,51 +358,57 @@ class GraphedScore:
             raise RuntimeError('GraphedScore outlived its model')
         return m
 
-    def _run(self):
-        with torch.no_grad():
-            res = self.module(img=[self.img], img_metas=[self.metas], return_loss=False, image_ids=self.ids, **self.kw)
-        self.out = res
-
-    @staticmethod
-    def _signature(img, img_metas):
-        return (tuple(img.shape), tuple((tuple(m['img_shape']), tuple(float(v) for v in torch.as_tensor(m['scale_factor']).reshape(-1)))
-                                        for m in img_metas))
+    def _run(self, ent):
+        from . import scoring
+        with torch.no_grad(), scoring.static_meta(ent['hw'], ent['sc']):
+            ent['out'] = self.module(img=[ent['img']], img_metas=[ent['metas']], return_loss=False, image_ids=ent['ids'], **self.kw)
 
     def maybe(self, img, img_metas, image_ids):
-        """Replay if (shape, image sizes, scale factors) repeat from the previous batch, else None (caller scores eagerly)."""
-        sig = self._signature(img, img_metas)
-        if sig != self.sig and sig != getattr(self, 'pending', None):
-            self.pending = sig
+        """Replay if this batch shape is captured, capture if it repeats the previous batch's shape, else None (caller scores eagerly)."""
+        shape = tuple(img.shape)
+        if shape not in self.cache and shape != self.pending:
+            self.pending = shape
             return None
         return self(img, img_metas, image_ids)
 
+    def _fill(self, ent, img, img_metas, image_ids):
+        from . import scoring
+        hw, sc = scoring.meta_values([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas])
+        ent['img'].copy_(img, non_blocking=True)
+        ent['ids'].copy_(image_ids, non_blocking=True)
+        ent['hw'].copy_(hw.pin_memory(), non_blocking=True), ent['sc'].copy_(sc.pin_memory(), non_blocking=True)
+
     def __call__(self, img, img_metas, image_ids):
-        sig = self._signature(img, img_metas)
-        if sig != self.sig:
-            self.graph = None
-            self.img = torch.empty(tuple(img.shape), dtype=torch.float32, device=self.dev)
-            self.ids = torch.zeros(img.shape[0], dtype=torch.int64, device=self.dev)
-            self.metas = [dict(m) for m in img_metas]
-            self.img.copy_(img), self.ids.copy_(image_ids)
+        shape = tuple(img.shape)
+        ent = self.cache.pop(shape, None)
+        if ent is None:
+            while self.cache and (len(self.cache) >= self.MAX_GRAPHS or _low_memory(self.dev)):
+                self.cache.pop(next(iter(self.cache)))
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+            B = img.shape[0]
+            ent = dict(img=torch.empty(shape, dtype=torch.float32, device=self.dev), ids=torch.zeros(B, dtype=torch.int64, device=self.dev),
+                       hw=torch.zeros(B, 2, device=self.dev), sc=torch.ones(B, 4, device=self.dev), metas=[dict(m) for m in img_metas])
+            self._fill(ent, img, img_metas, image_ids)
             self.module.eval()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(self.warmup):
-                    self._run()
+                    self._run(ent)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             ho.reset_zero_arena()
             AF.PREP.refresh_if_stale()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-                self._run()
+            ent['graph'] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent['graph'], capture_error_mode='thread_local'):
+                self._run(ent)
             ho.reset_zero_arena()
-            self._keep = _pin_caches()
-            self.sig = sig
-        self.img.copy_(img, non_blocking=True)
-        self.ids.copy_(image_ids, non_blocking=True)
+            ent['keep'] = _pin_caches()
+        self.cache[shape] = ent
+        self._fill(ent, img, img_metas, image_ids)
         AF.PREP.refresh_if_stale()        # e.g. a training replay or a checkpoint load since the last scoring batch
-        self.graph.replay()
-        unc = self.out[1]
-        return self.out[0], (unc.clone() if torch.is_tensor(unc) else unc)
+        ent['graph'].replay()
+        unc = ent['out'][1]
+        return ent['out'][0], (unc.clone() if torch.is_tensor(unc) else unc)

@@ -114,6 +114,16 @@ class L_AnchorHead(BaseModule):
         if key not in cache:
             cache[key] = all(bool(f.all()) for f in flags)          # one-time host check per shape
         valid = None if cache[key] else torch.stack(flags).to(torch.uint8)
+        static = getattr(gt_bboxes, 'static', None)
+        if static is not None:
+            # HIP-graph replay (graphs.GraphedTrainStep): the flags live in a STATIC device buffer that is refreshed from each batch's
+            # pad shapes before a replay, so one captured graph serves every batch of this tensor shape (keep-ratio VOC batches differ
+            # in their per-image pad shapes, not in the padded batch shape)
+            if static.get('valid') is None:
+                static['valid'] = torch.stack(flags).to(torch.uint8).contiguous()
+                static['valid_fn'] = lambda metas: torch.stack(
+                    [ag.flat_valid_flags(featmap_sizes, tuple(int(v) for v in m['pad_shape'][:2]), device) for m in metas]).to(torch.uint8)
+            valid = static['valid']
         gts, counts, labs = pack_gts(gt_bboxes, gt_labels, device)
         starts = [0]
         for n in nla:

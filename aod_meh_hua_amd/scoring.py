@@ -41,11 +41,38 @@ def nhwc_view(x, c):
 
 
 _META = {}
+_META_STATIC = None      # (hw [B,2], sc [B,4]) static device buffers of a captured scoring graph (graphs.GraphedScore refreshes them per batch)
+
+
+class static_meta:
+    """inside this context the image sizes / scale factors of a scoring batch are read from the given STATIC device buffers instead of
+    value-keyed cached tensors: a captured scoring graph then serves every batch of its tensor shape, whatever the per-image sizes are"""
+
+    def __init__(self, hw, sc):
+        self.new = (hw, sc)
+
+    def __enter__(self):
+        global _META_STATIC
+        self.prev, _META_STATIC = _META_STATIC, self.new
+
+    def __exit__(self, *exc):
+        global _META_STATIC
+        _META_STATIC = self.prev
+        return False
+
+
+def meta_values(img_shapes, scale_factors):
+    """host rows ([B,2] sizes, [B,4] scale factors) as float32 tensors: what a static-meta graph copies into its buffers"""
+    hw = torch.tensor([[float(s[0]), float(s[1])] for s in img_shapes], dtype=torch.float32)
+    sc = torch.tensor(np.stack([np.asarray(s, np.float32).reshape(-1)[:4] for s in scale_factors]), dtype=torch.float32)
+    return hw, sc
 
 
 def _meta_tensors(img_shapes, scale_factors, dev):
     """[B,2] image sizes and [B,4] scale factors on the device, cached by value: the pool loop re-uses a handful of shapes, and an
     H2D copy per batch would also break HIP-graph capture of the scoring pass."""
+    if _META_STATIC is not None:
+        return _META_STATIC[0], (_META_STATIC[1] if scale_factors is not None else None)
     key = (tuple((float(s[0]), float(s[1])) for s in img_shapes),
            None if scale_factors is None else tuple(tuple(float(v) for v in np.asarray(s, np.float32).reshape(-1)[:4]) for s in scale_factors), str(dev))
     hit = _META.get(key)

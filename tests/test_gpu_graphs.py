@@ -129,3 +129,56 @@ def test_capture_applies_the_batch_once_and_eager_iterations_may_interleave():
     new = {k: v.detach().float().cpu() for k, v in model2.state_dict().items()}
     worst = max(float((new[k] - ref_sd[k]).abs().max() / (ref_sd[k].abs().max() + 1e-12)) for k in ref_sd if ref_sd[k].is_floating_point())
     assert worst < 5e-3, worst
+
+
+def _ragged_batch(seed, shapes, H=128, W=160):
+    """two images zero-padded into one [2, 3, H, W] tensor with their own img / pad shapes and scale factors (what mmcv-style collate
+    hands over for keep-ratio data)"""
+    B = len(shapes)
+    img = torch.zeros(B, 3, H, W)
+    metas, gtb, gtl = [], [], []
+    for b, (h, w, ph, pw, sf) in enumerate(shapes):
+        img[b, :, :h, :w] = synth.images(1, h, w, seed=seed + b)[0]
+        metas.append(dict(img_shape=(h, w, 3), pad_shape=(ph, pw, 3), ori_shape=(int(h / sf), int(w / sf), 3),
+                          scale_factor=np.array([sf] * 4, np.float32), flip=False, flip_direction=None))
+        bb, ll = synth.random_gts(1, h, w, seed=seed + 10 + b, gmin=1, gmax=3)
+        gtb.append(bb[0]), gtl.append(ll[0])
+    return dict(img=img.cuda(), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+
+
+def test_one_graph_serves_batches_that_differ_only_in_their_per_image_shapes():
+    """keep-ratio VOC batches of one padded tensor shape differ in their per-image pad shapes (valid-anchor flags), image
+    sizes and scale factors (box clipping / rescaling in the scoring pass).  Those are STATIC device inputs of the captured graphs
+    (L_AnchorHead.get_targets_batch, scoring.static_meta): the second batch REPLAYS the graph captured on the first and must equal eager."""
+    from aod_meh_hua_amd.graphs import GraphedScore, GraphedTrainStep
+    a = _ragged_batch(71, [(128, 160, 128, 160, 1.0), (128, 160, 128, 160, 1.0)])
+    b = _ragged_batch(75, [(120, 150, 128, 160, 1.25), (90, 100, 96, 128, 0.8)])
+    model, opt, opt_L = _build()
+    ref = [_eager_iter(model, opt, opt_L, d) for d in (a, b)]
+    ref_sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    model2, opt2, opt_L2 = _build()
+    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=1, Labeled=True, Pseudo=False)
+    got = []
+    for d in (a, b):
+        o = gs(d)
+        got.append((float(o['loss']), float(o['log_vars']['loss_L'])))
+    torch.cuda.synchronize()
+    assert len(gs.cache) == 1, 'the second batch must replay the first batch\'s graph'
+    assert np.allclose(np.array(got), np.array(ref), rtol=3e-3), (got, ref)
+    new = {k: v.detach().float().cpu() for k, v in model2.state_dict().items()}
+    worst = max(float((new[k] - ref_sd[k]).abs().max() / (ref_sd[k].abs().max() + 1e-12)) for k in ref_sd if ref_sd[k].is_floating_point())
+    assert worst < 5e-3, worst
+    # scoring: image sizes / scale factors are static inputs too
+    model.eval()
+    kw = dict(rescale=True, isEval=False, isUnc='Epistemic', uPool='Entropy_NMS', uPool2='objectSum_scaleMax_classSum', scaleUnc=False,
+              showNMS=False, saveUnc=False, saveMaxConf=False, clsW=False, batchIdx=0)
+    with torch.no_grad():            # trained-like head so that the scores are not all zero
+        model.bbox_head.retina_cls.weight.mul_(60.0), model.bbox_head.retina_cls.bias.mul_(60.0)
+    gsc = GraphedScore(model, **kw)
+    for d, base in ((a, 0), (b, 2), (a, 4)):
+        ids = torch.tensor([base, base + 1], device='cuda')
+        with torch.no_grad():
+            _, unc_e = model(img=[d['img']], img_metas=[d['img_metas']], return_loss=False, image_ids=ids, **kw)
+        _, unc_g = gsc(d['img'], d['img_metas'], ids)
+        assert torch.equal(torch.as_tensor(unc_e).float().cpu(), unc_g.float().cpu()), (base, unc_e, unc_g)
+    assert len(gsc.cache) == 1 and float(unc_g.abs().sum()) > 0
