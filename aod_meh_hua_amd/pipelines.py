@@ -64,14 +64,35 @@ def rescale_size(old_size, scale):
     return int(w * float(sf) + 0.5), int(h * float(sf) + 0.5)
 
 
+def _lin_coords(n_in, n_out):
+    """source index pair and weight of every destination index: half-pixel centres, clamped at the borders (cv2.INTER_LINEAR / torch
+    align_corners=False: fx = (dx + 0.5) * scale - 0.5, sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= n - 1 -> (n - 1, 0))"""
+    x = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * np.float32(n_in / n_out) - np.float32(0.5)
+    x = np.maximum(x, np.float32(0))
+    x0 = np.minimum(np.floor(x).astype(np.int64), n_in - 1)
+    x1 = np.minimum(x0 + 1, n_in - 1)
+    return x0, x1, (x - x0.astype(np.float32)).astype(np.float32)
+
+
 def imresize(img, size):
-    """mmcv.imresize(img, (w, h)), bilinear.  uint8 in -> uint8 out, float in -> float out."""
+    """mmcv.imresize(img, (w, h)), bilinear.  uint8 in -> uint8 out, float in -> float out.  Plain fp32 numpy arithmetic in a fixed order
+    (rows first, then columns): the same pixels in the main process and in a loader worker, whatever the thread count -- ATen's CPU
+    interpolation kernels round a handful of pixels differently with 1 and with 8 threads, which moved HUA scores of the affected images
+    by ~1 % between a synchronous and a worker-backed pool loader."""
     w, h = size
-    t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None].float()
-    o = torch.nn.functional.interpolate(t, size=(h, w), mode='bilinear', align_corners=False)[0].permute(1, 2, 0)
+    src = np.ascontiguousarray(img).astype(np.float32)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    y0, y1, wy = _lin_coords(src.shape[0], h)
+    x0, x1, wx = _lin_coords(src.shape[1], w)
+    wy, wx = wy[:, None, None], wx[None, :, None]
+    rows = src[y0] * (np.float32(1) - wy) + src[y1] * wy                     # [h, W_in, C]
+    out = rows[:, x0] * (np.float32(1) - wx) + rows[:, x1] * wx              # [h, w, C]
+    if img.ndim == 2:
+        out = out[:, :, 0]
     if img.dtype == np.uint8:
-        return o.round().clamp(0, 255).to(torch.uint8).numpy()
-    return o.numpy().astype(img.dtype)
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out.astype(img.dtype)
 
 
 def imrescale(img, scale):
