@@ -373,10 +373,11 @@ class GraphedScore:
 
     def _fill(self, ent, img, img_metas, image_ids):
         from . import scoring
-        hw, sc = scoring.meta_values([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas])
+        # (value-keyed device copies of the sizes / scale factors: a pool re-uses a handful of them; device-to-device into the static buffers)
+        hw, sc = scoring._meta_tensors([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas], self.dev)
         ent['img'].copy_(img, non_blocking=True)
         ent['ids'].copy_(image_ids, non_blocking=True)
-        ent['hw'].copy_(hw.pin_memory(), non_blocking=True), ent['sc'].copy_(sc.pin_memory(), non_blocking=True)
+        ent['hw'].copy_(hw, non_blocking=True), ent['sc'].copy_(sc, non_blocking=True)
 
     def __call__(self, img, img_metas, image_ids):
         shape = tuple(img.shape)
