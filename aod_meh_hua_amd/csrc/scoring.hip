@@ -503,280 +503,15 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   if (threadIdx.x == 0) s_nvalid = nvalid;
 }
 
-// ---------------------------------------------------------------- S4b: the same NMS with one workgroup per (image, CLASS)
-// The class offsets make the classes independent (a box only ever suppresses boxes of its own class), so the greedy pass runs per class
-// -- B x C workgroups instead of B -- and a merge takes the max_num best survivors of an image in the global key order.  Index-exact with
-// nms_kernel: same keys (score bits, then lower position in the flat valid list), same offset boxes (class * (max valid coordinate + 1),
-// added in fp32 before the IoU like mmcv's batched_nms), same IoU expression, and `keep` is again the position in the flat valid list.
-//   nms_prep_kernel   per image: rowbase[cand] = number of valid (candidate, class) entries in front of candidate `cand`, max coordinate
-//   nms_class_kernel  per (class, image): compaction of the class's valid candidates, tranche-wise sort, greedy pass -> <= max_num keys
-//   nms_merge_kernel  per image: the max_num largest keys of all classes, decoded back to (candidate, class) through rowbase
-struct NmsCArgs {
-  const float* boxes; const float* scores;
-  int n, C, max_num;
-  float score_thr, iou_thr;
-  int* rowbase;            // [B][n + 1]
-  float* maxc;             // [B]
-  int* vlist;              // [B][C][n] candidates of a class in candidate order
-  unsigned long long* kkey;// [B][C][max_num] kept keys per class
-  int* kcnt;               // [B][C]
-  float* dets; long long* det_labels; long long* keep; int* num_det;
-};
-
-__global__ __launch_bounds__(TB) void nms_prep_kernel(const NmsCArgs p) {
-  __shared__ int s_warp[TB / 64];
-  __shared__ float s_maxc;
-  const int b = blockIdx.x;
-  const float* bx = p.boxes + (long long)b * p.n * 4;
-  const float* sc = p.scores + (long long)b * p.n * (p.C + 1);
-  int* rb = p.rowbase + (long long)b * (p.n + 1);
-  if (threadIdx.x == 0) s_maxc = -INFINITY;
-  __syncthreads();
-  int base = 0;
-  float mymax = -INFINITY;
-  for (int c0 = 0; c0 < p.n; c0 += TB) {
-    const int cand = c0 + threadIdx.x;
-    int cnt = 0;
-    if (cand < p.n) {
-      const float* row = sc + (long long)cand * (p.C + 1);
-      for (int c = 0; c < p.C; ++c) cnt += row[c] > p.score_thr ? 1 : 0;
-      if (cnt) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
-        mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
-      }
-    }
-    int tot;
-    const int pos = base + block_excl_scan(cnt, s_warp, tot);
-    if (cand < p.n) rb[cand] = pos;
-    base += tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) rb[p.n] = base;
-  mymax = wave_max(mymax);
-  if ((threadIdx.x & 63) == 0 && mymax > -INFINITY) atomicMax((int*)&s_maxc, __float_as_int(mymax));      // coords >= 0 after clipping
-  __syncthreads();
-  if (threadIdx.x == 0) p.maxc[b] = s_maxc;
-}
-
-__global__ __launch_bounds__(TB) void nms_class_kernel(const NmsCArgs p) {
-  __shared__ int hist[264];
-  __shared__ int s_warp[TB / 64];
-  __shared__ unsigned long long keys[TR];
-  __shared__ float kbox[256][4];
-  __shared__ float karea[256];
-  __shared__ int s_nkept;
-  const int cl = blockIdx.x, b = blockIdx.y;
-  const int C = p.C, n = p.n, max_num = p.max_num;
-  const float* bx = p.boxes + (long long)b * n * 4;
-  const float* sc = p.scores + (long long)b * n * (C + 1);
-  const int* rb = p.rowbase + (long long)b * (n + 1);
-  int* vl = p.vlist + ((long long)b * C + cl) * n;
-  unsigned long long* kk = p.kkey + ((long long)b * C + cl) * max_num;
-  if (threadIdx.x == 0) s_nkept = 0;
-  __syncthreads();
-  // 1. this class's valid candidates, in candidate order
-  int base = 0;
-  for (int c0 = 0; c0 < n; c0 += TB) {
-    const int cand = c0 + threadIdx.x;
-    const bool v = cand < n && sc[(long long)cand * (C + 1) + cl] > p.score_thr;
-    int tot;
-    const int pos = base + block_excl_scan(v ? 1 : 0, s_warp, tot);
-    if (v) vl[pos] = cand;
-    base += tot;
-    __syncthreads();
-  }
-  const int nvalid = base;
-  const float off = (float)cl * (p.maxc[b] + 1.f);
-  // key of the i-th valid candidate of the class: its position in the image's flat valid list = rowbase + valid classes in front of cl
-  auto key = [&](long long i) {
-    const int cand = vl[i];
-    const float* row = sc + (long long)cand * (C + 1);
-    int pidx = rb[cand];
-    for (int c = 0; c < cl; ++c) pidx += row[c] > p.score_thr ? 1 : 0;
-    return ((unsigned long long)__float_as_uint(row[cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pidx);
-  };
-  unsigned long long upper = ~0ull;
-  int done = 0;
-  while (done < nvalid) {
-    if (s_nkept >= max_num) break;
-    const int take = min(TR, nvalid - done);
-    int np2 = 64;
-    while (np2 < take) np2 <<= 1;
-    unsigned long long kth = 0ull;
-    if (nvalid - done > TR) kth = radix_select_kth(key, nvalid, upper, take, hist);      // (one tranche holds a whole class almost always)
-    for (int i = threadIdx.x; i < np2; i += TB) keys[i] = 0ull;
-    __syncthreads();
-    if (threadIdx.x == 0) hist[262] = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < nvalid; c0 += TB) {          // any order: the sort follows
-      const int i = c0 + threadIdx.x;
-      unsigned long long kv = 0ull;
-      bool t = false;
-      if (i < nvalid) { kv = key(i); t = kv < upper && kv >= kth; }
-      const unsigned long long m = __ballot(t);
-      if (m) {
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-        int b0 = 0;
-        if (lane == leader) b0 = atomicAdd(&hist[262], __popcll(m));
-        b0 = __shfl(b0, leader, 64);
-        if (t) keys[b0 + __popcll(m & ((1ull << lane) - 1ull))] = kv;
-      }
-    }
-    bitonic_desc(keys, np2);
-    // greedy scan by wave 0, 64 candidates per round (every kept box has this class: no class test)
-    if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-      int nk = s_nkept;
-      for (int c0 = 0; c0 < take; c0 += 64) {
-        if (nk >= max_num) break;
-        const int i = c0 + lane;
-        const bool act = i < take;
-        float q[4] = {0, 0, 0, 0}, area = 0.f;
-        unsigned long long kv = 0ull;
-        if (act) {
-          kv = keys[i];
-          const int pidx = (int)(0xffffffffu - (unsigned)(kv & 0xffffffffull));
-          // candidate of this entry: the last cand with rowbase[cand] <= pidx (binary search; rowbase is non-decreasing)
-          int lo = 0, hi = n - 1;
-          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rb[mid] <= pidx) lo = mid; else hi = mid - 1; }
-          const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)lo * 4);
-          for (int u = 0; u < 4; ++u) q[u] = r[u] + off;
-          area = (q[2] - q[0]) * (q[3] - q[1]);
-        }
-        bool sup = !act;
-        for (int j = 0; j < nk && !sup; ++j) {
-          const float w = fmaxf(0.f, fminf(q[2], kbox[j][2]) - fmaxf(q[0], kbox[j][0]));
-          const float h = fmaxf(0.f, fminf(q[3], kbox[j][3]) - fmaxf(q[1], kbox[j][1]));
-          const float inter = w * h;
-          const float ovr = inter / (karea[j] + area - inter);
-          if (ovr > p.iou_thr) sup = true;
-        }
-        for (int s2 = 0; s2 < 64; ++s2) {
-          const bool s_keep = __shfl((int)(!sup), s2, 64) != 0;
-          if (!s_keep) continue;                    // uniform
-          if (nk >= max_num) break;                 // uniform
-          const float b0 = __shfl(q[0], s2, 64), b1 = __shfl(q[1], s2, 64), b2 = __shfl(q[2], s2, 64), b3 = __shfl(q[3], s2, 64);
-          const float ar = __shfl(area, s2, 64);
-          if (lane == s2) {
-            kbox[nk][0] = q[0]; kbox[nk][1] = q[1]; kbox[nk][2] = q[2]; kbox[nk][3] = q[3]; karea[nk] = area;
-            kk[nk] = kv;
-          }
-          ++nk;
-          if (lane > s2 && !sup) {
-            const float w = fmaxf(0.f, fminf(q[2], b2) - fmaxf(q[0], b0));
-            const float h = fmaxf(0.f, fminf(q[3], b3) - fmaxf(q[1], b1));
-            const float inter = w * h;
-            const float ovr = inter / (ar + area - inter);
-            if (ovr > p.iou_thr) sup = true;
-          }
-        }
-      }
-      if (lane == 0) s_nkept = nk;
-    }
-    __syncthreads();
-    upper = kth;
-    done += take;
-    if (kth == 0ull) break;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) p.kcnt[(long long)b * C + cl] = s_nkept;
-}
-
-__global__ __launch_bounds__(TB) void nms_merge_kernel(const NmsCArgs p) {
-  __shared__ int hist[264];
-  __shared__ unsigned long long keys[256];
-  const int b = blockIdx.x;
-  const int C = p.C, n = p.n, max_num = p.max_num;
-  const float* bx = p.boxes + (long long)b * n * 4;
-  const float* sc = p.scores + (long long)b * n * (C + 1);
-  const int* rb = p.rowbase + (long long)b * (n + 1);
-  const unsigned long long* kk = p.kkey + (long long)b * C * max_num;
-  const int* kc = p.kcnt + (long long)b * C;
-  // flat index space e = class * max_num + j; entries beyond a class's count read as key 0
-  const long long E = (long long)C * max_num;
-  auto key = [&](long long e) {
-    const int c = (int)(e / max_num), j = (int)(e - (long long)c * max_num);
-    return j < kc[c] ? kk[e] : 0ull;
-  };
-  // total survivors
-  __shared__ int s_tot;
-  if (threadIdx.x == 0) { int t = 0; for (int c = 0; c < C; ++c) t += kc[c]; s_tot = t; }
-  __syncthreads();
-  const int total = s_tot;
-  const int nk = min(total, max_num);
-  unsigned long long kth = 1ull;                          // (keys of real entries are > 0: a score above the threshold has non-zero bits)
-  if (total > max_num) kth = radix_select_kth(key, E, ~0ull, max_num, hist);
-  for (int i = threadIdx.x; i < 256; i += TB) keys[i] = 0ull;
-  __syncthreads();
-  if (threadIdx.x == 0) hist[262] = 0;
-  __syncthreads();
-  for (long long e0 = 0; e0 < E; e0 += TB) {
-    const long long e = e0 + threadIdx.x;
-    unsigned long long kv = 0ull;
-    bool t = false;
-    if (e < E) { kv = key(e); t = kv >= kth && kv != 0ull; }
-    const unsigned long long m = __ballot(t);
-    if (m) {
-      const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-      int b0 = 0;
-      if (lane == leader) b0 = atomicAdd(&hist[262], __popcll(m));
-      b0 = __shfl(b0, leader, 64);
-      if (t) keys[b0 + __popcll(m & ((1ull << lane) - 1ull))] = kv;
-    }
-  }
-  bitonic_desc(keys, 256);
-  if ((int)threadIdx.x < nk) {
-    const unsigned long long kv = keys[threadIdx.x];
-    const int pidx = (int)(0xffffffffu - (unsigned)(kv & 0xffffffffull));
-    int lo = 0, hi = n - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rb[mid] <= pidx) lo = mid; else hi = mid - 1; }
-    // class = the (pidx - rowbase[cand])-th valid class of the candidate's row
-    const float* row = sc + (long long)lo * (C + 1);
-    int want = pidx - rb[lo], cl = 0;
-    for (int c = 0; c < C; ++c) {
-      if (row[c] > p.score_thr) { if (want == 0) { cl = c; break; } --want; }
-    }
-    const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)lo * 4);
-    float* o = p.dets + ((long long)b * max_num + threadIdx.x) * 5;
-    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = __uint_as_float((unsigned)(kv >> 32));
-    p.det_labels[(long long)b * max_num + threadIdx.x] = cl;
-    p.keep[(long long)b * max_num + threadIdx.x] = pidx;
-  }
-  if (threadIdx.x == 0) p.num_det[b] = nk;
-  for (int i = nk * 5 + threadIdx.x; i < max_num * 5; i += TB) p.dets[(long long)b * max_num * 5 + i] = 0.f;
-  for (int i = nk + threadIdx.x; i < max_num; i += TB) { p.det_labels[(long long)b * max_num + i] = -1; p.keep[(long long)b * max_num + i] = -1; }
-}
-
-// workspace: vlist [B][C][n] ints | rowbase [B][n + 1] ints | maxc [B] floats | kcnt [B][C] ints | kkey [B][C][max_num <= 256] u64
-extern "C" size_t aod_nms_ws_bytes(int B, int n, int C) {
-  return (size_t)B * n * C * 4 + (size_t)B * (n + 1) * 4 + (size_t)B * 4 + (size_t)B * C * 4 + 16 + (size_t)B * C * 256 * 8;
-}
+extern "C" size_t aod_nms_ws_bytes(int B, int n, int C) { return (size_t)B * n * C * 4; }
 
 extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B, int n, int C, float score_thr, float iou_thr, int max_num,
                                   float* dets, int64_t* det_labels, int64_t* keep, int32_t* num_det, void* ws, aod_stream_t stream) {
   if (B == 0) return 0;
   AOD_CHECK_ARG(boxes && scores && dets && det_labels && keep && num_det && ws, "nms: null pointer");
   AOD_CHECK_ARG(max_num >= 1 && max_num <= 256 && C >= 1, "nms: max_num must be in 1..256");
-  static const char* dbg = getenv("AOD_NMS_PER_CLASS");          // debug switch: 0 = one workgroup per image (nms_kernel)
-  if (dbg && dbg[0] == '0') {
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
-                       (long long*)det_labels, (long long*)keep, num_det, (int*)ws);
-    AOD_LAUNCH_CHECK();
-    return 0;
-  }
-  NmsCArgs a;
-  a.boxes = boxes; a.scores = scores; a.n = n; a.C = C; a.max_num = max_num; a.score_thr = score_thr; a.iou_thr = iou_thr;
-  char* w = (char*)ws;
-  a.vlist = (int*)w; w += (size_t)B * n * C * 4;
-  a.rowbase = (int*)w; w += (size_t)B * (n + 1) * 4;
-  a.maxc = (float*)w; w += (size_t)B * 4;
-  a.kcnt = (int*)w; w += (size_t)B * C * 4;
-  w = (char*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
-  a.kkey = (unsigned long long*)w;
-  a.dets = dets; a.det_labels = (long long*)det_labels; a.keep = (long long*)keep; a.num_det = num_det;
-  hipLaunchKernelGGL(nms_prep_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(nms_class_kernel, dim3(C, B), dim3(TB), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(nms_merge_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
+                     (long long*)det_labels, (long long*)keep, num_det, (int*)ws);
   AOD_LAUNCH_CHECK();
   return 0;
 }
