@@ -621,6 +621,30 @@ def bottleneck64_fwd(x, blk, identity):
     return as_nchw(out, B, H, W)
 
 
+def bottleneck128_applies(blk, x):
+    """an identity bottleneck of the 128-plane stage (resnet.py:262-301: 512 -> 128 -> 128 -> 512, stride 1, no downsample branch) whose
+    forward keeps nothing for a backward pass (inference / frozen): one launch (aod_bottleneck128_fwd)"""
+    if _PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or blk.planes != 128 or blk.downsample is not None:
+        return False
+    c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+    if (x.dtype != torch.bfloat16 or c1.in_channels != 512 or c3.out_channels != 512 or tuple(c1.stride) != (1, 1) or tuple(c2.stride) != (1, 1)
+            or tuple(c2.dilation) != (1, 1) or tuple(c2.padding) != (1, 1) or blk.norm1.training or blk.norm2.training or blk.norm3.training):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not x.requires_grad and not any(q.requires_grad for q in blk.parameters())
+
+
+def bottleneck128_fwd(x, blk):
+    B, Cin, H, W = x.shape
+    bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
+    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+    out = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale, p3.shift)
+    return as_nchw(out, B, H, W)
+
+
 def _stem_w4(conv):
     """[O, C, 7, 7] stem filter regrouped for the space-to-depth input: [O, 4C, 4, 4] with w4[o, (dy*2+dx)*C + c, R, S] =
     w7[o, c, 2R + dy - 1, 2S + dx - 1] (zero where that tap index is -1).  ONE persistent tensor per conv module, rewritten IN PLACE when

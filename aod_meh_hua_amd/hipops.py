@@ -364,6 +364,20 @@ def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_ro
     return out
 
 
+def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=False):
+    """aod_bottleneck128_fwd: identity bottleneck of the 128-plane stage in one launch; keep=True also returns the intermediates t1, t2"""
+    M, Cin = x_rows.shape
+    assert M == B * H * W and Cin == 512
+    out = torch.empty(M, 512, dtype=torch.bfloat16, device=x_rows.device)
+    t1 = torch.empty(M, 128, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+    t2 = torch.empty(M, 128, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+    flops = 2.0 * M * (512 * 128 + 1152 * 128 + 128 * 512)
+    prof_flops('fwd', (M, 512, 512 + 1152 + 128, 11, 1), flops,
+               lambda: call('aod_bottleneck128_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3), ptr(b3),
+                            ptr(out), ptr(t1), ptr(t2), stream()))
+    return (out, t1, t2) if keep else out
+
+
 def rows_to_nchw(rows, seg: Seg):
     """View rows of one segment as a [B, C, H, W] channels_last tensor (no copy)."""
     Cc = rows.shape[1]

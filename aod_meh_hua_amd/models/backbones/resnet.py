@@ -45,6 +45,8 @@ class Bottleneck(BaseModule):
         if AF.bottleneck64_applies(self, x):       # frozen / inference 64-channel block: one launch, intermediates stay in LDS
             identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])
             return AF.bottleneck64_fwd(x, self, identity)
+        if AF.bottleneck128_applies(self, x):      # inference / frozen identity block of the 128-plane stage: one launch, filters streamed
+            return AF.bottleneck128_fwd(x, self)
         # (a block WITH a downsample branch reads a stage input: conv1 and the downsample conv share it -- and with the neck's lateral conv --
         # through the gradient junction ResNet.forward put on it)
         ds = self.downsample is not None

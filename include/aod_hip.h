@@ -98,6 +98,12 @@ int aod_set_pointwise_mode(int mode);
 int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
                          aod_stream_t stream);
+/* The same for an IDENTITY bottleneck of the 128-plane stage (layer2: 512 -> 128 -> 128 -> 512, residual = x): the conv2 / conv3 filters are
+ * streamed through LDS rings (csrc/bottleneck_wide.hip).  t1 / t2 (optional, [B*H*W][128] bf16): the block's two intermediates for the
+ * pixels of the image -- with them the launch is also the forward of a TRAINING step (the backward pass reads them); NULL: inference. */
+int aod_bottleneck128_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
+                          aod_stream_t stream);
 
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).

@@ -218,6 +218,47 @@ def test_space_to_depth_stem_equals_the_7x7_stem(built, monkeypatch):
         assert torch.equal(pooled.float(), F.max_pool2d(y1.float(), 3, 2, 1))
 
 
+def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch):
+    """aod_bottleneck128_fwd (identity blocks of layer2 in the scoring pass: conv1 on the 10 x 18 halo, conv2 / conv3 filters streamed through
+    LDS rings) against the block as three launches of the implicit-GEMM kernel: one-tile, ragged multi-tile and multi-image inputs -- same
+    bf16 rounding points and the same K order per output element -> identical bits; the optional intermediates t1 / t2 (training forward)
+    equal the three-launch block's conv1 / conv2 outputs."""
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    layer2 = model.backbone.layer2
+    g = synth.gen(6)
+    model.eval()
+    for B, H, W in ((1, 8, 16), (2, 21, 37), (3, 64, 64)):
+        x = (torch.randn(B, 512, H, W, generator=g).relu() * 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            for blk in list(layer2)[1:]:
+                monkeypatch.setenv('AOD_FUSE_BOTTLENECK128', '0')
+                assert not AF.bottleneck128_applies(blk, x)
+                t1_0 = blk.conv1(x, bn=blk.norm1, relu=True)
+                t2_0 = blk.conv2(t1_0, bn=blk.norm2, relu=True)
+                y0 = blk(x)
+                monkeypatch.setenv('AOD_FUSE_BOTTLENECK128', '1')
+                assert AF.bottleneck128_applies(blk, x)
+                y1 = blk(x)
+                bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
+                p1 = AF.PREP.get(blk.conv1.weight, bn(blk.norm1), 512, blk.norm1.eps)
+                p2 = AF.PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
+                p3 = AF.PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+                y2, t1, t2 = ho.bottleneck128_fwd(AF.as_rows(x), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale,
+                                                   p3.shift, keep=True)
+                torch.cuda.synchronize()
+                assert y1.shape == y0.shape and torch.equal(y1, y0) and torch.equal(AF.as_nchw(y2, B, H, W), y0)
+                assert torch.equal(AF.as_nchw(t1, B, H, W), t1_0) and torch.equal(AF.as_nchw(t2, B, H, W), t2_0)
+                assert float(y0.float().abs().mean()) > 1e-3
+                x = y0
+    monkeypatch.delenv('AOD_FUSE_BOTTLENECK128')
+    model.train()
+    xg = torch.randn(1, 512, 16, 16).cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert not AF.bottleneck128_applies(layer2[1], xg)          # trainable stage under autograd: per-conv launches
+
+
 def test_fused_bottleneck_equals_the_three_launch_block(built, monkeypatch):
     """aod_bottleneck64_fwd (conv1 on the tile halo -> LDS, conv2 gathered from LDS, conv3 + residual from LDS: one launch per frozen layer1
     block) against the block as three / four launches of the implicit-GEMM kernel, on a one-tile image, ragged multi-tile images and

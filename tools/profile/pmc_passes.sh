@@ -23,7 +23,7 @@ sha = '$SHA'
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob('$D/traffic/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:60]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:60]
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 out = {}
 for k, d in agg.items():
@@ -40,12 +40,12 @@ for k, v in sorted(out.items(), key=lambda kv: -(kv[1]['read_MB_per_launch'] + k
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); dur = collections.defaultdict(list)
 for f in glob.glob('$D/hua*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:48]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:48]
         if 'hua' not in k: continue
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 for f in glob.glob('$D/hua1/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:48]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:48]
         if 'hua' in k: dur[k].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 ko = {}
 for k, d in agg.items():
