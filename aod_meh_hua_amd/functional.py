@@ -336,9 +336,14 @@ class ConvFn(Function):
         res_rows = as_rows(res) if res is not None else None
         out_rows = as_rows(meta['out']) if meta.get('out') is not None else None      # caller-provided destination (pyramid slice)
         # the pre-BN activations z are NOT kept: the BN weight gradient comes from <w, dW> (see backward)
-        r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
-                           pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], out=out_rows, alg=(I, O))
-        y_rows, y_segs = r[0], r[1]
+        if meta.get('pre') is not None:
+            # the output was already computed by a fused multi-conv launch (bottleneck128_train_fwd): this call only records the autograd
+            # node -- saved tensors, slots and backward are exactly those of the stand-alone launch
+            y_rows, y_segs = meta['pre'], ho.out_segs(x_segs, R, S, meta['stride'], meta['pad'], meta['dil'])
+        else:
+            r = ho.conv2d_rows(x_rows, x_segs, wp, O, R, S, meta['stride'], meta['pad'], meta['dil'], pre_scale=scale,
+                               pre_shift=shift, res=res_rows, relu=meta['relu'], out_f32=meta['out_f32'], out=out_rows, alg=(I, O))
+            y_rows, y_segs = r[0], r[1]
         ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
         ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
         ctx.nx = len(xs)
@@ -432,7 +437,7 @@ class ConvFn(Function):
 
 
 def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False,
-                shared_input=False):
+                shared_input=False, pre=None):
     """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps.
     sole_consumer: the caller guarantees that every x is the ReLU output of a conv_bn_act call and feeds NOTHING but this conv, which
     lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot).  sole_consumer='res': x additionally feeds
@@ -443,7 +448,7 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
         from .precision_x3 import conv_bn_act_x3
         outs = conv_bn_act_x3(xl, w, bn, bias, res, dict(stride=stride, pad=pad, dil=dil, relu=relu, eps=bn.eps if bn is not None else 0.0))
         return outs[0] if single else list(outs)
-    meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out)
+    meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out, pre=pre)
     if torch.is_grad_enabled():
         if relu and not out_f32:
             meta['slot'] = ActSlot()
@@ -633,6 +638,32 @@ def bottleneck128_applies(blk, x):
     if not torch.is_grad_enabled():
         return True
     return not x.requires_grad and not any(q.requires_grad for q in blk.parameters())
+
+
+def bottleneck128_train_applies(blk, x):
+    """the same block under autograd (trainable layer2 in the training step): the fused launch also writes the two intermediates, and the
+    three convs are recorded as autograd nodes around its outputs (conv_bn_act(pre=...)): forward = one launch, backward unchanged"""
+    if not torch.is_grad_enabled() or _os.environ.get('AOD_FUSE_BOTTLENECK128_TRAIN', '1') == '0':
+        return False
+    if (_PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or blk.planes != 128 or blk.downsample is not None
+            or x.dtype != torch.bfloat16):
+        return False
+    c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+    return (c1.in_channels == 512 and c3.out_channels == 512 and tuple(c1.stride) == (1, 1) and tuple(c2.stride) == (1, 1)
+            and tuple(c2.dilation) == (1, 1) and tuple(c2.padding) == (1, 1) and not (blk.norm1.training or blk.norm2.training or blk.norm3.training))
+
+
+def bottleneck128_train_fwd(x, blk):
+    """(t1, t2, y) row tensors of the fused launch for a block under autograd"""
+    B, Cin, H, W = x.shape
+    bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
+    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+    with torch.no_grad():
+        y, t1, t2 = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale,
+                                         p3.shift, keep=True)
+    return t1, t2, y
 
 
 def bottleneck128_fwd(x, blk):

@@ -50,10 +50,13 @@ class Bottleneck(BaseModule):
         # (a block WITH a downsample branch reads a stage input: conv1 and the downsample conv share it -- and with the neck's lateral conv --
         # through the gradient junction ResNet.forward put on it)
         ds = self.downsample is not None
-        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if not ds else False, shared_input=ds)
-        out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True)      # conv1's / conv2's outputs feed only the next conv:
+        pre = (None, None, None)
+        if AF.bottleneck128_train_applies(self, x):      # training forward of an identity block of the 128-plane stage: ONE launch computes
+            pre = AF.bottleneck128_train_fwd(x, self)    # t1, t2 and y; the three calls below only record the autograd nodes around them
+        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if not ds else False, shared_input=ds, pre=pre[0])
+        out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True, pre=pre[1])      # conv1's / conv2's outputs feed only the next conv:
         identity = x if not ds else self.downsample[0](x, bn=self.downsample[1], shared_input=True)
-        return self.conv3(out, bn=self.norm3, res=identity, relu=True, sole_consumer=True)   # their ReLU backward rides on its dgrad
+        return self.conv3(out, bn=self.norm3, res=identity, relu=True, sole_consumer=True, pre=pre[2])   # their ReLU backward rides on its dgrad
 
 
 class ResLayer(Sequential):
