@@ -626,13 +626,18 @@ def bottleneck64_fwd(x, blk, identity):
     return as_nchw(out, B, H, W)
 
 
+def _wide_stage(blk):
+    """128 planes (layer2, aod_bottleneck128_fwd) or 256 planes (layer3, aod_bottleneck256_fwd; AOD_FUSE_BOTTLENECK256=0 switches it off)"""
+    return blk.planes == 128 or (blk.planes == 256 and _os.environ.get('AOD_FUSE_BOTTLENECK256', '1') != '0')
+
+
 def bottleneck128_applies(blk, x):
     """an identity bottleneck of the 128-plane stage (resnet.py:262-301: 512 -> 128 -> 128 -> 512, stride 1, no downsample branch) whose
     forward keeps nothing for a backward pass (inference / frozen): one launch (aod_bottleneck128_fwd)"""
-    if _PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or blk.planes != 128 or blk.downsample is not None:
+    if _PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None:
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-    if (x.dtype != torch.bfloat16 or c1.in_channels != 512 or c3.out_channels != 512 or tuple(c1.stride) != (1, 1) or tuple(c2.stride) != (1, 1)
+    if (x.dtype != torch.bfloat16 or c1.in_channels != 4 * blk.planes or c3.out_channels != 4 * blk.planes or tuple(c1.stride) != (1, 1) or tuple(c2.stride) != (1, 1)
             or tuple(c2.dilation) != (1, 1) or tuple(c2.padding) != (1, 1) or blk.norm1.training or blk.norm2.training or blk.norm3.training):
         return False
     if not torch.is_grad_enabled():
@@ -645,11 +650,11 @@ def bottleneck128_train_applies(blk, x):
     three convs are recorded as autograd nodes around its outputs (conv_bn_act(pre=...)): forward = one launch, backward unchanged"""
     if not torch.is_grad_enabled() or _os.environ.get('AOD_FUSE_BOTTLENECK128_TRAIN', '1') == '0':
         return False
-    if (_PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or blk.planes != 128 or blk.downsample is not None
+    if (_PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None
             or x.dtype != torch.bfloat16):
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-    return (c1.in_channels == 512 and c3.out_channels == 512 and tuple(c1.stride) == (1, 1) and tuple(c2.stride) == (1, 1)
+    return (c1.in_channels == 4 * blk.planes and c3.out_channels == 4 * blk.planes and tuple(c1.stride) == (1, 1) and tuple(c2.stride) == (1, 1)
             and tuple(c2.dilation) == (1, 1) and tuple(c2.padding) == (1, 1) and not (blk.norm1.training or blk.norm2.training or blk.norm3.training))
 
 
@@ -658,8 +663,8 @@ def bottleneck128_train_fwd(x, blk):
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
-    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
-    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
     with torch.no_grad():
         y, t1, t2 = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale,
                                          p3.shift, keep=True)
@@ -670,8 +675,8 @@ def bottleneck128_fwd(x, blk):
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
-    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
-    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
     out = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale, p3.shift)
     return as_nchw(out, B, H, W)
 

@@ -365,15 +365,17 @@ def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_ro
 
 
 def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=False):
-    """aod_bottleneck128_fwd: identity bottleneck of the 128-plane stage in one launch; keep=True also returns the intermediates t1, t2"""
+    """aod_bottleneck128_fwd / aod_bottleneck256_fwd (by the channel count of x: 512 / 1024): identity bottleneck of the 128- / 256-plane
+    stage in one launch; keep=True also returns the intermediates t1, t2"""
     M, Cin = x_rows.shape
-    assert M == B * H * W and Cin == 512
-    out = torch.empty(M, 512, dtype=torch.bfloat16, device=x_rows.device)
-    t1 = torch.empty(M, 128, dtype=torch.bfloat16, device=x_rows.device) if keep else None
-    t2 = torch.empty(M, 128, dtype=torch.bfloat16, device=x_rows.device) if keep else None
-    flops = 2.0 * M * (512 * 128 + 1152 * 128 + 128 * 512)
-    prof_flops('fwd', (M, 512, 512 + 1152 + 128, 11, 1), flops,
-               lambda: call('aod_bottleneck128_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3), ptr(b3),
+    assert M == B * H * W and Cin in (512, 1024)
+    Pl = Cin // 4
+    out = torch.empty(M, Cin, dtype=torch.bfloat16, device=x_rows.device)
+    t1 = torch.empty(M, Pl, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+    t2 = torch.empty(M, Pl, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+    flops = 2.0 * M * (Cin * Pl + 9 * Pl * Pl + Pl * Cin)
+    prof_flops('fwd', (M, Cin, Cin + 9 * Pl + Pl, 11, 1), flops,
+               lambda: call('aod_bottleneck128_fwd' if Pl == 128 else 'aod_bottleneck256_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3), ptr(b3),
                             ptr(out), ptr(t1), ptr(t2), stream()))
     return (out, t1, t2) if keep else out
 

@@ -104,6 +104,11 @@ int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void
 int aod_bottleneck128_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                           const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
                           aod_stream_t stream);
+/* ... and of the 256-plane stage (layer3: 1024 -> 256 -> 256 -> 1024; t1 / t2 [B*H*W][256]): 4 x 16 pixel tiles, the eight waves split the
+ * output channels, all three filters streamed in 32-KB slices. */
+int aod_bottleneck256_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
+                          aod_stream_t stream);
 
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).

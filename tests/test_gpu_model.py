@@ -218,8 +218,10 @@ def test_space_to_depth_stem_equals_the_7x7_stem(built, monkeypatch):
         assert torch.equal(pooled.float(), F.max_pool2d(y1.float(), 3, 2, 1))
 
 
-def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch):
-    """aod_bottleneck128_fwd (identity blocks of layer2 in the scoring pass: conv1 on the 10 x 18 halo, conv2 / conv3 filters streamed through
+@pytest.mark.parametrize('stage,planes,shapes', [('layer2', 128, ((1, 8, 16), (2, 21, 37), (3, 64, 64))),
+                                                 ('layer3', 256, ((1, 4, 16), (2, 13, 37), (3, 32, 32)))])
+def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch, stage, planes, shapes):
+    """aod_bottleneck128_fwd / aod_bottleneck256_fwd (identity blocks of layer2 / layer3: conv1 on the tile halo, filters streamed through
     LDS rings) against the block as three launches of the implicit-GEMM kernel: one-tile, ragged multi-tile and multi-image inputs -- same
     bf16 rounding points and the same K order per output element -> identical bits; the optional intermediates t1 / t2 (training forward)
     equal the three-launch block's conv1 / conv2 outputs."""
@@ -227,11 +229,11 @@ def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch):
     model.load_state_dict(sd, strict=True)
     from aod_meh_hua_amd import functional as AF
     from aod_meh_hua_amd import hipops as ho
-    layer2 = model.backbone.layer2
+    layer2 = getattr(model.backbone, stage)
     g = synth.gen(6)
     model.eval()
-    for B, H, W in ((1, 8, 16), (2, 21, 37), (3, 64, 64)):
-        x = (torch.randn(B, 512, H, W, generator=g).relu() * 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    for B, H, W in shapes:
+        x = (torch.randn(B, 4 * planes, H, W, generator=g).relu() * 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             for blk in list(layer2)[1:]:
                 monkeypatch.setenv('AOD_FUSE_BOTTLENECK128', '0')
@@ -243,9 +245,9 @@ def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch):
                 assert AF.bottleneck128_applies(blk, x)
                 y1 = blk(x)
                 bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
-                p1 = AF.PREP.get(blk.conv1.weight, bn(blk.norm1), 512, blk.norm1.eps)
-                p2 = AF.PREP.get(blk.conv2.weight, bn(blk.norm2), 128, blk.norm2.eps)
-                p3 = AF.PREP.get(blk.conv3.weight, bn(blk.norm3), 128, blk.norm3.eps)
+                p1 = AF.PREP.get(blk.conv1.weight, bn(blk.norm1), 4 * planes, blk.norm1.eps)
+                p2 = AF.PREP.get(blk.conv2.weight, bn(blk.norm2), planes, blk.norm2.eps)
+                p3 = AF.PREP.get(blk.conv3.weight, bn(blk.norm3), planes, blk.norm3.eps)
                 y2, t1, t2 = ho.bottleneck128_fwd(AF.as_rows(x), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale,
                                                    p3.shift, keep=True)
                 torch.cuda.synchronize()
@@ -255,7 +257,7 @@ def test_fused_bottleneck128_equals_the_three_launch_block(built, monkeypatch):
                 x = y0
     monkeypatch.delenv('AOD_FUSE_BOTTLENECK128')
     model.train()
-    xg = torch.randn(1, 512, 16, 16).cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xg = torch.randn(1, 4 * planes, 16, 16).cuda().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     assert not AF.bottleneck128_applies(layer2[1], xg)          # trainable stage under autograd: per-conv launches
 
 
