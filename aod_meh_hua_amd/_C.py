@@ -78,6 +78,7 @@ _SIGS = {
     'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
     'aod_softmax_rowmax': (C.c_int, [P, I32, I64, I32, F32, P, P, I32, P]),
     'aod_topk_stable': (C.c_int, [P, I32, I64, I32, P, I64, P]),
+    'aod_pre_nms_levels': (C.c_int, [I32, P, P, P, P, P, P, I32, I32, F32, I32, I32, P, P, P, P, F32, P, P, P, P, P, P, P, I64, P]),
     'aod_gather_decode': (C.c_int, [P, P, P, P, P, I32, I64, I32, I32, I64, P, P, P, P, F32, P, P, P, P, I64, I64, I64, I32, P]),
     'aod_nms_ws_bytes': (SZ, [I32, I32, I32]),
     'aod_multiclass_nms': (C.c_int, [P, P, I32, I32, I32, F32, F32, I32, P, P, P, P, P, P]),

@@ -49,12 +49,10 @@ __device__ __forceinline__ void row_scores(const float* __restrict__ x, int C, f
 
 // ---------------------------------------------------------------- S1: row max of normalised scores + level gate
 template <int CT>
-__global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __restrict__ cls, long long rows_per_img, int B, int C,
-                                                             float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg, int has_bg) {
-  extern __shared__ __attribute__((aligned(16))) float srow[];
+__device__ __forceinline__ void rowmax_block(const float* __restrict__ cls, long long rows_per_img, int b, int bx, int C, float fg_thr,
+                                             float* __restrict__ rowmax, int* __restrict__ any_fg, int has_bg, float* srow) {
   const int P = C | 1;
-  const int b = blockIdx.y;
-  const long long r0 = (long long)blockIdx.x * 256;
+  const long long r0 = (long long)bx * 256;
   const int nr = (int)min((long long)256, rows_per_img - r0);
   const float* src = cls + ((long long)b * rows_per_img + r0) * C;
   aod_stage_rows<256>(src, srow, nr, C, P);
@@ -69,6 +67,12 @@ __global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __rest
     fg = ma > fg_thr;
   }
   if (__ballot(fg) && (threadIdx.x & 63) == 0) atomicOr(any_fg + b, 1);
+}
+template <int CT>
+__global__ __launch_bounds__(256) void softmax_rowmax_kernel(const float* __restrict__ cls, long long rows_per_img, int B, int C,
+                                                             float fg_thr, float* __restrict__ rowmax, int* __restrict__ any_fg, int has_bg) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  rowmax_block<CT>(cls, rows_per_img, blockIdx.y, blockIdx.x, C, fg_thr, rowmax, any_fg, has_bg, srow);
 }
 
 extern "C" int aod_softmax_rowmax(const float* cls, int B, int64_t rows_per_img, int C, float fg_thr, float* rowmax, int32_t* any_fg,
@@ -206,14 +210,15 @@ __device__ unsigned long long radix_select_kth(KeyFn key, long long n, unsigned 
 
 // ---------------------------------------------------------------- S2: stable top-k per (image, level)
 // key = (score bits << 32) | (0xffffffff - index): larger key = higher score, then lower index; keys are unique.
-__global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ score, long long A, int k, int* __restrict__ idx_out, long long out_pitch,
-                                                  int cache_n) {
-  __shared__ int hist[264];
-  __shared__ int s_warp[TB / 64];
-  __shared__ unsigned long long keys[1024];
-  extern __shared__ float s_cache[];          // the row's scores: the 8 select passes + the compaction re-read them, and a dependent
-  const int b = blockIdx.x;                   // L2 round trip per 1024 elements and pass is what the kernel's time used to be
-  const float* s = score + (long long)b * A;
+struct TopkLds {
+  int hist[264];
+  int s_warp[TB / 64];
+  unsigned long long keys[1024];
+};
+// top-k of one row by the whole block; idx_out[0..k) = anchor indices in descending (score, then lower index) order
+__device__ void topk_block(const float* __restrict__ s, long long A, int k, int* __restrict__ idx_out, int cache_n, TopkLds& L, float* s_cache) {
+  int* const hist = L.hist;
+  unsigned long long* const keys = L.keys;
   const long long ncache = A < (long long)cache_n ? A : (long long)cache_n;
   for (long long i = threadIdx.x; i < ncache; i += TB) s_cache[i] = s[i];
   __syncthreads();
@@ -241,7 +246,14 @@ __global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ scor
     }
   }
   bitonic_desc(keys, 1024);
-  for (int i = threadIdx.x; i < k; i += TB) idx_out[(long long)b * out_pitch + i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+  for (int i = threadIdx.x; i < k; i += TB) idx_out[i] = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+}
+__global__ __launch_bounds__(TB) void topk_kernel(const float* __restrict__ score, long long A, int k, int* __restrict__ idx_out, long long out_pitch,
+                                                  int cache_n) {
+  __shared__ TopkLds L;
+  extern __shared__ float s_cache[];          // the row's scores: the 8 select passes + the compaction re-read them, and a dependent
+  const int b = blockIdx.x;                   // L2 round trip per 1024 elements and pass is what the kernel's time used to be
+  topk_block(score + (long long)b * A, A, k, idx_out + (long long)b * out_pitch, cache_n, L, s_cache);
 }
 
 extern "C" int aod_topk_stable(const float* score, int B, int64_t A, int k, int32_t* idx, int64_t out_pitch, aod_stream_t stream) {
@@ -269,11 +281,7 @@ struct GatherArgs {
   long long n_total; long long cand0; long long anchor0; int normalize;
 };
 template <int CT>
-__global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) {
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= p.k) return;
-  const long long a = p.idx ? p.idx[(long long)b * p.idx_pitch + j] : j;
+__device__ __forceinline__ void gather_one(const GatherArgs& p, int b, int j, long long a) {
   const long long row = (long long)b * p.A + a;
   float x[CT], s[CT], ma, ms;
 #pragma unroll
@@ -321,6 +329,14 @@ __global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) 
     p.boxes[o * 4 + i] = v;
   }
 }
+template <int CT>
+__global__ __launch_bounds__(256) void gather_decode_kernel(const GatherArgs p) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.k) return;
+  const long long a = p.idx ? p.idx[(long long)b * p.idx_pitch + j] : j;
+  gather_one<CT>(p, b, j, a);
+}
 
 extern "C" int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, const float* anchors, const int32_t* idx,
                                  int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
@@ -336,6 +352,96 @@ extern "C" int aod_gather_decode(const float* cls, const float* reg, const float
   p.boxes = boxes; p.scores = scores; p.lam = lam; p.cand_anchor = cand_anchor; p.n_total = n_total; p.cand0 = cand0; p.anchor0 = anchor0; p.normalize = normalize;
   if (C <= 24) hipLaunchKernelGGL(gather_decode_kernel<24>, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gather_decode_kernel<MAXC>, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- S1-S3 of ALL pyramid levels in two launches
+// As 13 launches (5 x row max, 3 x top-k, 5 x gather) the pre-NMS stage is a chain of 6-80 us kernels that occupy 16-150 CUs each: 330 us
+// per 16-image batch of which the level-0 top-k alone is 78.  The level chains are independent: (1) one launch scans every level's logits,
+// (2) one launch runs a workgroup per (image, level) that selects the level's top-k (where k < A) and gathers + decodes its candidates.
+constexpr int MAXL = 8;
+struct LevelsArgs {
+  const float* cls[MAXL]; const float* reg[MAXL]; const float* lam_map[MAXL]; const float* anchors[MAXL];
+  float* rowmax[MAXL]; int* idx[MAXL];                   // idx[l] = null: the level keeps all its anchors (k == A)
+  long long A[MAXL]; int k[MAXL]; int blk0[MAXL + 1]; long long cand0[MAXL]; long long anchor0[MAXL];
+  int L, B, C, has_bg, normalize, cache_n;
+  float fg_thr;
+  int* any_fg;                                           // [L][B]
+  GatherArgs g;                                          // the level-independent part (outputs, image sizes, coder constants)
+};
+template <int CT>
+__global__ __launch_bounds__(256) void softmax_rowmax_levels_kernel(const LevelsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  int l = 0;
+  while (l + 1 < p.L && (int)blockIdx.x >= p.blk0[l + 1]) ++l;
+  rowmax_block<CT>(p.cls[l], p.A[l], blockIdx.y, blockIdx.x - p.blk0[l], p.C, p.fg_thr, p.rowmax[l], p.any_fg + l * p.B, p.has_bg, srow);
+}
+template <int CT>
+__global__ __launch_bounds__(TB) void topk_gather_levels_kernel(const LevelsArgs p) {
+  __shared__ TopkLds Lds;
+  extern __shared__ float s_cache[];
+  const int b = blockIdx.x, l = blockIdx.y;
+  const long long A = p.A[l];
+  const int k = p.k[l];
+  GatherArgs g = p.g;
+  g.cls = p.cls[l]; g.reg = p.reg[l]; g.lam_map = p.lam_map[l]; g.anchors = p.anchors[l]; g.A = A; g.k = k; g.cand0 = p.cand0[l]; g.anchor0 = p.anchor0[l];
+  if (p.idx[l]) {
+    topk_block(p.rowmax[l] + (long long)b * A, A, k, p.idx[l] + (long long)b * k, p.cache_n, Lds, s_cache);
+    for (int j = threadIdx.x; j < k; j += TB)
+      gather_one<CT>(g, b, j, (long long)(0xffffffffu - (unsigned)(Lds.keys[j] & 0xffffffffull)));
+  } else {
+    for (int j = threadIdx.x; j < k; j += TB) gather_one<CT>(g, b, j, (long long)j);
+  }
+}
+
+extern "C" int aod_pre_nms_levels(int L, const float* const* cls, const float* const* reg, const float* const* lam_map,
+                                  const float* const* anchors, const int64_t* A, const int32_t* k, int B, int C, float fg_thr, int has_bg,
+                                  int normalize, const float* img_hw, const float* scale4, const float* means4, const float* stds4,
+                                  float wh_ratio_clip, float* rowmax, int32_t* any_fg, int32_t* idx, float* boxes, float* scores, float* lam,
+                                  int32_t* cand_anchor, int64_t n_total, aod_stream_t stream) {
+  if (B == 0 || L == 0) return 0;
+  AOD_CHECK_ARG(L >= 1 && L <= MAXL && cls && reg && lam_map && anchors && A && k && C >= 1 && C <= MAXC, "pre_nms_levels: bad args");
+  AOD_CHECK_ARG(img_hw && rowmax && any_fg && boxes && scores && lam && cand_anchor, "pre_nms_levels: null pointer");
+  LevelsArgs p;
+  memset(&p, 0, sizeof(p));
+  long long a0 = 0, c0 = 0, i0 = 0, amax = 0;
+  int nb = 0;
+  for (int l = 0; l < L; ++l) {
+    AOD_CHECK_ARG(A[l] >= 1 && k[l] >= 1 && k[l] <= A[l] && k[l] <= 1024, "pre_nms_levels: need 1 <= k <= min(1024, A) per level");
+    AOD_CHECK_ARG(k[l] == A[l] || idx, "pre_nms_levels: idx buffer needed for levels with k < A");
+    p.cls[l] = cls[l]; p.reg[l] = reg[l]; p.lam_map[l] = lam_map[l]; p.anchors[l] = anchors[l];
+    p.A[l] = A[l]; p.k[l] = k[l];
+    p.rowmax[l] = rowmax + (long long)B * a0;
+    p.idx[l] = k[l] < A[l] ? idx + (long long)B * i0 : nullptr;
+    if (k[l] < A[l]) { i0 += k[l]; amax = A[l] > amax ? A[l] : amax; }
+    p.blk0[l] = nb; nb += (int)((A[l] + 255) / 256);
+    p.cand0[l] = c0; p.anchor0[l] = a0;
+    c0 += k[l]; a0 += A[l];
+  }
+  p.blk0[L] = nb;
+  AOD_CHECK_ARG(c0 == n_total, "pre_nms_levels: n_total must be the sum of k");
+  p.L = L; p.B = B; p.C = C; p.has_bg = has_bg; p.normalize = normalize; p.fg_thr = fg_thr; p.any_fg = any_fg;
+  p.cache_n = (int)(amax < 36864 ? amax : 36864);
+  GatherArgs& g = p.g;
+  g.B = B; g.C = C; g.idx = nullptr; g.idx_pitch = 0; g.img_hw = img_hw; g.scale4 = scale4;
+  for (int i = 0; i < 4; ++i) { g.means[i] = means4 ? means4[i] : 0.f; g.stds[i] = stds4 ? stds4[i] : 1.f; }
+  g.max_ratio = fabsf(logf(wh_ratio_clip));
+  g.boxes = boxes; g.scores = scores; g.lam = lam; g.cand_anchor = cand_anchor; g.n_total = n_total; g.normalize = normalize;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_gather_levels_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_gather_levels_kernel<MAXC>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
+    attr_done = true;
+  }
+  const size_t srow = (size_t)256 * (C | 1) * 4, cache = (size_t)p.cache_n * 4;
+  if (C <= 24) {
+    hipLaunchKernelGGL(softmax_rowmax_levels_kernel<24>, dim3(nb, B), dim3(256), srow, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(topk_gather_levels_kernel<24>, dim3(B, L), dim3(TB), cache, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(softmax_rowmax_levels_kernel<MAXC>, dim3(nb, B), dim3(256), srow, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(topk_gather_levels_kernel<MAXC>, dim3(B, L), dim3(TB), cache, (hipStream_t)stream, p);
+  }
   AOD_LAUNCH_CHECK();
   return 0;
 }

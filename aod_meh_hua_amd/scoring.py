@@ -4,12 +4,14 @@ ComputeObjUnc / AggregateObjScaleUnc (:489-619) for a whole batch without a host
     per level   aod_softmax_rowmax  -> row max of the normalised scores, level gate
                 aod_topk_stable     -> per-image top-nms_pre anchors (levels with more than nms_pre anchors)
                 aod_gather_decode   -> candidates: boxes / scores(+bg) / lambda / anchor id
+                (all levels in two launches: aod_pre_nms_levels)
     per batch   aod_multiclass_nms  -> dets [B,max,5], labels, keep, num_det
                 aod_hua_score       -> one epistemic-uncertainty score per image
 
 `unc` stays on the device ([B] fp32 tensor): the pool loop (apis/test.py single_gpu_uncertainty) concatenates
 tensors and only syncs once per pool, instead of the reference's `.item()` per (object, level, class) bin."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -115,8 +117,32 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
     lam_o = torch.empty(B, n, device=dev)
     cand_anchor = torch.empty(B, n, dtype=torch.int32, device=dev)
     img_hw, sc4 = _meta_tensors(img_shapes, scale_factors if rescale else None, dev)
+    level_start = [0]
+    for l in range(L):
+        level_start.append(level_start[-1] + ks[l])
+    if L <= 8 and max(ks) <= 1024 and os.environ.get('AOD_PRE_NMS_MERGED', '1') != '0':
+        # all levels in two launches (aod_pre_nms_levels): one [sum B*A] row-max buffer and one index buffer, handed out as per-level views
+        rm = torch.empty(B * sum(A), device=dev)
+        tk = [l for l in range(L) if ks[l] < A[l]]
+        ix = torch.empty(max(B * sum(ks[l] for l in tk), 1), dtype=torch.int32, device=dev)
+        anch = [a.contiguous() for a in mlvl_anchors]
+        PA = C.c_void_p * L
+        call('aod_pre_nms_levels', L, PA(*[ptr(t).value for t in cls]), PA(*[ptr(t).value for t in reg]), PA(*[ptr(t).value for t in lam]),
+             PA(*[ptr(t).value for t in anch]), (C.c_int64 * L)(*A), (C.c_int32 * L)(*ks), B, C_, fg_thr, int(has_bg),
+             2 if has_bg else int(bool(normalize)), ptr(img_hw), ptr(sc4), _F4(*means), _F4(*stds), float(wh_ratio_clip), ptr(rm), ptr(any_fg),
+             ptr(ix), ptr(boxes), ptr(scores), ptr(lam_o), ptr(cand_anchor), n, stream())
+        rowmaxes, idxs, r0, i0 = [], [], 0, 0
+        for l in range(L):
+            rowmaxes.append(rm[r0:r0 + B * A[l]].view(B, A[l]))
+            r0 += B * A[l]
+            if ks[l] < A[l]:
+                idxs.append(ix[i0:i0 + B * ks[l]].view(B, ks[l]))
+                i0 += B * ks[l]
+            else:
+                idxs.append(None)
+        return Candidates(boxes, scores, lam_o, cand_anchor, level_start, any_fg, idxs, rowmaxes)
     c0 = a0 = 0
-    level_start, idxs, rowmaxes = [0], [], []
+    idxs, rowmaxes = [], []
     for l in range(L):
         rowmax = torch.empty(B, A[l], device=dev)
         from .hipops import prof_bytes
@@ -133,7 +159,6 @@ def pre_nms(mlvl_cls, mlvl_reg, mlvl_L, mlvl_anchors, img_shapes, scale_factors,
              ptr(cand_anchor), n, c0, a0, 2 if has_bg else int(bool(normalize)), stream())
         c0 += ks[l]
         a0 += A[l]
-        level_start.append(c0)
     return Candidates(boxes, scores, lam_o, cand_anchor, level_start, any_fg, idxs, rowmaxes)
 
 

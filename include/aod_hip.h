@@ -286,6 +286,16 @@ int aod_gather_decode(const float* cls, const float* reg, const float* lam_map, 
                       int B, int64_t A, int k, int C, int64_t idx_pitch, const float* img_hw, const float* scale4,
                       const float* means4, const float* stds4, float wh_ratio_clip, float* boxes, float* scores, float* lam,
                       int32_t* cand_anchor, int64_t n_total, int64_t cand0, int64_t anchor0, int normalize, aod_stream_t stream);
+/* The three steps above for ALL L (<= 8) pyramid levels of a batch in two launches (the per-level loop of Lambda_L2.py:264-310 /
+ * My_L_ssd_head.py:331-365): one scan of every level's logits, then one workgroup per (image, level) that selects the level's top-k[l]
+ * (where k[l] < A[l]) and gathers + decodes its candidates.  cls / reg / lam_map / anchors / A / k: HOST arrays of L entries.
+ * rowmax: [sum_l B*A[l]] level-major (level l = a [B, A[l]] block); any_fg [L, B] (zeroed by the caller); idx: level-major [B, k[l]]
+ * blocks of the levels with k[l] < A[l] only (may be NULL when there is none); n_total = sum_l k[l].  Results are those of the
+ * per-level entry points bit for bit. */
+int aod_pre_nms_levels(int L, const float* const* cls, const float* const* reg, const float* const* lam_map, const float* const* anchors,
+                       const int64_t* A, const int32_t* k, int B, int C, float fg_thr, int has_bg, int normalize, const float* img_hw,
+                       const float* scale4, const float* means4, const float* stds4, float wh_ratio_clip, float* rowmax, int32_t* any_fg,
+                       int32_t* idx, float* boxes, float* scores, float* lam, int32_t* cand_anchor, int64_t n_total, aod_stream_t stream);
 /* multiclass_nms (core/post_processing/bbox_nms.py:7-93 -> mmcv batched_nms / nms_cpu semantics, both its <10000 and
  * per-class paths reduce to this class-aware greedy scan).  boxes [B,n,4], scores [B,n,C+1]; outputs dets [B,max_num,5],
  * det_labels [B,max_num] int64, keep [B,max_num] int64 (index into the score>thr list; -1 padded), num_det [B] int32. */

@@ -228,3 +228,32 @@ def test_save_max_conf_matches_get_max_conf(run):
     cls_p, _, _ = synth.planted_heads(2, 128, 128)
     exp = torch.stack([c.permute(0, 2, 3, 1).reshape(2, -1, 20).softmax(-1).reshape(2, -1).max(-1)[0] for c in cls_p], 1).max(-1)[0]
     assert np.allclose(cand.max_conf().cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('B,H,W,has_bg', [(2, 128, 128, False), (3, 256, 320, False), (16, 512, 512, False), (2, 128, 128, True)])
+def test_merged_level_launches_equal_the_per_level_chain(monkeypatch, B, H, W, has_bg):
+    """aod_pre_nms_levels (row max of all levels in one launch + one (image, level) workgroup grid for top-k, gather and decode) against the
+    13-launch per-level chain on the same head outputs: every output identical (indices, boxes, scores, lambda, level gates)."""
+    from aod_meh_hua_amd import scoring
+    from aod_meh_hua_amd.core.anchor import AnchorGenerator
+    C_ = 21 if has_bg else 20
+    cls_p, reg_p, L_p = synth.planted_heads(B, H, W, C=C_, seed=31 + B)
+    mt = synth.metas(B, H, W, scale=1.25)
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    anchors = ag.grid_anchors([tuple(c.shape[-2:]) for c in cls_p], 'cuda')
+    args = ([c.cuda() for c in cls_p], [r.cuda() for r in reg_p], [l.cuda() for l in L_p], anchors, [m['img_shape'] for m in mt],
+            [m['scale_factor'] for m in mt], 1000, C_, (0., 0., 0., 0.), (1., 1., 1., 1.))
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('AOD_PRE_NMS_MERGED', mode)
+        out[mode] = scoring.pre_nms(*args, has_bg=has_bg)
+    torch.cuda.synchronize()
+    a, b = out['0'], out['1']
+    assert a.level_start == b.level_start
+    for name in ('boxes', 'scores', 'lam', 'cand_anchor', 'any_fg'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for x, y in zip(a.topk_idx, b.topk_idx):
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
+    for x, y in zip(a.rowmax, b.rowmax):
+        assert torch.equal(x, y)
+    assert torch.equal(a.max_conf(), b.max_conf())
