@@ -39,6 +39,7 @@ _SIGS = {
     'aod_set_pointwise_mode': (C.c_int, [I32]),
     'aod_bottleneck64_fwd': (C.c_int, [P, I32, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck128_fwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'aod_bottleneck_bwd': (C.c_int, [I32, P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck256_fwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_conv2d': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, P]),
     'aod_conv2d_ws_bytes': (SZ, [C.POINTER(ConvDesc)]),

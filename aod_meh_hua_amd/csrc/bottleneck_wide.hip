@@ -28,6 +28,11 @@ struct BnwArgs {
   bf16_t* y;             // [B*H*W][512]
   bf16_t* t1;            // [B*H*W][128] or null
   bf16_t* t2;            // [B*H*W][128] or null
+  // backward form (BWD instances): ReLU masks = the block's saved activations, and fp32 column sums of the three results
+  const bf16_t* m1;      // [B*H*W][P]    mask of the first product  (forward t2)
+  const bf16_t* m2;      // [B*H*W][P]    mask of the second product (forward t1)
+  const bf16_t* m3;      // [B*H*W][4P]   mask of the third product  (forward x)
+  float* cs1; float* cs2; float* cs3;     // [P] [P] [4P], += (atomics)
   int B, H, W, tiles_y, tiles_x;
 };
 
@@ -40,7 +45,8 @@ constexpr int STG1 = XCH + W1CH;                                         // 40 9
 constexpr int OFF_T1 = 2 * STG1;                                         // 81 920: t1 as 2 sub-images [192][128 B]
 constexpr int T1SUB = HROWS * 128;
 constexpr int OFF_VEC = OFF_T1 + 2 * T1SUB;                              // 131 072: s1 b1 s2 b2 [128] s3 b3 [512] fp32
-constexpr int LDS_BYTES = OFF_VEC + (4 * P + 2 * 4 * P) * 4;             // 137 216
+constexpr int OFF_CS3 = OFF_VEC + (4 * P + 2 * 4 * P) * 4;               // 137 216: column sums (backward form): third result [512], first [128],
+constexpr int LDS_BYTES = OFF_CS3 + 6 * P * 4;                           // second [128] fp32 -> 140 288
 constexpr int W2SLOT = P * 128, W2R = 5;                                 // phase 2 ring over the phase-1 staging area (81 920 = 5 slots)
 constexpr int OFF_T2 = 0, T2SUB = TH * TW * 128;                         // t2 [2][128][128 B] = 32 768 over the dead ring
 constexpr int OFF_W3 = 2 * T2SUB, W3SLOT = 2 * P * 128, W3R = 3;         // 32 768 .. 131 072: three 32-KB conv3 filter chunks
@@ -68,7 +74,31 @@ __device__ __forceinline__ int wrow(int j, int lr) { return (j >> 1) * 32 + (lr 
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck128_fwd_kernel(const BnwArgs p) {
+// bit j of the result: element j of the 16-B piece (8 bf16) is > 0 -- the ReLU mask of 8 channels in 8 bits
+__device__ __forceinline__ unsigned pos_bits(const u32x4_t q) {
+  unsigned m = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    m |= (__uint_as_float(q[w] << 16) > 0.f ? 1u : 0u) << (2 * w);
+    m |= (__uint_as_float(q[w] & 0xffff0000u) > 0.f ? 1u : 0u) << (2 * w + 1);
+  }
+  return m;
+}
+// sum over the 16 lanes that share lq (the lanes of one pixel block that hold the same 8 channels) = one DPP row: four rotate-and-add steps
+// on the vector ALU, every lane ends up with the total (__shfl_xor would be four ds_bpermute round trips through the LDS pipe per value)
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum_lr(float v) {
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+  return v;
+}
+
+// BWD: the same three products are the block's DGRAD chain (csrc/conv.hip dgrad epilogue semantics: result = mask > 0 ? acc (+ res) : 0,
+// fp32 column sums of the results): x = the finished gradient G of the block output, w1 / w2 / w3 = the scale-folded dgrad filters of
+// conv3 / conv2 / conv1, t1 / t2 / y = the gradients of forward t2 / t1 / x, residual = G (the skip branch).
+template <bool BWD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck128_kernel(const BnwArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -104,7 +134,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // folded BN vectors -> LDS once (an ordinary global load beside LDS-DMA makes hipcc drain the DMA queue where the value is used)
   float* const vec = reinterpret_cast<float*>(smem + OFF_VEC);
-  {
+  // BWD: the column sums of the three results are collected in LDS (ds_add_f32) and leave the workgroup as ONE coalesced global atomic per
+  // channel at the end (4-lane atomics straight from the epilogues serialised on their 128-1024 addresses: 635 us instead of 75)
+  float* const csl = reinterpret_cast<float*>(smem + OFF_CS3);
+  if constexpr (BWD) {
+    csl[t] = 0.f;
+    if (t < 2 * P) csl[4 * P + t] = 0.f;
+  }
+  if constexpr (!BWD) {
     if (t < 128) vec[t] = p.s1[t];
     else if (t < 256) vec[t] = p.b1[t - 128];
     else if (t < 384) vec[t] = p.s2[t - 256];
@@ -115,6 +152,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* const vs1 = vec, * const vb1 = vec + 128, * const vs2 = vec + 256, * const vb2 = vec + 384, * const vs3 = vec + 512, * const vb3 = vec + 1024;
 
   // ------------------------------------------------------------------ phase 1: t1 = relu(bn1(conv1(x))) on the halo
+  const auto rsrc_m1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m1, 0, BWD ? (int)(npix * P * 2) : 0, 0x00020000);
+  const auto rsrc_m2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m2, 0, BWD ? (int)(npix * P * 2) : 0, 0x00020000);
+  const auto rsrc_m3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m3, 0, BWD ? (int)(npix * CIN * 2) : 0, 0x00020000);
+  u32x4_t mk1[3][2];                               // BWD: mask pieces of this lane's halo pixels (out-of-image pixels read 0 = masked)
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int h = (3 * wp + i) * 16 + lr;
+      int y, x;
+      const unsigned hrow = halo_pix(h, y, x) ? (unsigned)((img0 + (long long)y * p.W + x) * (P * 2)) : OOB;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) mk1[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m1, (int)(hrow + (unsigned)((64 * wc + 32 * jp + lq * 8) * 2)), 0, 0);
+    }
+  }
   unsigned xoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -175,6 +226,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // epilogue 1: t1 -> LDS (zero outside the image) and, for the tile's own pixels, -> global (training forward)
   {
     char* t1 = smem + OFF_T1;
+    float cs1v[2][8] = {};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int h = (3 * wp + i) * 16 + lr;
@@ -187,18 +239,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int jp = 0; jp < 2; ++jp) {
         const int c = 64 * wc + 32 * jp + lq * 8;
         bf16x8 o;
+        if constexpr (BWD) {
+          const unsigned mb = pos_bits(mk1[i][jp]);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = ((mb >> (4 * q + r)) & 1u) ? acc1[i][2 * jp + q][r] + 0.f : 0.f;
+              o[4 * q + r] = (bf16_t)v;
+              cs1v[jp][4 * q + r] += inner ? v : 0.f;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x4 sc = *reinterpret_cast<const f32x4*>(vs1 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb1 + c + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[4 * q + r] = (bf16_t)(ok ? fmaxf(acc1[i][2 * jp + q][r] * sc[r] + sh[r], 0.f) : 0.f);
         }
+        }
         *reinterpret_cast<bf16x8*>(t1 + wc * T1SUB + swz(h, jp * 4 + lq)) = o;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_t1, (int)(grow + (unsigned)(c * 2)), 0, 0);
       }
     }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = sum_lr(cs1v[jp][j]);
+          if (lr == 0) atomicAdd(csl + 4 * P + 64 * wc + 32 * jp + lq * 8 + j, v);
+        }
+    }
   }
   __syncthreads();                                // t1 complete; the staging area is free
+  // BWD: the masks of the two later epilogues, requested ahead of the filter ring (older than every ring load: in-order return has them
+  // in registers by the first counted wait); the third one (forward x, 16 pieces) is boiled down to a bit per element after the loop
+  u32x4_t mk2[2][2], mk3[2][4][2];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = ty0 + 2 * wp + i, x = tx0 + lr;
+      const bool ok = y < p.H && x < p.W;
+      const long long pix = img0 + (long long)y * p.W + x;
+      const unsigned r2 = ok ? (unsigned)(pix * (P * 2)) : OOB, r3 = ok ? (unsigned)(pix * (CIN * 2)) : OOB;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        mk2[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m2, (int)(r2 + (unsigned)((64 * wc + 32 * jp + lq * 8) * 2)), 0, 0);
+#pragma unroll
+        for (int n3 = 0; n3 < 4; ++n3)
+          mk3[i][n3][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m3, (int)(r3 + (unsigned)((n3 * 128 + 64 * wc + 32 * jp + lq * 8) * 2)), 0, 0);
+      }
+    }
+  }
 
   // ------------------------------------------------------------------ phase 2: t2 = relu(bn2(conv2(t1))), filter slices through a ring
   unsigned w2base[2];
@@ -228,7 +320,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
       if (s + L2 < NS2) issue2(s + L2, slot == 0 ? W2R - 1 : slot - 1);
       const int tap = s >> 1, half = s & 1;
-      const int r = tap / 3, q = tap - r * 3;
+      const int r0_ = tap / 3, q0_ = tap - r0_ * 3;
+      const int r = BWD ? 2 - r0_ : r0_, q = BWD ? 2 - q0_ : q0_;      // dgrad: tap (r, s) of the [I][R][S][O] pack reads pixel (y + 1 - r, x + 1 - s)
       const char* t1 = smem + OFF_T1 + half * T1SUB;
       const char* ws = smem + slot * W2SLOT;
 #pragma unroll
@@ -249,9 +342,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();                                // the ring is dead: t2 goes over it
+  unsigned mb3[2][2] = {};                        // BWD: byte (n3 & 3) of mb3[i][jp] = mask bits of chunk n3
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int n3 = 0; n3 < 4; ++n3) mb3[i][jp] |= pos_bits(mk3[i][n3][jp]) << (8 * n3);
+  }
   unsigned prow[2];                               // byte offset of the lane's pixel rows in a [B*H*W][512] bf16 tensor
   {
     char* t2 = smem + OFF_T2;
+    float cs2v[2][8] = {};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int y = ty0 + 2 * wp + i, x = tx0 + lr;
@@ -263,15 +366,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int jp = 0; jp < 2; ++jp) {
         const int c = 64 * wc + 32 * jp + lq * 8;
         bf16x8 o;
+        if constexpr (BWD) {
+          const unsigned mb = pos_bits(mk2[i][jp]);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = ((mb >> (4 * q + r)) & 1u) ? acc2[i][2 * jp + q][r] + 0.f : 0.f;
+              o[4 * q + r] = (bf16_t)v;
+              cs2v[jp][4 * q + r] += v;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x4 sc = *reinterpret_cast<const f32x4*>(vs2 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb2 + c + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[4 * q + r] = (bf16_t)fmaxf(acc2[i][2 * jp + q][r] * sc[r] + sh[r], 0.f);
         }
+        }
         *reinterpret_cast<bf16x8*>(t2 + wc * T2SUB + swz(o_, jp * 4 + lq)) = o;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_t2, (int)(grow + (unsigned)(c * 2)), 0, 0);
       }
+    }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = sum_lr(cs2v[jp][j]);
+          if (lr == 0) atomicAdd(csl + 5 * P + 64 * wc + 32 * jp + lq * 8 + j, v);
+        }
     }
   }
   __syncthreads();
@@ -325,6 +449,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float c3v[2][8] = {};                         // BWD: this lane's column sums of the chunk (its two pixel rows)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -332,6 +457,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int c = n3 * 128 + 64 * wc + 32 * jp + lq * 8;
         const u32x4_t q = rv[i][n3][jp];
         bf16x8 o;
+        if constexpr (BWD) {
+          const unsigned mb = mb3[i][jp] >> (8 * n3);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc3[i][2 * jp + h2][r] + 0.f;
+            v[0] += __uint_as_float(q[2 * h2] << 16); v[1] += __uint_as_float(q[2 * h2] & 0xffff0000u);
+            v[2] += __uint_as_float(q[2 * h2 + 1] << 16); v[3] += __uint_as_float(q[2 * h2 + 1] & 0xffff0000u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = ((mb >> (4 * h2 + r)) & 1u) ? v[r] : 0.f;
+              o[4 * h2 + r] = (bf16_t)v[r];
+              c3v[jp][4 * h2 + r] += v[r];
+            }
+          }
+        } else
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const f32x4 sc = *reinterpret_cast<const f32x4*>(vs3 + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vb3 + c + 4 * h2);
@@ -345,6 +487,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_y, (int)(prow[i] + (unsigned)(c * 2)), 0, 0);
       }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cs = sum_lr(c3v[jp][j]);
+          if (lr == 0) atomicAdd(csl + n3 * 128 + 64 * wc + 32 * jp + lq * 8 + j, cs);
+        }
+    }
+  }
+  if constexpr (BWD) {                            // column sums of the third result: one global atomic per channel and workgroup
+    __syncthreads();
+    atomicAdd(p.cs3 + t, csl[t]);
+    if (t < P) atomicAdd(p.cs1 + t, csl[4 * P + t]);
+    else if (t < 2 * P) atomicAdd(p.cs2 + t - P, csl[4 * P + t]);
   }
 }
 
@@ -370,7 +527,8 @@ constexpr int OFF_W3 = 4 * T2SUB;                                        // phas
 constexpr int OFF_VEC3 = OFF_W3 + WR * WSLOT;                            // s3 b3 [1024] fp32: 131 072 .. 139 264 (over the dead t1)
 static_assert(WR * WSLOT <= OFF_T1 && OFF_VEC3 + 2 * CIN * 4 <= OFF_VEC && LDS_BYTES <= 160 * 1024, "LDS map");
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck256_fwd_kernel(const BnwArgs p) {
+template <bool BWD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck256_kernel(const BnwArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -397,13 +555,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return h < HPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
   };
   float* const vec = reinterpret_cast<float*>(smem + OFF_VEC);
-  {
+  if constexpr (!BWD) {
     vec[t] = t < 256 ? p.s1[t] : p.b1[t - 256];
     vec[512 + t] = t < 256 ? p.s2[t] : p.b2[t - 256];
   }
   const float* const vs1 = vec, * const vb1 = vec + 256, * const vs2 = vec + 512, * const vb2 = vec + 768;
 
   // ------------------------------------------------------------------ phase 1
+  const int cw = 32 * uw + lq * 8;                 // this lane's 8 consecutive channels (within P, and within a 256-channel conv3 chunk)
+  const auto rsrc_m1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m1, 0, BWD ? (int)(npix * P * 2) : 0, 0x00020000);
+  const auto rsrc_m2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m2, 0, BWD ? (int)(npix * P * 2) : 0, 0x00020000);
+  const auto rsrc_m3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m3, 0, BWD ? (int)(npix * CIN * 2) : 0, 0x00020000);
+  u32x4_t mk1[7];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      int y, x;
+      const unsigned hrow = halo_pix(i * 16 + lr, y, x) ? (unsigned)((img0 + (long long)y * p.W + x) * (P * 2)) : OOB;
+      mk1[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m1, (int)(hrow + (unsigned)(cw * 2)), 0, 0);
+    }
+  }
   unsigned xoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -461,9 +632,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < NK1) issue1(buf);
   }
-  const int cw = 32 * uw + lq * 8;                 // this lane's 8 consecutive channels (within P, and within a 256-channel conv3 chunk)
   {
     char* t1 = smem + OFF_T1;
+    float cs1v[8] = {};
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int h = i * 16 + lr;
@@ -473,17 +644,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bool inner = ok && hy >= 1 && hy <= TH && hx >= 1 && hx <= TW;
       const unsigned grow = inner ? (unsigned)((img0 + (long long)y * p.W + x) * (P * 2)) : OOB;
       bf16x8 o;
+      if constexpr (BWD) {
+        const unsigned mb = pos_bits(mk1[i]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = ((mb >> (4 * q + r)) & 1u) ? acc1[i][q][r] + 0.f : 0.f;
+            o[4 * q + r] = (bf16_t)v;
+            cs1v[4 * q + r] += inner ? v : 0.f;
+          }
+      } else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(vs1 + cw + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb1 + cw + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * q + r] = (bf16_t)(ok ? fmaxf(acc1[i][q][r] * sc[r] + sh[r], 0.f) : 0.f);
       }
+      }
       *reinterpret_cast<bf16x8*>(t1 + (uw >> 1) * T1SUB + swz(h, (uw & 1) * 4 + lq)) = o;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_t1, (int)(grow + (unsigned)(cw * 2)), 0, 0);
     }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {           // (every channel belongs to one wave: plain LDS stores)
+        const float v = sum_lr(cs1v[j]);
+        if (lr == 0) reinterpret_cast<float*>(smem + OFF_VEC)[cw + j] = v;
+      }
+    }
   }
   __syncthreads();
+  u32x4_t mk2[4], mk3[4][4];                       // BWD: masks of the two later epilogues, requested ahead of the filter ring
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = ty0 + i, x = tx0 + lr;
+      const bool ok = y < p.H && x < p.W;
+      const long long pix = img0 + (long long)y * p.W + x;
+      const unsigned r2 = ok ? (unsigned)(pix * (P * 2)) : OOB, r3 = ok ? (unsigned)(pix * (CIN * 2)) : OOB;
+      mk2[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m2, (int)(r2 + (unsigned)(cw * 2)), 0, 0);
+#pragma unroll
+      for (int n3 = 0; n3 < 4; ++n3) mk3[i][n3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m3, (int)(r3 + (unsigned)((n3 * 256 + cw) * 2)), 0, 0);
+    }
+  }
 
   // ------------------------------------------------------------------ phase 2: 36 slices (tap, 64-channel quarter)
   unsigned w2base[4];
@@ -512,7 +715,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
       if (s + LA < NS2) issue2(s + LA, slot == 0 ? WR - 1 : slot - 1);
       const int tap = s >> 2, qt = s & 3;
-      const int r = tap / 3, q = tap - r * 3;
+      const int r0_ = tap / 3, q0_ = tap - r0_ * 3;
+      const int r = BWD ? 2 - r0_ : r0_, q = BWD ? 2 - q0_ : q0_;
       const char* t1 = smem + OFF_T1 + qt * T1SUB;
       const char* ws = smem + slot * WSLOT;
 #pragma unroll
@@ -533,9 +737,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();
+  unsigned mb3[4] = {};                            // BWD: byte n3 of mb3[i] = mask bits of chunk n3
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n3 = 0; n3 < 4; ++n3) mb3[i] |= pos_bits(mk3[i][n3]) << (8 * n3);
+  }
   unsigned prow[4];
   {
     char* t2 = smem;
+    float cs2v[8] = {};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = ty0 + i, x = tx0 + lr;
@@ -543,19 +755,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       prow[i] = ok ? (unsigned)((img0 + (long long)y * p.W + x) * (CIN * 2)) : OOB;
       const unsigned grow = ok ? (unsigned)((img0 + (long long)y * p.W + x) * (P * 2)) : OOB;
       bf16x8 o;
+      if constexpr (BWD) {
+        const unsigned mb = pos_bits(mk2[i]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = ((mb >> (4 * q + r)) & 1u) ? acc2[i][q][r] + 0.f : 0.f;
+            o[4 * q + r] = (bf16_t)v;
+            cs2v[4 * q + r] += v;
+          }
+      } else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(vs2 + cw + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb2 + cw + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * q + r] = (bf16_t)fmaxf(acc2[i][q][r] * sc[r] + sh[r], 0.f);
       }
+      }
       *reinterpret_cast<bf16x8*>(t2 + (uw >> 1) * T2SUB + swz(i * 16 + lr, (uw & 1) * 4 + lq)) = o;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsrc_t2, (int)(grow + (unsigned)(cw * 2)), 0, 0);
     }
-    // conv3's folded BN vectors over the dead t1 (plain loads: they are waited for right here, before any LDS-DMA of this phase)
-    float* const v3 = reinterpret_cast<float*>(smem + OFF_VEC3);
-    v3[t] = p.s3[t]; v3[512 + t] = p.s3[512 + t];
-    v3[1024 + t] = p.b3[t]; v3[1536 + t] = p.b3[512 + t];
+    if constexpr (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = sum_lr(cs2v[j]);
+        if (lr == 0) reinterpret_cast<float*>(smem + OFF_VEC)[P + cw + j] = v;
+      }
+    } else {
+      // conv3's folded BN vectors over the dead t1 (plain loads: they are waited for right here, before any LDS-DMA of this phase)
+      float* const v3 = reinterpret_cast<float*>(smem + OFF_VEC3);
+      v3[t] = p.s3[t]; v3[512 + t] = p.s3[512 + t];
+      v3[1024 + t] = p.b3[t]; v3[1536 + t] = p.b3[512 + t];
+    }
   }
   __syncthreads();
 
@@ -579,6 +811,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   issue3(0, 0);
   issue3(1, 1);
   f32x4 acc3[4][2];
+  float cs3v[4][8] = {};                           // BWD: column sums of the third result; every channel of it belongs to one wave only
   {
     int slot = 0;
 #pragma unroll
@@ -617,6 +850,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 4; ++i) {
           const u32x4_t q = rv[i][n3];
           bf16x8 o;
+          if constexpr (BWD) {
+            const unsigned mb = mb3[i] >> (8 * n3);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc3[i][h2][r] + 0.f;
+              v[0] += __uint_as_float(q[2 * h2] << 16); v[1] += __uint_as_float(q[2 * h2] & 0xffff0000u);
+              v[2] += __uint_as_float(q[2 * h2 + 1] << 16); v[3] += __uint_as_float(q[2 * h2 + 1] & 0xffff0000u);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = ((mb >> (4 * h2 + r)) & 1u) ? v[r] : 0.f;
+                o[4 * h2 + r] = (bf16_t)v[r];
+                cs3v[n3][4 * h2 + r] += v[r];
+              }
+            }
+          } else
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(vs3 + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vb3 + c + 4 * h2);
@@ -634,51 +884,86 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       slot = slot == WR - 1 ? 0 : slot + 1;
     }
   }
+  if constexpr (BWD) {
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = sum_lr(cs3v[n3][j]);
+        if (lr == 0) reinterpret_cast<float*>(smem + OFF_VEC3)[n3 * 256 + cw + j] = v;
+      }
+    // the three column-sum vectors leave the workgroup as coalesced global atomics, one per channel (4-lane atomics straight from the
+    // epilogues serialise on their addresses: 205 us instead of 67).  OFF_VEC / OFF_VEC3: the BN vector areas, unused in this form
+    __syncthreads();
+    const float* const c12 = reinterpret_cast<const float*>(smem + OFF_VEC);
+    const float* const c3 = reinterpret_cast<const float*>(smem + OFF_VEC3);
+    if (t < P) atomicAdd(p.cs1 + t, c12[t]); else atomicAdd(p.cs2 + t - P, c12[t]);
+    atomicAdd(p.cs3 + t, c3[t]);
+    atomicAdd(p.cs3 + 512 + t, c3[512 + t]);
+  }
 }
 }  // namespace w256
 
 }  // namespace
 
-extern "C" int aod_bottleneck128_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
-                                     const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1,
-                                     void* t2, aod_stream_t stream) {
-  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck128: null pointer");
-  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck128: bad geometry");
-  AOD_CHECK_ARG((long long)B * H * W * CIN * 2 < 0xe0000000ll, "bottleneck128: operand larger than 3.5 GiB");
+template <int PL, bool BWD>
+static int launch_wide(BnwArgs& a, hipStream_t st) {
+  constexpr int th = PL == 128 ? TH : w256::TH, tw = PL == 128 ? TW : w256::TW, lds = PL == 128 ? LDS_BYTES : w256::LDS_BYTES;
+  a.tiles_y = (a.H + th - 1) / th; a.tiles_x = (a.W + tw - 1) / tw;
+  const void* fn;
+  if constexpr (PL == 128) fn = reinterpret_cast<const void*>(&bottleneck128_kernel<BWD>);
+  else fn = reinterpret_cast<const void*>(&w256::bottleneck256_kernel<BWD>);
+  static bool attr_done = false;               // one flag per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  if constexpr (PL == 128) hipLaunchKernelGGL(bottleneck128_kernel<BWD>, dim3(a.B * a.tiles_y * a.tiles_x), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(w256::bottleneck256_kernel<BWD>, dim3(a.B * a.tiles_y * a.tiles_x), dim3(512), lds, st, a);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+static int wide_fwd(int PL, const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                    const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2, aod_stream_t stream) {
+  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck128/256: null pointer");
+  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck128/256: bad geometry");
+  AOD_CHECK_ARG((long long)B * H * W * (4 * PL) * 2 < 0xe0000000ll, "bottleneck128/256: operand larger than 3.5 GiB");
   BnwArgs a;
+  memset(&a, 0, sizeof(a));
   a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w3 = (const bf16_t*)w3;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.y = (bf16_t*)y; a.t1 = (bf16_t*)t1; a.t2 = (bf16_t*)t2;
   a.B = B; a.H = H; a.W = W;
-  a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck128_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(bottleneck128_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-  AOD_LAUNCH_CHECK();
-  return 0;
+  return PL == 128 ? launch_wide<128, false>(a, (hipStream_t)stream) : launch_wide<256, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int aod_bottleneck128_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                                     const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1,
+                                     void* t2, aod_stream_t stream) {
+  return wide_fwd(128, x, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, y, t1, t2, stream);
 }
 
 extern "C" int aod_bottleneck256_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                                      const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1,
                                      void* t2, aod_stream_t stream) {
-  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck256: null pointer");
-  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck256: bad geometry");
-  AOD_CHECK_ARG((long long)B * H * W * w256::CIN * 2 < 0xe0000000ll, "bottleneck256: operand larger than 3.5 GiB");
+  return wide_fwd(256, x, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, y, t1, t2, stream);
+}
+
+extern "C" int aod_bottleneck_bwd(int planes, const void* g, int B, int H, int W, const void* wd3, const void* wd2, const void* wd1,
+                                  const void* act_t2, const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2,
+                                  float* colsum_t1, float* colsum_x, aod_stream_t stream) {
+  AOD_CHECK_ARG(planes == 128 || planes == 256, "bottleneck_bwd: planes must be 128 or 256");
+  AOD_CHECK_ARG(g && wd3 && wd2 && wd1 && act_t2 && act_t1 && act_x && gx && gt2 && gt1 && colsum_t2 && colsum_t1 && colsum_x,
+                "bottleneck_bwd: null pointer");
+  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck_bwd: bad geometry");
+  AOD_CHECK_ARG((long long)B * H * W * (4 * planes) * 2 < 0xe0000000ll, "bottleneck_bwd: operand larger than 3.5 GiB");
   BnwArgs a;
-  a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w3 = (const bf16_t*)w3;
-  a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
-  a.y = (bf16_t*)y; a.t1 = (bf16_t*)t1; a.t2 = (bf16_t*)t2;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)g; a.w1 = (const bf16_t*)wd3; a.w2 = (const bf16_t*)wd2; a.w3 = (const bf16_t*)wd1;
+  a.y = (bf16_t*)gx; a.t1 = (bf16_t*)gt2; a.t2 = (bf16_t*)gt1;
+  a.m1 = (const bf16_t*)act_t2; a.m2 = (const bf16_t*)act_t1; a.m3 = (const bf16_t*)act_x;
+  a.cs1 = colsum_t2; a.cs2 = colsum_t1; a.cs3 = colsum_x;
   a.B = B; a.H = H; a.W = W;
-  a.tiles_y = (H + w256::TH - 1) / w256::TH; a.tiles_x = (W + w256::TW - 1) / w256::TW;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w256::bottleneck256_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w256::LDS_BYTES);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(w256::bottleneck256_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), w256::LDS_BYTES, (hipStream_t)stream, a);
-  AOD_LAUNCH_CHECK();
-  return 0;
+  return planes == 128 ? launch_wide<128, true>(a, (hipStream_t)stream) : launch_wide<256, true>(a, (hipStream_t)stream);
 }

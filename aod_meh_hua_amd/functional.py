@@ -203,6 +203,24 @@ class ActSlot:
         self.res_ok, self.res_grad = False, None
 
 
+class BwdChain:
+    """The three convs of ONE identity bottleneck (128 / 256 planes) whose dgrads run as one launch (aod_bottleneck_bwd).  conv3's backward
+    comes first: when every ActSlot hand-over of the block is in place (conv3 -> t2, conv2 -> t1, conv1 -> x with the skip gradient) it
+    launches the whole chain, keeps its own result and leaves the other two here; conv2's and conv1's backward pick them up instead of
+    launching their dgrads.  Weight gradients stay per conv (they read the same bits)."""
+    __slots__ = ('meta', 'x_rows', 'prep', 'out')
+
+    def __init__(self):
+        self.meta, self.x_rows, self.prep, self.out = {}, {}, {}, {}
+
+
+def bwd_chain_for(blk, x):
+    """a BwdChain for a block whose training forward qualifies for the fused kernels (same conditions; AOD_FUSE_BOTTLENECK_BWD=0 switches
+    the fused backward off), else None"""
+    on = _os.environ.get('AOD_FUSE_BOTTLENECK_BWD', '1') != '0'
+    return BwdChain() if on and _FUSE_ACT and bottleneck128_train_applies(blk, x) else None
+
+
 class GradAcc:
     """Gradient junction of a tensor that feeds SEVERAL convs (a ResNet stage output: the next stage's conv1 and downsample conv, and the
     neck's lateral conv).  Autograd would run the three dgrads into three tensors and add them with two elementwise passes (62 us for C3 at
@@ -348,6 +366,9 @@ class ConvFn(Function):
         ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
         ctx.nx = len(xs)
         ctx.save_for_backward(w, gamma, mean, scale, invstd, x_rows, y_rows if meta['relu'] else None)
+        if meta.get('chain') is not None:
+            ch, role = meta['chain']
+            ch.meta[role], ch.x_rows[role], ch.prep[role] = meta, x_rows, (w, gamma, mean, cin, x_segs)
         outs = tuple(as_nchw(y_rows[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for s in y_segs)
         return outs
 
@@ -421,8 +442,25 @@ class ConvFn(Function):
             if acc is not None:                 # gradient junction: the running sum of the other consumers' dX rides on this dgrad's epilogue
                 assert not fuse and len(xd) == 1
                 res_g = acc.partial
-            dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
-                                      res=res_g, mask=x_rows if fuse else None, colsum=s1_in, alg=(I, O))
+            ch, role = meta.get('chain') or (None, 0)
+            dx = None
+            if ch is not None and fuse and acc is None and dz.dtype == torch.bfloat16:
+                if role == 3 and res_g is None and _chain_ready(ch, meta):
+                    # the whole block's dgrad chain in one launch; G = dz is also the skip gradient conv1's epilogue adds
+                    s0 = x_segs[0]
+                    wds = {3: wd}
+                    for r in (2, 1):
+                        w_, g_, m_, cin_, _ = ch.prep[r]
+                        wds[r] = PREP.get(w_, (g_, None, m_, None) if g_ is not None else None, cin_, ch.meta[r]['eps']).wd
+                    gx, dx, gt1, cx, s1_in, c1 = ho.bottleneck_bwd(dz, s0.B, s0.H, s0.W, wds[3], wds[2], wds[1], x_rows, ch.x_rows[2], ch.x_rows[1])
+                    ch.out[2], ch.out[1] = (gt1, c1), (gx, cx)
+                elif role in ch.out:
+                    dx, s1_in = ch.out.pop(role)
+                    if role == 1:
+                        ch.meta.clear(), ch.x_rows.clear(), ch.prep.clear()
+            if dx is None:
+                dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
+                                          res=res_g, mask=x_rows if fuse else None, colsum=s1_in, alg=(I, O))
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
@@ -436,8 +474,26 @@ class ConvFn(Function):
         return (None, gw, ggamma, gbeta, None, None, gbias, gres) + tuple(gxs)
 
 
+def _chain_ready(ch, meta3):
+    """every hand-over of the block is in place: conv2 and conv1 fuse their producers' activation backward, the skip gradient of conv3 is
+    routed to conv1's epilogue, one dense level each"""
+    if set(ch.meta) != {1, 2, 3} or ch.out:
+        return False
+    m1, m2 = ch.meta[1], ch.meta[2]
+    sl1, sl2 = m1.get('in_slot'), m2.get('in_slot')
+    if sl1 is None or sl2 is None or meta3.get('res_slot') is not sl1 or sl1.res_grad is None:
+        return False
+    if m1.get('in_acc') is not None or m2.get('in_acc') is not None:
+        return False
+    for r in (1, 2, 3):
+        segs = ch.prep[r][4]
+        if len(segs) != 1 or segs[0].row0 != 0:
+            return False
+    return True
+
+
 def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, out=None, sole_consumer=False,
-                shared_input=False, pre=None):
+                shared_input=False, pre=None, chain=None):
     """xs: tensor or list of tensors (levels).  bn: object with weight/bias/running_mean/running_var/eps.
     sole_consumer: the caller guarantees that every x is the ReLU output of a conv_bn_act call and feeds NOTHING but this conv, which
     lets this conv's dgrad epilogue perform that producer's activation backward (ActSlot).  sole_consumer='res': x additionally feeds
@@ -449,6 +505,8 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
         outs = conv_bn_act_x3(xl, w, bn, bias, res, dict(stride=stride, pad=pad, dil=dil, relu=relu, eps=bn.eps if bn is not None else 0.0))
         return outs[0] if single else list(outs)
     meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out, pre=pre)
+    if chain is not None and torch.is_grad_enabled():
+        meta['chain'] = chain
     if torch.is_grad_enabled():
         if relu and not out_f32:
             meta['slot'] = ActSlot()

@@ -380,6 +380,24 @@ def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=
     return (out, t1, t2) if keep else out
 
 
+def bottleneck_bwd(g_rows, B, H, W, wd3, wd2, wd1, act_t2, act_t1, act_x):
+    """aod_bottleneck_bwd: dgrad chain of an identity bottleneck (128 / 256 planes) in one launch -> (gx, gt2, gt1, colsum_x, colsum_t2, colsum_t1)"""
+    M, Cin = g_rows.shape
+    assert M == B * H * W and Cin in (512, 1024) and act_x.shape == g_rows.shape
+    Pl = Cin // 4
+    assert act_t2.shape == (M, Pl) and act_t1.shape == (M, Pl)
+    dev = g_rows.device
+    gx = torch.empty(M, Cin, dtype=torch.bfloat16, device=dev)
+    gt2 = torch.empty(M, Pl, dtype=torch.bfloat16, device=dev)
+    gt1 = torch.empty(M, Pl, dtype=torch.bfloat16, device=dev)
+    cx, c2, c1 = zeros_f32(Cin, dev), zeros_f32(Pl, dev), zeros_f32(Pl, dev)
+    flops = 2.0 * M * (Cin * Pl + 9 * Pl * Pl + Pl * Cin)
+    prof_flops('dgrad', (M, Cin, Cin + 9 * Pl + Pl, 11, 1), flops,
+               lambda: call('aod_bottleneck_bwd', Pl, ptr(g_rows), B, H, W, ptr(wd3), ptr(wd2), ptr(wd1), ptr(act_t2), ptr(act_t1), ptr(act_x),
+                            ptr(gx), ptr(gt2), ptr(gt1), ptr(c2), ptr(c1), ptr(cx), stream()))
+    return gx, gt2, gt1, cx, c2, c1
+
+
 def rows_to_nchw(rows, seg: Seg):
     """View rows of one segment as a [B, C, H, W] channels_last tensor (no copy)."""
     Cc = rows.shape[1]

@@ -348,11 +348,11 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d used as a PARAMETER HOLDER (same state_dict keys / init as the reference).  Its compute
     runs on the HIP implicit-GEMM kernel; there is no ATen fallback."""
 
-    def forward(self, x, bn=None, res=None, relu=False, out_f32=False, out=None, sole_consumer=False, shared_input=False, pre=None):
+    def forward(self, x, bn=None, res=None, relu=False, out_f32=False, out=None, sole_consumer=False, shared_input=False, pre=None, chain=None):
         assert self.groups == 1 and self.padding[0] == self.padding[1] and self.stride[0] == self.stride[1]
         return AF.conv_bn_act(x, self.weight, bn=bn, bias=self.bias, res=res, stride=self.stride[0], pad=self.padding[0],
                               dil=self.dilation[0], relu=relu, out_f32=out_f32, out=out, sole_consumer=sole_consumer, shared_input=shared_input,
-                              pre=pre)
+                              pre=pre, chain=chain)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

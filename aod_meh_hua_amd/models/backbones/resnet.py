@@ -50,13 +50,15 @@ class Bottleneck(BaseModule):
         # (a block WITH a downsample branch reads a stage input: conv1 and the downsample conv share it -- and with the neck's lateral conv --
         # through the gradient junction ResNet.forward put on it)
         ds = self.downsample is not None
-        pre = (None, None, None)
-        if AF.bottleneck128_train_applies(self, x):      # training forward of an identity block of the 128-plane stage: ONE launch computes
-            pre = AF.bottleneck128_train_fwd(x, self)    # t1, t2 and y; the three calls below only record the autograd nodes around them
-        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if not ds else False, shared_input=ds, pre=pre[0])
-        out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True, pre=pre[1])      # conv1's / conv2's outputs feed only the next conv:
-        identity = x if not ds else self.downsample[0](x, bn=self.downsample[1], shared_input=True)
-        return self.conv3(out, bn=self.norm3, res=identity, relu=True, sole_consumer=True, pre=pre[2])   # their ReLU backward rides on its dgrad
+        pre, ch = (None, None, None), None
+        if AF.bottleneck128_train_applies(self, x):      # training forward of an identity block of the 128- / 256-plane stage: ONE launch
+            pre = AF.bottleneck128_train_fwd(x, self)    # computes t1, t2 and y; the three calls below only record the autograd nodes around
+            ch = AF.bwd_chain_for(self, x)               # them -- and their three dgrads run as one launch too (aod_bottleneck_bwd)
+        role = (lambda r: (ch, r)) if ch is not None else (lambda r: None)
+        out = self.conv1(x, bn=self.norm1, relu=True, sole_consumer='res' if not ds else False, shared_input=ds, pre=pre[0], chain=role(1))
+        out = self.conv2(out, bn=self.norm2, relu=True, sole_consumer=True, pre=pre[1], chain=role(2))   # conv1's / conv2's outputs feed only the
+        identity = x if not ds else self.downsample[0](x, bn=self.downsample[1], shared_input=True)     # next conv: their ReLU backward rides on
+        return self.conv3(out, bn=self.norm3, res=identity, relu=True, sole_consumer=True, pre=pre[2], chain=role(3))       # its dgrad
 
 
 class ResLayer(Sequential):

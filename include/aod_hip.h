@@ -109,6 +109,16 @@ int aod_bottleneck128_fwd(const void* x, int B, int H, int W, const void* w1, co
 int aod_bottleneck256_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                           const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
                           aod_stream_t stream);
+/* The DGRAD chain of the same identity blocks (planes = 128 / 256) in one launch -- the three dgrad launches of conv3, conv2, conv1 with
+ * their fused epilogues (aod_conv2d: mask / res / colsum) back to back, the two intermediates staying in LDS:
+ *   gt2 = [act_t2 > 0] * conv3_T(g)        gt1 = [act_t1 > 0] * conv2_T(gt2)        gx = [act_x > 0] * (conv1_T(gt1) + g)
+ * g [B*H*W][4*planes]: the finished gradient w.r.t. the block's pre-ReLU output (it is also the skip branch's gradient); wd3 [planes][4*planes],
+ * wd2 [planes][3][3][planes], wd1 [4*planes][planes]: the packed dgrad filters (BN scale folded in, aod_pack_weights_dgrad); act_*: the
+ * activations the forward pass saved; colsum_*: fp32 [planes] [planes] [4*planes], += column sums of the three results (the BN-shift
+ * gradients of conv2, conv1 and of the previous block's conv3).  Gradients equal those of the three launches bit for bit. */
+int aod_bottleneck_bwd(int planes, const void* g, int B, int H, int W, const void* wd3, const void* wd2, const void* wd1, const void* act_t2,
+                       const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
+                       float* colsum_x, aod_stream_t stream);
 
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).

@@ -289,3 +289,44 @@ def test_fused_bottleneck_equals_the_three_launch_block(built, monkeypatch):
     model.train()
     xg = torch.randn(1, 256, 16, 16).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
     assert not AF.bottleneck64_applies(model.backbone.layer2[0], xg)
+
+
+@pytest.mark.parametrize('stage,planes,shape', [('layer2', 128, (2, 21, 37)), ('layer2', 128, (3, 64, 64)), ('layer3', 256, (2, 13, 37)),
+                                               ('layer3', 256, (3, 32, 32))])
+def test_fused_bottleneck_backward_equals_the_three_dgrad_launches(built, monkeypatch, stage, planes, shape):
+    """aod_bottleneck_bwd (dgrad chain of an identity block: the three products with the mask / skip-gradient / column-sum epilogues of the
+    dgrad launches, intermediates in LDS) against the three launches, through autograd over a whole stage (downsample block + identity
+    blocks, so that the ActSlot / skip-gradient hand-overs at both ends of every chain are exercised): input gradient and conv weight
+    gradients identical bits; BN gradients (fp32 atomics in both forms) within 1e-5 of their scale."""
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    layer = getattr(model.backbone, stage)
+    model.train()                                         # norm_eval=True keeps BN in eval mode (resnet.py:630-640)
+    B, H, W = shape
+    cin = layer[0].conv1.in_channels
+    g = synth.gen(9)
+    x0 = (torch.randn(B, cin, 2 * H, 2 * W, generator=g).relu() * 0.5).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = (torch.randn(B, 4 * planes, H, W, generator=g) * 0.1).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    params = [q for q in layer.parameters() if q.requires_grad]
+    res, calls = {}, {}
+    orig = ho.bottleneck_bwd
+    for mode in ('0', '1'):
+        monkeypatch.setenv('AOD_FUSE_BOTTLENECK_BWD', mode)
+        n = [0]
+        monkeypatch.setattr(ho, 'bottleneck_bwd', lambda *a, **k: (n.__setitem__(0, n[0] + 1), orig(*a, **k))[1])
+        x = x0.clone().requires_grad_(True)
+        y = layer(x)
+        grads = torch.autograd.grad(y, [x] + params, gy)
+        torch.cuda.synchronize()
+        res[mode], calls[mode] = [t.clone() for t in grads], n[0]
+    assert calls['0'] == 0 and calls['1'] == len(layer) - 1          # every identity block took the fused chain
+    names = ['x'] + [n_ for n_, q in layer.named_parameters() if q.requires_grad]
+    for n_, a, b in zip(names, res['0'], res['1']):
+        if a.dim() == 4:
+            assert torch.equal(a, b), n_
+        else:
+            scale = float(a.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-7, (n_, float((a - b).abs().max()), scale)
+    assert float(res['1'][0].float().abs().mean()) > 0
