@@ -50,6 +50,9 @@ _SIGS = {
     'aod_conv2d_wgrad': (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     'aod_conv2d_wgrad_splits': (C.c_int, [C.POINTER(ConvDesc)]),
     'aod_conv2d_wgrad_slabs': (C.c_int, [C.POINTER(ConvDesc), P, P, P, I32, I64, P, P]),
+    'aod_conv2d_wgrad_group_plan': (C.c_int, [P, I32, P]),
+    'aod_conv2d_wgrad_grouped': (C.c_int, [P, I32, P, P, P, P, P, P, P]),
+    'aod_unpack_wgrad_slabs_grouped': (C.c_int, [I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_unpack_wgrad_slabs': (C.c_int, [P, I32, I64, P, I32, I32, I32, I32, I32, I32, P, P, P, P, P, P, P]),
     'aod_conv_row_table_bytes': (SZ, [C.POINTER(ConvDesc)]),
     'aod_conv_row_table': (C.c_int, [C.POINTER(ConvDesc), P, P]),

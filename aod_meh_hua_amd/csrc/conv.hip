@@ -1062,7 +1062,7 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 // reads, so the 128 x 128 form moves 768 B of LDS per MFMA -- more than the LDS delivers at the matrix pipe's rate; the big tile halves
 // that (and the LDS-DMA traffic per MFMA), like the 256 x 256 tile of the forward kernel.
 template <int NW, int TN, int TK>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
   constexpr int RPW = 4 * NW;          // pixel rows covered per pass of all waves
   constexpr int PASSES = 64 / RPW;
   constexpr int WNC = NW / 2;          // waves along the (tap, channel) axis
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int wm = uw / WNC, wn = uw % WNC;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   const int split = bid % p.splits; bid /= p.splits;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
   const int n0 = tile_n * (128 * TN), k0 = tile_k * (128 * TK);
@@ -1266,6 +1266,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK
 // MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup ends with
 // 64 KB of output -- fp32 atomics at ~1.3 TB/s chip-wide (0.05 us per workgroup) or, in slab mode, plain stores at ~5.5 TB/s (0.012 us)
 // plus the unpack kernel's read of one more slab per split.
+template <int NW, int TN, int TK>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
+  wgrad_tile<NW, TN, TK>(p, blockIdx.x);
+}
+// Grouped launch: up to WG_MAXG weight gradients (ANY geometries, one tile form) share one grid.  Alone a backbone layer needs 100+ pixel
+// splits of its few 128 x 128 tiles to fill the chip -- a 512 x 128 filter (256 KB) leaves 30 MB of partial slabs for the unpack; three
+// layers together need a third of the splits each (longer pixel runs per workgroup, a third of the slab traffic, one launch).
+constexpr int WG_MAXG = 4;
+struct WgradGroups { WgradParams g[WG_MAXG]; int wg0[WG_MAXG + 1]; int n; };
+template <int NW, int TN, int TK>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_grouped_kernel(const WgradGroups gp) {
+  const int b = blockIdx.x;
+  // (selects, not an indexed read of the argument block: a run-time index would move the whole array to scratch memory)
+  if (b < gp.wg0[1]) wgrad_tile<NW, TN, TK>(gp.g[0], b);
+  else if (b < gp.wg0[2]) wgrad_tile<NW, TN, TK>(gp.g[1], b - gp.wg0[1]);
+  else if (b < gp.wg0[3]) wgrad_tile<NW, TN, TK>(gp.g[2], b - gp.wg0[2]);
+  else wgrad_tile<NW, TN, TK>(gp.g[3], b - gp.wg0[3]);
+}
+
 static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big) {
   // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
   static const char* dbg_big = getenv("AOD_WGRAD_256");
@@ -1291,8 +1310,8 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
   splits = (M + rps - 1) / rps;
 }
 
-static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
-                        const void* row_table, aod_stream_t stream) {
+// operands + geometry of one weight gradient (everything but the split plan)
+static int wgrad_fill(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, const void* row_table, WgradParams& p) {
   AOD_CHECK_ARG(d && x && dz && dw && row_table, "wgrad: null pointer");
   AOD_CHECK_ARG(!d->transposed, "wgrad: descriptor must be the forward descriptor");
   AOD_CHECK_ARG(d->N % 8 == 0, "wgrad: N %d must be a multiple of 8 (pad dZ)", d->N);
@@ -1300,8 +1319,6 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   memset(&cp, 0, sizeof(cp));
   int rc = fill_params(d, cp);
   if (rc) return rc;
-  if (cp.M == 0) return 0;
-  WgradParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const bf16_t*)x; p.dz = (const bf16_t*)dz; p.dw = dw; p.tab = (const RowRec*)row_table;
   p.C = cp.C; p.N = cp.N; p.K = cp.K; p.R = cp.R; p.S = cp.S; p.dil = cp.dil; p.M = cp.M;
@@ -1317,27 +1334,123 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   p.z_bytes = zrows * p.N * 2;
   p.tab_bytes = (long long)p.M * (long long)sizeof(RowRec);
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
+  { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
+  return 0;
+}
+
+static void wgrad_attrs() {
+  static bool attr_done = false;
+  if (attr_done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  attr_done = true;
+}
+
+static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
+                        const void* row_table, aod_stream_t stream) {
+  WgradParams p;
+  int rc = wgrad_fill(d, x, dz, dw, row_table, p);
+  if (rc) return rc;
+  if (p.M == 0) return 0;
   int splits, rps, big;
   wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps, big);
   const int tiles = p.tiles_n * p.tiles_k;
   p.splits = splits; p.rows_per_split = rps;
   p.slab_stride = slab_stride;
-  { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
   if (slab_stride > 0) {
     AOD_CHECK_ARG(splits <= max_slabs, "wgrad: %d slabs needed, %d provided (aod_conv2d_wgrad_splits)", splits, max_slabs);
     AOD_CHECK_ARG(slab_stride >= (long long)p.N * p.K, "wgrad: slab stride smaller than N*K");
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-    attr_done = true;
-  }
+  wgrad_attrs();
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
   if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
   else if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL((conv_wgrad_kernel<8, 1, 1>), dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// Split plan of a GROUP (slab form): every workgroup of the launch runs the same number T of 64-pixel steps (the groups' tiles are the same
+// size, so that equalises their durations); T = the smallest for which the grid fits the chip's slots -- group g then gets ceil(steps_g / T)
+// splits.  All members must take the same tile form (`big` of wgrad_plan); returns that form, or -1 when they do not.
+static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int* tiles_n, int* tiles_k, int* splits, int* rps) {
+  int big = -1;
+  long long tiles[WG_MAXG];
+  int steps[WG_MAXG], max_steps = 1;
+  for (int g = 0; g < n; ++g) {
+    int sp, r, b;
+    wgrad_plan(M[g], N[g], K[g], true, tiles_n[g], tiles_k[g], sp, r, b);
+    if (big >= 0 && b != big) return -1;
+    big = b;
+    tiles[g] = (long long)tiles_n[g] * tiles_k[g];
+    steps[g] = (M[g] + 63) / 64;
+    if (steps[g] > max_steps) max_steps = steps[g];
+  }
+  static const char* dbg_slots = getenv("AOD_WGRAD_SLOTS");      // (debug: grid size the group plan aims at, small-tile form)
+  const int slots = big ? 256 : (dbg_slots ? atoi(dbg_slots) : 512);
+  int T = 1;
+  for (; T < max_steps; ++T) {
+    long long tot = 0;
+    for (int g = 0; g < n; ++g) tot += tiles[g] * ((steps[g] + T - 1) / T);
+    if (tot <= slots) break;
+  }
+  for (int g = 0; g < n; ++g) {
+    rps[g] = T * 64;
+    splits[g] = (M[g] + rps[g] - 1) / rps[g];
+  }
+  return big;
+}
+
+extern "C" int aod_conv2d_wgrad_group_plan(const aod_conv_desc_t* const* descs, int n, int32_t* splits_out) {
+  AOD_CHECK_ARG(descs && splits_out && n >= 1 && n <= WG_MAXG, "wgrad_group_plan: 1..4 descriptors");
+  int M[WG_MAXG], N[WG_MAXG], K[WG_MAXG], tn[WG_MAXG], tk[WG_MAXG], sp[WG_MAXG], rps[WG_MAXG];
+  for (int g = 0; g < n; ++g) {
+    AOD_CHECK_ARG(descs[g] && !descs[g]->transposed, "wgrad_group_plan: forward descriptors");
+    ConvKParams cp;
+    memset(&cp, 0, sizeof(cp));
+    int rc = fill_params(descs[g], cp);
+    if (rc) return rc;
+    AOD_CHECK_ARG(cp.M > 0, "wgrad_group_plan: empty member");
+    M[g] = cp.M; N[g] = cp.N; K[g] = cp.K;
+  }
+  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps);
+  if (big < 0) return 1;                       // mixed tile forms: launch the members one by one
+  for (int g = 0; g < n; ++g) splits_out[g] = sp[g];
+  return 0;
+}
+
+extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int n, const void* const* x, const void* const* dz,
+                                        float* const* slabs, const int32_t* nslabs, const int64_t* slab_stride,
+                                        const void* const* row_table, aod_stream_t stream) {
+  AOD_CHECK_ARG(descs && x && dz && slabs && nslabs && slab_stride && row_table && n >= 1 && n <= WG_MAXG, "wgrad_grouped: 1..4 members");
+  WgradGroups gp;
+  memset(&gp, 0, sizeof(gp));
+  int M[WG_MAXG], N[WG_MAXG], K[WG_MAXG], tn[WG_MAXG], tk[WG_MAXG], sp[WG_MAXG], rps[WG_MAXG];
+  for (int g = 0; g < n; ++g) {
+    int rc = wgrad_fill(descs[g], x[g], dz[g], slabs[g], row_table[g], gp.g[g]);
+    if (rc) return rc;
+    AOD_CHECK_ARG(gp.g[g].M > 0, "wgrad_grouped: empty member");
+    M[g] = gp.g[g].M; N[g] = gp.g[g].N; K[g] = gp.g[g].K;
+  }
+  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps);
+  AOD_CHECK_ARG(big >= 0, "wgrad_grouped: the members take different tile forms (aod_conv2d_wgrad_group_plan tells)");
+  int wg = 0;
+  for (int g = 0; g < n; ++g) {
+    WgradParams& p = gp.g[g];
+    AOD_CHECK_ARG(sp[g] <= nslabs[g], "wgrad_grouped: member %d needs %d slabs, %d provided", g, sp[g], nslabs[g]);
+    AOD_CHECK_ARG(slab_stride[g] >= (long long)p.N * p.K, "wgrad_grouped: slab stride smaller than N*K");
+    p.tiles_n = tn[g]; p.tiles_k = tk[g]; p.splits = sp[g]; p.rows_per_split = rps[g]; p.slab_stride = slab_stride[g];
+    gp.wg0[g] = wg;
+    wg += tn[g] * tk[g] * sp[g];
+  }
+  for (int g = n; g <= WG_MAXG; ++g) gp.wg0[g] = g == n ? wg : 0x7fffffff;
+  gp.n = n;
+  wgrad_attrs();
+  if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 1, 1>), dim3(wg), dim3(512), 65536 + 4096, (hipStream_t)stream, gp);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -1417,15 +1530,18 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ d
 // through LDS and writes the OIHW gradient with consecutive lanes on consecutive elements.
 constexpr int UNP_CH = 1024;      // channels per LDS chunk (x RS <= 9 taps)
 constexpr int UNP_T = 1024;       // threads: 16 waves per block keep enough slab loads in flight (one block per output channel)
-__global__ __launch_bounds__(UNP_T) void unpack_wgrad_slabs_kernel(const float* __restrict__ dw, int nslabs, long long slab_stride,
-                                                                  float* __restrict__ g, const float* __restrict__ scale,
-                                                                  const float* __restrict__ w, float* __restrict__ wdot,
-                                                                  const float* __restrict__ bn_s1, const float* __restrict__ bn_mean,
-                                                                  const float* __restrict__ bn_invstd, int O, int I, int RS, int Ipad, int accumulate) {
-  __shared__ float tile[UNP_CH * 9 + 1];
-  __shared__ float red[UNP_T / 64];
-  const int oo = blockIdx.x;
-  const float sc = scale ? scale[oo] : 1.f;
+struct UnpackArgs {
+  const float* dw; float* g; const float* scale; const float* w; float* wdot; const float* bn_s1; const float* bn_mean; const float* bn_invstd;
+  long long slab_stride;
+  int nslabs, O, I, RS, Ipad, accumulate;
+};
+__device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* tile, float* red) {
+  const float* __restrict__ dw = a.dw;
+  float* __restrict__ g = a.g;
+  const float* __restrict__ w = a.w;
+  const int nslabs = a.nslabs, I = a.I, RS = a.RS, Ipad = a.Ipad, accumulate = a.accumulate;
+  const long long slab_stride = a.slab_stride;
+  const float sc = a.scale ? a.scale[oo] : 1.f;
   float dot = 0.f;
   for (int c0 = 0; c0 < I; c0 += UNP_CH) {
     const int nc = min(UNP_CH, I - c0);
@@ -1451,16 +1567,32 @@ __global__ __launch_bounds__(UNP_T) void unpack_wgrad_slabs_kernel(const float* 
     }
     __syncthreads();
   }
-  if (wdot) {
+  if (a.wdot) {
     dot = wave_sum(dot);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
     __syncthreads();
     if (threadIdx.x == 0) {
       float d = 0.f;
       for (int k = 0; k < UNP_T / 64; ++k) d += red[k];
-      wdot[oo] = bn_s1 ? bn_invstd[oo] * (d - bn_mean[oo] * bn_s1[oo]) : d;
+      a.wdot[oo] = a.bn_s1 ? a.bn_invstd[oo] * (d - a.bn_mean[oo] * a.bn_s1[oo]) : d;
     }
   }
+}
+__global__ __launch_bounds__(UNP_T) void unpack_wgrad_slabs_kernel(const UnpackArgs a) {
+  __shared__ float tile[UNP_CH * 9 + 1];
+  __shared__ float red[UNP_T / 64];
+  unpack_row(a, blockIdx.x, tile, red);
+}
+// the unpacks of a grouped wgrad launch in one grid: block -> (member, output channel)
+struct UnpackGroups { UnpackArgs g[WG_MAXG]; int blk0[WG_MAXG + 1]; };
+__global__ __launch_bounds__(UNP_T) void unpack_wgrad_slabs_grouped_kernel(const UnpackGroups gp) {
+  __shared__ float tile[UNP_CH * 9 + 1];
+  __shared__ float red[UNP_T / 64];
+  const int b = blockIdx.x;
+  if (b < gp.blk0[1]) unpack_row(gp.g[0], b, tile, red);
+  else if (b < gp.blk0[2]) unpack_row(gp.g[1], b - gp.blk0[1], tile, red);
+  else if (b < gp.blk0[3]) unpack_row(gp.g[2], b - gp.blk0[2], tile, red);
+  else unpack_row(gp.g[3], b - gp.blk0[3], tile, red);
 }
 // ---- batched parameter preparation: ONE launch re-derives, for every registered conv layer, the folded eval-BN vectors
 // (scale = gamma * rsqrt(var + eps), shift = beta - mean * scale, invstd) and both packed bf16 weight images (forward
@@ -1594,8 +1726,37 @@ extern "C" int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t
   AOD_CHECK_ARG(!wdot || w_oihw, "unpack_wgrad_slabs: wdot needs the weights");
   AOD_CHECK_ARG(!bn_s1 || (wdot && bn_mean && bn_invstd), "unpack_wgrad_slabs: BN mode needs wdot, mean and invstd");
   if (O == 0) return 0;
-  hipLaunchKernelGGL(unpack_wgrad_slabs_kernel, dim3(O), dim3(UNP_T), 0, (hipStream_t)stream, dw_slabs, nslabs, (long long)slab_stride, g, scale,
-                     w_oihw, wdot, bn_s1, bn_mean, bn_invstd, O, I, R * S, Ipad, accumulate);
+  UnpackArgs a;
+  a.dw = dw_slabs; a.g = g; a.scale = scale; a.w = w_oihw; a.wdot = wdot; a.bn_s1 = bn_s1; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+  a.slab_stride = slab_stride; a.nslabs = nslabs; a.O = O; a.I = I; a.RS = R * S; a.Ipad = Ipad; a.accumulate = accumulate;
+  hipLaunchKernelGGL(unpack_wgrad_slabs_kernel, dim3(O), dim3(UNP_T), 0, (hipStream_t)stream, a);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_unpack_wgrad_slabs_grouped(int n, const float* const* dw_slabs, const int32_t* nslabs, const int64_t* slab_stride,
+                                              float* const* g, const int32_t* O, const int32_t* I, const int32_t* R, const int32_t* S,
+                                              const int32_t* Ipad, const int32_t* accumulate, const float* const* scale,
+                                              const float* const* w_oihw, float* const* wdot, const float* const* bn_s1,
+                                              const float* const* bn_mean, const float* const* bn_invstd, aod_stream_t stream) {
+  AOD_CHECK_ARG(n >= 1 && n <= WG_MAXG && dw_slabs && nslabs && slab_stride && g && O && I && R && S && Ipad && accumulate && scale &&
+                w_oihw && wdot && bn_s1 && bn_mean && bn_invstd, "unpack_wgrad_slabs_grouped: 1..4 members, no null arrays");
+  UnpackGroups gp;
+  memset(&gp, 0, sizeof(gp));
+  int blk = 0;
+  for (int i = 0; i < n; ++i) {
+    AOD_CHECK_ARG(dw_slabs[i] && g[i] && nslabs[i] >= 1 && slab_stride[i] > 0 && O[i] >= 1, "unpack_wgrad_slabs_grouped: null / empty member");
+    AOD_CHECK_ARG(R[i] * S[i] <= 9, "unpack_wgrad_slabs_grouped: at most 9 taps");
+    AOD_CHECK_ARG(!wdot[i] || w_oihw[i], "unpack_wgrad_slabs_grouped: wdot needs the weights");
+    AOD_CHECK_ARG(!bn_s1[i] || (wdot[i] && bn_mean[i] && bn_invstd[i]), "unpack_wgrad_slabs_grouped: BN mode needs wdot, mean and invstd");
+    UnpackArgs& a = gp.g[i];
+    a.dw = dw_slabs[i]; a.g = g[i]; a.scale = scale[i]; a.w = w_oihw[i]; a.wdot = wdot[i]; a.bn_s1 = bn_s1[i]; a.bn_mean = bn_mean[i];
+    a.bn_invstd = bn_invstd[i];
+    a.slab_stride = slab_stride[i]; a.nslabs = nslabs[i]; a.O = O[i]; a.I = I[i]; a.RS = R[i] * S[i]; a.Ipad = Ipad[i]; a.accumulate = accumulate[i];
+    gp.blk0[i] = blk;
+    blk += O[i];
+  }
+  for (int i = n; i <= WG_MAXG; ++i) gp.blk0[i] = i == n ? blk : 0x7fffffff;
+  hipLaunchKernelGGL(unpack_wgrad_slabs_grouped_kernel, dim3(blk), dim3(UNP_T), 0, (hipStream_t)stream, gp);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -336,6 +336,62 @@ def _grad_slice(w, device):
     return dst
 
 
+class _WgradQueue:
+    """Weight gradients of consecutive convs are LAUNCHED TOGETHER (hipops.wgrad_unpack_group: one grouped wgrad + one grouped unpack for up
+    to four layers).  Alone a backbone layer needs 100+ pixel splits of its few tiles to fill the chip and leaves as many partial slabs (a
+    256-KB filter: 30 MB); in a group every member needs a fraction of them.  A conv's backward therefore only QUEUES its weight gradient
+    and returns the (not yet written) gradient tensors; the queue is flushed when it holds four jobs, when a job cannot share the grid of
+    the waiting ones, and at the end of the backward pass (autograd callback) -- i.e. before anything can read a gradient:
+      * autograd installs a returned tensor as .grad without reading it only if .grad is None and nothing else refers to the tensor (the job
+        keeps aliases); a parameter whose .grad exists, or that is used twice in one pass (the engine adds the two gradients when the second
+        arrives), is not deferred -- and the second use flushes the queue first;
+      * segmented backward passes (data parallelism) are separate engine runs: every segment's gradients are complete when its run returns."""
+    jobs, seen, armed = [], set(), False
+    enabled = _os.environ.get('AOD_WGRAD_GROUP', '1') != '0'
+
+    @classmethod
+    def flush(cls):
+        jobs, cls.jobs = cls.jobs, []
+        if jobs:
+            ho.wgrad_unpack_group(jobs)
+
+    @classmethod
+    def _end_of_pass(cls):
+        cls.armed = False
+        cls.seen.clear()
+        cls.flush()
+
+    @classmethod
+    def submit(cls, job, wid, defer):
+        if not cls.armed:
+            cls.armed = True
+            cls.seen.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_pass)
+        if wid in cls.seen or not (defer and cls.enabled):
+            cls.flush()
+            job.run_alone()
+            cls.seen.add(wid)
+            return
+        cls.seen.add(wid)
+        if cls.jobs and ho.wgrad_group_splits(cls.jobs + [job]) is None:
+            cls.flush()
+        cls.jobs.append(job)
+        if len(cls.jobs) == 4:
+            cls.flush()
+
+
+def _wgrad(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, w, O, I, dst, scale=None, bn=None, gamma=None):
+    """weight gradient (+ BN weight gradient when bn = (s1, mean, invstd)) of one conv through the queue -> (gw, ggamma)"""
+    dev = dz.device
+    gw = dst if dst is not None else torch.empty(O, I, R, S, dtype=torch.float32, device=dev)
+    wdot = torch.empty(O, dtype=torch.float32, device=dev) if bn is not None else None
+    job = ho.WgradJob(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, O, I, gw.detach(), scale=scale,
+                      w=w.detach() if bn is not None else None, wdot=wdot.detach() if wdot is not None else None, bn=bn)
+    defer = R * S <= 9 and w.grad is None and (gamma is None or gamma.grad is None)
+    _WgradQueue.submit(job, id(w), defer)
+    return gw, wdot
+
+
 class ConvFn(Function):
     """y = act(conv(x, w) * scale + shift + res) over one or several pyramid levels sharing `w`.
 
@@ -417,13 +473,11 @@ class ConvFn(Function):
                 gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
         x_segs = ctx.x_segs
         if need_w or need_bn:
-            dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'], alg=(I, O))
-            dst = _grad_slice(w, dw.device) if need_w else None
+            dst = _grad_slice(w, dz.device) if need_w else None
+            gw, ggamma = _wgrad(x_rows, x_segs, dz, dsegs, R, S, meta['stride'], meta['pad'], meta['dil'], (I, O), w, O, I, dst,
+                                scale=scale if ctx.has_bn else None, bn=(s1, mean, invstd) if need_bn else None, gamma=gamma if need_bn else None)
             if need_bn:
-                gw, ggamma = ho.unpack_wgrad(dw, O, I, grad_oihw=dst, scale=scale, w_oihw=w.detach(), want_wdot=True, bn=(s1, mean, invstd))
                 gbeta = s1
-            else:
-                gw = ho.unpack_wgrad(dw, O, I, grad_oihw=dst, scale=scale if ctx.has_bn else None)
             if not need_w:
                 gw = None
         gxs = [None] * ctx.nx
@@ -576,8 +630,7 @@ class ConvPairFn(Function):
             gbs.append(s1[:O] if ctx.needs_input_grad[2 + 2 * gi] else None)
             gw = None
             if ctx.needs_input_grad[1 + 2 * gi]:
-                dw = ho.conv2d_wgrad_rows(x_rows, x_segs, dz, dsegs, R, S, 1, meta['pad'], meta['dil'], alg=(I, O))
-                gw = ho.unpack_wgrad(dw, O, I, grad_oihw=_grad_slice(w, dw.device))
+                gw, _ = _wgrad(x_rows, x_segs, dz, dsegs, R, S, 1, meta['pad'], meta['dil'], (I, O), w, O, I, _grad_slice(w, dz.device))
             gws.append(gw)
         gxs = [None] * (2 * nl)
         need = [any(ctx.needs_input_grad[5 + gi * nl:5 + (gi + 1) * nl]) for gi in range(2)]

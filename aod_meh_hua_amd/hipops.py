@@ -235,6 +235,81 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     return out
 
 
+def _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, device):
+    if len(_ROW_TABLES) > 512:
+        _ROW_TABLES.clear()
+    key = (tuple(x_segs), tuple(dz_segs), Cin, Npad, R, S, stride, pad, dil, device.index)
+    tab = _ROW_TABLES.get(key)
+    if tab is None:
+        tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=device)
+        call('aod_conv_row_table', C.byref(d), ptr(tab), stream())
+        _ROW_TABLES[key] = tab
+    return tab
+
+
+class WgradJob:
+    """One weight gradient waiting for its launch: operands of conv2d_wgrad_rows + destinations of unpack_wgrad (all preallocated)."""
+    __slots__ = ('x_rows', 'x_segs', 'dz', 'dz_segs', 'R', 'S', 'stride', 'pad', 'dil', 'alg', 'O', 'I', 'gw', 'scale', 'w', 'wdot', 'bn',
+                 'desc')
+
+    def __init__(self, x_rows, x_segs, dz, dz_segs, R, S, stride, pad, dil, alg, O, I, gw, scale=None, w=None, wdot=None, bn=None):
+        self.x_rows, self.x_segs, self.dz, self.dz_segs = x_rows, x_segs, dz, dz_segs
+        self.R, self.S, self.stride, self.pad, self.dil, self.alg, self.O, self.I = R, S, stride, pad, dil, alg, O, I
+        self.gw, self.scale, self.w, self.wdot, self.bn = gw, scale, w, wdot, bn
+        self.desc = make_desc(x_rows.shape[1], dz.shape[1], R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
+
+    def run_alone(self):
+        dw = conv2d_wgrad_rows(self.x_rows, self.x_segs, self.dz, self.dz_segs, self.R, self.S, self.stride, self.pad, self.dil, alg=self.alg)
+        unpack_wgrad(dw, self.O, self.I, grad_oihw=self.gw, scale=self.scale, w_oihw=self.w, want_wdot=self.wdot is not None, bn=self.bn,
+                     wdot=self.wdot)
+
+
+def wgrad_group_splits(jobs):
+    """slab counts of the jobs as ONE grouped launch (aod_conv2d_wgrad_group_plan), or None when they cannot share a grid (mixed tile
+    forms, more than 9 taps, slab form switched off)"""
+    n = len(jobs)
+    if n > 4 or not SLAB_WGRAD or any(j.R * j.S > 9 for j in jobs):
+        return None
+    splits = (C.c_int32 * n)()
+    rc = _C.lib.aod_conv2d_wgrad_group_plan((C.c_void_p * n)(*[C.addressof(j.desc) for j in jobs]), n, splits)
+    return list(splits) if rc == 0 else None
+
+
+def wgrad_unpack_group(jobs):
+    """weight gradients of up to four convs: one grouped wgrad launch + one grouped unpack (aod_conv2d_wgrad_grouped,
+    aod_unpack_wgrad_slabs_grouped); a single job, or jobs that cannot share a grid, run as before"""
+    splits = wgrad_group_splits(jobs) if len(jobs) > 1 else None
+    if splits is None:
+        for j in jobs:
+            j.run_alone()
+        return
+    n = len(jobs)
+    dev = jobs[0].dz.device
+    strides = [j.dz.shape[1] * j.R * j.S * j.x_rows.shape[1] for j in jobs]
+    offs, tot = [], 0
+    for sp, st in zip(splits, strides):
+        offs.append(tot)
+        tot += sp * st
+    buf = _slab_scratch(tot, dev)
+    slabs = [buf[o:o + sp * st] for o, sp, st in zip(offs, splits, strides)]
+    tabs = [_row_table(j.desc, j.x_segs, j.dz_segs, j.x_rows.shape[1], j.dz.shape[1], j.R, j.S, j.stride, j.pad, j.dil, dev) for j in jobs]
+    PA, I32A, I64A = C.c_void_p * n, C.c_int32 * n, C.c_int64 * n
+    pv = lambda ts: PA(*[(ptr(t).value if t is not None else None) for t in ts])
+
+    def launch():
+        call('aod_conv2d_wgrad_grouped', PA(*[C.addressof(j.desc) for j in jobs]), n, pv([j.x_rows for j in jobs]), pv([j.dz for j in jobs]),
+             pv(slabs), I32A(*splits), I64A(*strides), pv(tabs), stream())
+    ms = [sum(sg.B * sg.H * sg.W for sg in j.dz_segs) for j in jobs]
+    flops = sum(2.0 * m * j.R * j.S * (j.alg[0] * j.alg[1] if j.alg is not None else j.dz.shape[1] * j.x_rows.shape[1]) for m, j in zip(ms, jobs))
+    # (per-shape listings show the group as one line: rows of the first member, summed N x K)
+    prof_flops('wgrad', (ms[0], sum(j.dz.shape[1] for j in jobs), sum(j.R * j.S * j.x_rows.shape[1] for j in jobs), 10 + n, 1), flops, launch)
+    ws = [j.w.contiguous() if (j.wdot is not None and j.w is not None) else None for j in jobs]
+    call('aod_unpack_wgrad_slabs_grouped', n, pv(slabs), I32A(*splits), I64A(*strides), pv([j.gw for j in jobs]), I32A(*[j.O for j in jobs]),
+         I32A(*[j.I for j in jobs]), I32A(*[j.R for j in jobs]), I32A(*[j.S for j in jobs]), I32A(*[j.x_rows.shape[1] for j in jobs]),
+         I32A(*[0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
+         pv([j.bn[1] if j.bn else None for j in jobs]), pv([j.bn[2] if j.bn else None for j in jobs]), stream())
+
+
 def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None, alg=None):
     """dW of a conv: with `dw` given, [Npad][R][S][C] fp32 ACCUMULATED into it (fp32 atomics); otherwise the deterministic slab form --
     returns [nslabs][Npad][R][S][C] partial sums in a per-device scratch (valid until the next wgrad launch; unpack_wgrad adds them)."""
@@ -245,14 +320,7 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
         nslabs = int(lib.aod_conv2d_wgrad_splits(C.byref(d)))
     if dw is None and nslabs == 0:
         dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
-    if len(_ROW_TABLES) > 512:
-        _ROW_TABLES.clear()
-    key = (tuple(x_segs), tuple(dz_segs), Cin, Npad, R, S, stride, pad, dil, x_rows.device.index)
-    tab = _ROW_TABLES.get(key)
-    if tab is None:
-        tab = torch.empty(max(int(_C.lib.aod_conv_row_table_bytes(C.byref(d))), 16), dtype=torch.uint8, device=x_rows.device)
-        call('aod_conv_row_table', C.byref(d), ptr(tab), stream())
-        _ROW_TABLES[key] = tab
+    tab = _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, x_rows.device)
     if nslabs:
         stride_ = Npad * R * S * Cin
         slabs = _slab_scratch(nslabs * stride_, x_rows.device).view(nslabs, Npad, R, S, Cin)
@@ -308,14 +376,15 @@ def reset_zero_arena():
     _ZEROS.clear()
 
 
-def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None):
+def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None, wdot=None):
     """Returns grad_oihw, or (grad_oihw, wdot) with wdot[o] = <w[o], dw[o]> when want_wdot; with bn = (s1, mean, invstd) wdot is the
     BatchNorm weight gradient invstd * (<w, dw> - mean * s1)."""
     if dw_orsi.dim() == 5:          # slab form (conv2d_wgrad_rows without `dw`)
         nslabs, Opad, R, S, Ipad = dw_orsi.shape
         if grad_oihw is None:
             grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
-        wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
+        if wdot is None:
+            wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
         call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), ptr(scale),
              ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
              ptr(bn[2]) if bn else None, stream())
@@ -329,7 +398,8 @@ def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, sc
     if clear and (O != Opad or I != Ipad):
         # dZ pad columns / x pad channels are zero, so wgrad added exact zeros there: nothing to clear beyond [O, I]
         pass
-    wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
+    if wdot is None:
+        wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
     call('aod_unpack_wgrad', ptr(dw_orsi), ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), int(bool(clear)), ptr(scale),
          ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
          ptr(bn[2]) if bn else None, stream())

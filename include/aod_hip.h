@@ -140,6 +140,14 @@ int aod_conv2d_wgrad(const aod_conv_desc_t* desc, const void* x, const void* dz,
 int aod_conv2d_wgrad_splits(const aod_conv_desc_t* desc);
 int aod_conv2d_wgrad_slabs(const aod_conv_desc_t* desc, const void* x, const void* dz, float* slabs, int nslabs, int64_t slab_stride,
                            const void* row_table, aod_stream_t stream);
+/* Grouped form: the weight gradients of n (<= 4) convolutions of ANY geometries in one grid -- e.g. the three convs of a bottleneck once
+ * its dgrad chain has produced all three gradients.  Alone a backbone layer needs 100+ pixel splits of its few tiles to fill the chip and
+ * leaves that many partial slabs; together each needs a fraction of them.  aod_conv2d_wgrad_group_plan: splits_out[i] = slabs member i
+ * needs; returns 1 (nothing written) when the members do not share a tile form -- launch them one by one then.  All arrays are HOST
+ * arrays of n entries.  Results differ from the single launches by the association of the pixel sum only (other split boundaries). */
+int aod_conv2d_wgrad_group_plan(const aod_conv_desc_t* const* descs, int n, int32_t* splits_out);
+int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int n, const void* const* x, const void* const* dz, float* const* slabs,
+                             const int32_t* nslabs, const int64_t* slab_stride, const void* const* row_table, aod_stream_t stream);
 /* Row table of a forward descriptor (32 B per destination pixel: source block origin, top-left tap, extents,
  * dZ row).  Depends only on segment geometry / stride / pad / filter size: build once, reuse for every wgrad
  * launch with that geometry. */
@@ -166,6 +174,12 @@ int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t slab_strid
                            int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
                            const float* bn_mean, const float* bn_invstd, aod_stream_t stream);
 
+/* ... and the unpacks of a grouped launch in one grid (arrays of n <= 4 entries; entries of scale / w_oihw / wdot / bn_* may be NULL). */
+int aod_unpack_wgrad_slabs_grouped(int n, const float* const* dw_slabs, const int32_t* nslabs, const int64_t* slab_stride, float* const* g,
+                                   const int32_t* O, const int32_t* I, const int32_t* R, const int32_t* S, const int32_t* Ipad,
+                                   const int32_t* accumulate, const float* const* scale, const float* const* w_oihw, float* const* wdot,
+                                   const float* const* bn_s1, const float* const* bn_mean, const float* const* bn_invstd,
+                                   aod_stream_t stream);
 /* Batched re-derivation of everything the conv launches read from the parameters, for ALL layers in one launch (after an optimizer
  * step every trainable layer is stale): items_dev = device array of `nitems` records of aod_param_prep_item_bytes() bytes,
  *   { const float* w_oihw, gamma, beta, mean, var;  void* w_fwd_packed, w_dgrad_packed;  float* scale, shift, invstd;
