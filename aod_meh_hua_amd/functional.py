@@ -228,10 +228,14 @@ class GradAcc:
     and hands back None until the last registered consumer has run, which returns the total.  Consumers register in forward
     (conv_bn_act(shared_input=True)), so the count is exactly the convs that were applied to the tensor; `check_junctions()` (called when the
     next iteration starts) fails loudly if a registered consumer never ran its backward and a partial sum was left behind."""
-    __slots__ = ('n', 'arrived', 'partial', '__weakref__')
+    __slots__ = ('n', 'arrived', 'partial', 'slot', '__weakref__')
 
-    def __init__(self):
+    def __init__(self, slot=None):
         self.n, self.arrived, self.partial = 0, 0, None
+        # ActSlot of the conv that PRODUCED the tensor (a stage output is the ReLU output of the last block's conv3): the last consumer's
+        # dgrad epilogue then also applies that ReLU's mask to the finished sum and column-sums it -- the producer's backward starts from the
+        # masked gradient instead of an elementwise pass over the stage output (aod_act_bwd: 54 us for C3)
+        self.slot = slot
 
 
 _JUNCTIONS = []
@@ -240,7 +244,7 @@ _JUNCTIONS = []
 def share_input_grad(x):
     """mark `x` (a tensor that requires grad, about to feed several convs) as a gradient junction"""
     if torch.is_grad_enabled() and x.requires_grad and _PREC == 'bf16' and _os.environ.get('AOD_GRAD_JUNCTIONS', '1') != '0':
-        x._aod_acc = GradAcc()
+        x._aod_acc = GradAcc(getattr(x, '_aod_slot', None) if _FUSE_ACT and _os.environ.get('AOD_JUNCTION_MASK', '1') != '0' else None)
         _JUNCTIONS.append(_weakref.ref(x._aod_acc))
     return x
 
@@ -286,6 +290,8 @@ def cut(x):
     if _CUTS is None or not torch.is_grad_enabled() or not x.requires_grad or _PREC != 'bf16':
         return x
     xc = x.detach().requires_grad_()
+    if getattr(x, '_aod_slot', None) is not None:
+        xc._aod_slot = x._aod_slot          # the junction on the copy finishes the producer's activation backward across the cut (GradAcc.slot)
     _CUTS.append((x, xc))
     return xc
 
@@ -336,6 +342,9 @@ def _grad_slice(w, device):
     return dst
 
 
+_S1_OF = {}      # data_ptr of a masked gradient handed to a residual branch -> (its column sums, the tensor); emptied after every pass
+
+
 class _WgradQueue:
     """Weight gradients of consecutive convs are LAUNCHED TOGETHER (hipops.wgrad_unpack_group: one grouped wgrad + one grouped unpack for up
     to four layers).  Alone a backbone layer needs 100+ pixel splits of its few tiles to fill the chip and leaves as many partial slabs (a
@@ -359,6 +368,7 @@ class _WgradQueue:
     def _end_of_pass(cls):
         cls.armed = False
         cls.seen.clear()
+        _S1_OF.clear()
         cls.flush()
 
     @classmethod
@@ -457,9 +467,13 @@ class ConvFn(Function):
                 slot.masked, slot.s1 = False, None
             else:
                 plain = (not relu) and g_rows.dtype == torch.bfloat16
-                dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=False, want_dz=not plain)
-                if plain:
-                    dz = g_rows
+                known = _S1_OF.pop(g_rows.data_ptr(), None) if plain and _os.environ.get('AOD_S1_REUSE', '1') != '0' else None
+                if known is not None and known[1].shape == g_rows.shape:
+                    dz, s1 = g_rows, known[0]       # the gradient of a residual branch IS the block's masked gradient: its column sums exist
+                else:
+                    dz, _, s1, _ = ho.act_bwd(g_rows, a_rows, None, None, None, None, relu=relu, want_gm=False, want_dz=not plain)
+                    if plain:
+                        dz = g_rows
             gbias_v = s1
         need_bn = ctx.has_bn and ctx.needs_input_grad[2]
         if ctx.has_bias and ctx.needs_input_grad[6]:
@@ -471,6 +485,10 @@ class ConvFn(Function):
             else:
                 s = y_segs[0]
                 gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
+                if Opad == O and len(y_segs) == 1:
+                    # ... so a conv without ReLU at the end of that branch (the downsample conv + BN of a block's first bottleneck) needs no
+                    # pass of its own for the column sums; the entry keeps dz alive, so its address cannot be handed out again meanwhile
+                    _S1_OF[dz.data_ptr()] = (s1, dz)
         x_segs = ctx.x_segs
         if need_w or need_bn:
             dst = _grad_slice(w, dz.device) if need_w else None
@@ -493,9 +511,13 @@ class ConvFn(Function):
             if res_g is not None and not fuse:
                 raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')
             acc = meta.get('in_acc')
+            jslot = None
             if acc is not None:                 # gradient junction: the running sum of the other consumers' dX rides on this dgrad's epilogue
                 assert not fuse and len(xd) == 1
                 res_g = acc.partial
+                if acc.arrived == acc.n - 1 and acc.slot is not None and dz.dtype == torch.bfloat16 and xd[0].row0 == x_segs[0].row0:
+                    jslot = acc.slot            # last consumer: its epilogue finishes the producer's activation backward as well
+                    s1_in = ho.zeros_f32(cin, dz.device)
             ch, role = meta.get('chain') or (None, 0)
             dx = None
             if ch is not None and fuse and acc is None and dz.dtype == torch.bfloat16:
@@ -514,9 +536,11 @@ class ConvFn(Function):
                         ch.meta.clear(), ch.x_rows.clear(), ch.prep.clear()
             if dx is None:
                 dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
-                                          res=res_g, mask=x_rows if fuse else None, colsum=s1_in, alg=(I, O))
+                                          res=res_g, mask=x_rows if (fuse or jslot is not None) else None, colsum=s1_in, alg=(I, O))
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
+            if jslot is not None:
+                jslot.masked, jslot.s1 = True, s1_in
             gxs = [as_nchw(dx[s.row0:s.row0 + s.rows], s.B, s.H, s.W) if ctx.needs_input_grad[8 + i] else None
                    for i, s in enumerate(xd)]
             if acc is not None:
