@@ -629,8 +629,20 @@ class ConvPairFn(Function):
         assert segs[0] == segs[1] and wB.shape == wA.shape, 'paired tower convs need identical geometry'
         cin = rows[0].shape[1]
         pis = [PREP.get(w, None, cin, 0.0) for w in (wA, wB)]
-        outs, y_segs = ho.conv2d_rows_grouped(list(rows), list(segs[0]), [pi.wf for pi in pis], O, R, S, 1, meta['pad'], meta['dil'],
-                                              pre_shifts=[bA.detach(), bB.detach()], relu=True, alg=(I, O))
+        rows, wfs, shifts = list(rows), [pi.wf for pi in pis], [bA.detach(), bB.detach()]
+        rider = meta.get('rider')
+        if rider is not None:
+            # a third conv of the same geometry that belongs to ANOTHER autograd pass (the MEH tower on the detached pyramid, trained by its
+            # own loss and optimizer right after this pass): its forward rides in this grid -- 3 x 341 tiles = 3.996 rounds of the CUs instead
+            # of 2.66 + 1.33 -- and its output waits in meta['rider_out'] for the conv_bn_act(pre=...) call that records its autograd node
+            convL, xL = rider
+            rows.append(xL)
+            wfs.append(PREP.get(convL.weight, None, cin, 0.0).wf)
+            shifts.append(convL.bias.detach())
+        outs, y_segs = ho.conv2d_rows_grouped(rows, list(segs[0]), wfs, O, R, S, 1, meta['pad'], meta['dil'], pre_shifts=shifts, relu=True,
+                                              alg=(I, O))
+        if rider is not None:
+            meta['rider_out'] = outs[2]
         ctx.meta, ctx.x_segs, ctx.y_segs, ctx.nl = meta, list(segs[0]), y_segs, nl
         ctx.save_for_backward(wA, wB, rows[0], rows[1], outs[0], outs[1])
         return tuple(as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for o in outs for s in y_segs)
@@ -676,9 +688,10 @@ class ConvPairFn(Function):
         return (None, gws[0], gbs[0], gws[1], gbs[1]) + tuple(gxs)
 
 
-def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False):
+def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False, rider=None):
     """cls / reg tower convs of one depth (ConvModule.conv holders: weight, bias, padding, dilation) on their own level lists; falls back to
-    two conv_bn_act calls whenever the grouped form does not apply."""
+    two conv_bn_act calls whenever the grouped form does not apply.  rider = (conv holder, input rows [M, C]): a third conv of the same shape
+    whose forward (no autograd) is computed in the same launch; then returns (ya, yb, rider output rows or None)."""
     import os
     wA, wB = convA.weight, convB.weight
     ok = (_PREC == 'bf16' and os.environ.get('AOD_GROUP_TOWERS', '1') != '0' and wA.shape == wB.shape and wA.shape[0] % 8 == 0
@@ -686,9 +699,15 @@ def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False):
           and convA.padding == convB.padding and convA.dilation == convB.dilation and len(xsA) == len(xsB)
           and all(a.shape == b.shape and a.dtype == torch.bfloat16 for a, b in zip(xsA, xsB)))
     if not ok:
-        return (conv_bn_act(list(xsA), wA, bias=convA.bias, pad=convA.padding[0], dil=convA.dilation[0], relu=True, sole_consumer=sole_consumer),
-                conv_bn_act(list(xsB), wB, bias=convB.bias, pad=convB.padding[0], dil=convB.dilation[0], relu=True, sole_consumer=sole_consumer))
+        r = (conv_bn_act(list(xsA), wA, bias=convA.bias, pad=convA.padding[0], dil=convA.dilation[0], relu=True, sole_consumer=sole_consumer),
+             conv_bn_act(list(xsB), wB, bias=convB.bias, pad=convB.padding[0], dil=convB.dilation[0], relu=True, sole_consumer=sole_consumer))
+        return r if rider is None else r + (None,)
     meta = dict(pad=convA.padding[0], dil=convA.dilation[0], slot=[None, None], in_slot=[None, None])
+    if rider is not None:
+        cl = rider[0]
+        if (cl.weight.shape == wA.shape and cl.bias is not None and cl.padding == convA.padding and cl.dilation == convA.dilation
+                and cl.stride[0] == 1 and rider[1].dtype == torch.bfloat16):
+            meta['rider'] = rider
     grad = torch.is_grad_enabled()
     if grad:
         meta['slot'] = [ActSlot(), ActSlot()]
@@ -705,7 +724,7 @@ def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False):
         for gi, ys in enumerate((ya, yb)):
             for o in ys:
                 o._aod_slot = meta['slot'][gi]
-    return ya, yb
+    return (ya, yb) if rider is None else (ya, yb, meta.get('rider_out'))
 
 
 def conv_towers_nograd(xss, convs, relu=True):

@@ -389,8 +389,8 @@ class ConvModule(nn.Module):
         if self.with_activation:
             self.activate = nn.ReLU(inplace=inplace)
 
-    def forward(self, x, out=None, sole_consumer=False, shared_input=False):
-        return self.conv(x, relu=self.with_activation, out=out, sole_consumer=sole_consumer, shared_input=shared_input)
+    def forward(self, x, out=None, sole_consumer=False, shared_input=False, pre=None):
+        return self.conv(x, relu=self.with_activation, out=out, sole_consumer=sole_consumer, shared_input=shared_input, pre=pre)
 
 
 # ------------------------------------------------------------------------------ data containers / parallel

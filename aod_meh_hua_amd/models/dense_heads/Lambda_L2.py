@@ -62,8 +62,23 @@ class Lambda_L2Net(L_AnchorHead):
         cls_feat, reg_feat = feats, feats
         if len(self.cls_convs) == len(self.reg_convs) and all(m.with_activation for m in list(self.cls_convs) + list(self.reg_convs)):
             # the two towers advance together: one grouped launch per depth (functional.ConvPairFn)
+            # training: the MEH tower's forward (forward_L below, on the same -- detached -- pyramid, run by train_step_L right after this pass)
+            # rides in the same grouped launches; forward_L then only records its autograd nodes around the stored outputs
+            import os
+            ride = (torch.is_grad_enabled() and self.training and os.environ.get('AOD_MEH_RIDER', '1') != '0'
+                    and len(self.L_convs) == len(self.cls_convs) and all(m.with_activation for m in self.L_convs)
+                    and feats[0].dtype == torch.bfloat16)
+            self._L_pre = None
+            L_rows, L_outs = (AF.multi_rows([f.detach() for f in feats])[0] if ride else None), []
             for i, (cc, rc) in enumerate(zip(self.cls_convs, self.reg_convs)):          # every tower activation has exactly one consumer
-                cls_feat, reg_feat = AF.conv_pair_act(cls_feat, reg_feat, cc.conv, rc.conv, sole_consumer=i > 0)
+                if L_rows is not None:
+                    cls_feat, reg_feat, L_rows = AF.conv_pair_act(cls_feat, reg_feat, cc.conv, rc.conv, sole_consumer=i > 0,
+                                                                  rider=(self.L_convs[i].conv, L_rows))
+                    L_outs.append(L_rows)
+                else:
+                    cls_feat, reg_feat = AF.conv_pair_act(cls_feat, reg_feat, cc.conv, rc.conv, sole_consumer=i > 0)
+            if ride and len(L_outs) == len(self.L_convs) and all(o is not None for o in L_outs):
+                self._L_pre = (feats[0].data_ptr(), tuple(feats[0].shape), [m.conv.weight._version for m in self.L_convs], L_outs)
         else:
             for i, conv in enumerate(self.cls_convs):
                 cls_feat = conv(cls_feat, sole_consumer=i > 0)
@@ -75,8 +90,12 @@ class Lambda_L2Net(L_AnchorHead):
     def forward_L(self, feats, head_out=None, **kwargs):
         """Lambda_L2.py:82-83,96-103: MEH tower + retina_L + ReLU (fused)."""
         L_feat = list(feats)
+        pre, self._L_pre = getattr(self, '_L_pre', None), None
+        if pre is not None and not (torch.is_grad_enabled() and pre[0] == L_feat[0].data_ptr() and pre[1] == tuple(L_feat[0].shape)
+                                    and pre[2] == [m.conv.weight._version for m in self.L_convs]):
+            pre = None                  # another pyramid, or the tower's weights changed since forward(): compute it here
         for i, conv in enumerate(self.L_convs):
-            L_feat = conv(L_feat, sole_consumer=i > 0)
+            L_feat = conv(L_feat, sole_consumer=i > 0, pre=pre[3][i] if pre is not None else None)
         return self.retina_L(L_feat, relu=True, out_f32=True, sole_consumer=len(self.L_convs) > 0)
 
     def forward_single(self, x):

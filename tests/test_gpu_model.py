@@ -330,3 +330,46 @@ def test_fused_bottleneck_backward_equals_the_three_dgrad_launches(built, monkey
             scale = float(a.abs().max()) + 1e-12
             assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-7, (n_, float((a - b).abs().max()), scale)
     assert float(res['1'][0].float().abs().mean()) > 0
+
+
+def test_meh_tower_forward_riding_with_the_cls_reg_launches_is_identical(built, monkeypatch):
+    """Training: the MEH tower's forward (forward_L on the detached pyramid, Lambda_L2.py:96-103) is computed inside the grouped cls / reg
+    tower launches of the main forward (3 x 341 tiles = whole rounds of the CUs) and train_step_L only records its autograd nodes
+    (conv_bn_act(pre=...)).  Same launches' arithmetic -> the MEH loss and every MEH gradient are bit-identical to the separate forward; a
+    forward_L on a different pyramid ignores the stored outputs."""
+    model, sd = built
+    from aod_meh_hua_amd import hipops as ho
+    H, W = 128, 160
+    img = synth.images(2, H, W, seed=41).cuda()
+    gtb, gtl = synth.random_gts(2, H, W, seed=42, gmin=1, gmax=3)
+    data = dict(img=img, img_metas=synth.metas(2, H, W), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    head = model.bbox_head
+    Lp = [p for n in head.L_names for p in getattr(head, n).parameters()]
+    res, launches = {}, {}
+    orig = ho.conv2d_rows_grouped
+    for mode in ('0', '1'):
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        monkeypatch.setenv('AOD_MEH_RIDER', mode)
+        groups = []
+        monkeypatch.setattr(ho, 'conv2d_rows_grouped', lambda xs, *a, **k: (groups.append(len(xs)), orig(xs, *a, **k))[1])
+        model.zero_grad(set_to_none=True)
+        out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+        out['loss'].backward()
+        outL = model.train_step_L(prev, head_out, feat_out, Labeled=True, Pseudo=False)
+        outL['loss'].backward()
+        torch.cuda.synchronize()
+        res[mode] = [outL['loss'].detach().clone()] + [p.grad.detach().clone() for p in Lp]
+        launches[mode] = groups
+    assert launches['0'] == [2] * len(head.cls_convs) and launches['1'] == [3] * len(head.cls_convs)
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
+    assert float(res['1'][0]) > 0 and all(float(g.abs().max()) > 0 for g in res['1'][1:])
+    # stored outputs are tied to the pyramid they were computed on
+    monkeypatch.setenv('AOD_MEH_RIDER', '1')
+    out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    other = [f.detach().clone() for f in feat_out]
+    a = head.forward_L(other)
+    assert head._L_pre is None
+    b = head.forward_L(other)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
