@@ -645,7 +645,7 @@ class ConvPairFn(Function):
             meta['rider_out'] = outs[2]
         ctx.meta, ctx.x_segs, ctx.y_segs, ctx.nl = meta, list(segs[0]), y_segs, nl
         ctx.save_for_backward(wA, wB, rows[0], rows[1], outs[0], outs[1])
-        return tuple(as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for o in outs for s in y_segs)
+        return tuple(as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for o in outs[:2] for s in y_segs)
 
     @staticmethod
     def backward(ctx, *gouts):

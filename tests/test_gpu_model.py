@@ -363,7 +363,10 @@ def test_meh_tower_forward_riding_with_the_cls_reg_launches_is_identical(built, 
         launches[mode] = groups
     assert launches['0'] == [2] * len(head.cls_convs) and launches['1'] == [3] * len(head.cls_convs)
     for a, b in zip(res['0'], res['1']):
-        assert torch.equal(a, b)
+        if a.dim() >= 2:
+            assert torch.equal(a, b)                    # weight gradients: deterministic slab sums of identical operands
+        else:                                           # loss / bias gradients: fp32 atomics (arrival order) in both forms
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(a.abs().max()) + 1e-12)
     assert float(res['1'][0]) > 0 and all(float(g.abs().max()) > 0 for g in res['1'][1:])
     # stored outputs are tied to the pyramid they were computed on
     monkeypatch.setenv('AOD_MEH_RIDER', '1')
