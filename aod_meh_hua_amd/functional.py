@@ -395,8 +395,11 @@ def _wgrad(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, w, O, I, dst,
     dev = dz.device
     gw = dst if dst is not None else torch.empty(O, I, R, S, dtype=torch.float32, device=dev)
     wdot = torch.empty(O, dtype=torch.float32, device=dev) if bn is not None else None
+    # (aliases, not the tensors themselves: autograd steals a returned gradient -- s1 is also the BN-shift gradient -- only while it holds the
+    # one reference to it; otherwise it clones, one tiny copy launch per vector)
     job = ho.WgradJob(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, O, I, gw.detach(), scale=scale,
-                      w=w.detach() if bn is not None else None, wdot=wdot.detach() if wdot is not None else None, bn=bn)
+                      w=w.detach() if bn is not None else None, wdot=wdot.detach() if wdot is not None else None,
+                      bn=tuple(t.detach() for t in bn) if bn is not None else None)
     defer = R * S <= 9 and w.grad is None and (gamma is None or gamma.grad is None)
     _WgradQueue.submit(job, id(w), defer)
     return gw, wdot
