@@ -67,8 +67,12 @@ class _PrepRec(_C.Structure):
                 ('eps', _C.c_float), ('pad_', _C.c_int32), ('pad2_', _C.c_int64 * 2)]
 
 
+class _FragRec(_C.Structure):
+    _fields_ = [('src', _C.c_void_p), ('dst', _C.c_void_p), ('rows', _C.c_int32), ('K', _C.c_int32), ('blk0', _C.c_int32), ('pad_', _C.c_int32)]
+
+
 class _PrepItem:
-    __slots__ = ('srcs', 'ver', 'wf', 'wd', 'scale', 'shift', 'invstd', 'eps', 'dims', 'nblk')
+    __slots__ = ('srcs', 'ver', 'wf', 'wd', 'scale', 'shift', 'invstd', 'eps', 'dims', 'nblk', 'fragf', 'fragd')
 
 
 class ParamPrep:
@@ -110,6 +114,7 @@ class ParamPrep:
         else:
             it.scale = it.shift = it.invstd = None
         it.eps, it.dims, it.ver = float(eps), (O, I, R * S, cin_pad, opad), None
+        it.fragf = it.fragd = None
         if R * S <= 9:
             it.nblk = ((opad + 31) // 32) * ((cin_pad + 31) // 32)           # 32 x 32 channel tiles (aod_param_prep)
         else:
@@ -117,6 +122,21 @@ class ParamPrep:
         self.items[id(w)] = it
         self.dirty = True
         return it
+
+    def frag(self, it, which):
+        """fragment-major image (aod_frag_pack) of a layer's forward ('f') or dgrad ('d') pack for the register-streamed bottleneck kernels;
+        created on first request and from then on re-derived together with the packs, in the same batched step"""
+        name = 'fragf' if which == 'f' else 'fragd'
+        t = getattr(it, name)
+        if t is None:
+            src = it.wf if which == 'f' else it.wd
+            rows = src.shape[0]
+            assert rows % 256 == 0 and (src.numel() // rows) % 64 == 0, 'frag images need rows % 256 == 0 and K % 64 == 0'
+            t = torch.empty(src.numel(), dtype=torch.bfloat16, device=src.device)
+            setattr(it, name, t)
+            self.tables, it.ver = {}, None           # the device tables list the frag images: rebuild them, and pack this one now
+            self.refresh()
+        return t
 
     def refresh_if_stale(self):
         for r in self.stems:              # derived weights first: an in-place rewrite bumps the version the items below watch
@@ -161,9 +181,22 @@ class ParamPrep:
                 r.blk0, r.eps = blk, it.eps
                 blk += it.nblk
             host = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
-            ent = self.tables[stale] = (host.to(self.order[stale[0]].wf.device), blk)
+            dev = self.order[stale[0]].wf.device
+            # fragment-major images of the stale layers that have them: one more launch, after the packs they are made from
+            fl = [(src, dst) for i in stale for src, dst in ((self.order[i].wf, self.order[i].fragf), (self.order[i].wd, self.order[i].fragd))
+                  if dst is not None]
+            ftab, fblk = None, 0
+            if fl:
+                frecs = (_FragRec * len(fl))()
+                for r, (src, dst) in zip(frecs, fl):
+                    r.src, r.dst, r.rows, r.K, r.blk0 = src.data_ptr(), dst.data_ptr(), src.shape[0], src.numel() // src.shape[0], fblk
+                    fblk += (src.numel() + 2047) // 2048
+                ftab = torch.frombuffer(bytearray(bytes(frecs)), dtype=torch.uint8).to(dev)
+            ent = self.tables[stale] = (host.to(dev), blk, ftab, len(fl), fblk)
         self.table = ent[0]           # (kept alive for captured graphs by graphs._pin_caches)
         ho.call('aod_param_prep', ho.ptr(ent[0]), len(stale), ent[1], ho.stream())
+        if ent[2] is not None:
+            ho.call('aod_frag_pack', ho.ptr(ent[2]), ent[3], ent[4], ho.stream())
         for i in stale:
             self.order[i].ver = self._versions(self.order[i])
 
@@ -527,11 +560,16 @@ class ConvFn(Function):
                 if role == 3 and res_g is None and _chain_ready(ch, meta):
                     # the whole block's dgrad chain in one launch; G = dz is also the skip gradient conv1's epilogue adds
                     s0 = x_segs[0]
-                    wds = {3: wd}
+                    pis = {3: PREP.get(w, (gamma, None, mean, None) if ctx.has_bn else None, cin, meta['eps'])}
                     for r in (2, 1):
                         w_, g_, m_, cin_, _ = ch.prep[r]
-                        wds[r] = PREP.get(w_, (g_, None, m_, None) if g_ is not None else None, cin_, ch.meta[r]['eps']).wd
-                    gx, dx, gt1, cx, s1_in, c1 = ho.bottleneck_bwd(dz, s0.B, s0.H, s0.W, wds[3], wds[2], wds[1], x_rows, ch.x_rows[2], ch.x_rows[1])
+                        pis[r] = PREP.get(w_, (g_, None, m_, None) if g_ is not None else None, cin_, ch.meta[r]['eps'])
+                    # (the register-streamed form of the dgrad chain exists -- aod_bottleneck256f_bwd -- but is NOT taken: it fails the bit-equality
+                    # check against the three launches in its third product on this toolchain, tools/dbg/frag_check.py; AOD_BOTTLENECK_FRAG_BWD=1 for experiments)
+                    fr = O == 1024 and _os.environ.get('AOD_BOTTLENECK_FRAG_BWD', '0') == '1'
+                    wds = {r: (PREP.frag(pis[r], 'd') if fr else pis[r].wd) for r in (3, 2, 1)}
+                    gx, dx, gt1, cx, s1_in, c1 = ho.bottleneck_bwd(dz, s0.B, s0.H, s0.W, wds[3], wds[2], wds[1], x_rows, ch.x_rows[2], ch.x_rows[1],
+                                                                   frag=fr)
                     ch.out[2], ch.out[1] = (gt1, c1), (gx, cx)
                 elif role in ch.out:
                     dx, s1_in = ch.out.pop(role)
@@ -788,6 +826,11 @@ def _wide_stage(blk):
     return blk.planes == 128 or (blk.planes == 256 and _os.environ.get('AOD_FUSE_BOTTLENECK256', '1') != '0')
 
 
+def _frag_form(blk):
+    """the 256-plane block takes the register-streamed kernel with fragment-major filter images (AOD_BOTTLENECK_FRAG=0: the LDS-ring form)"""
+    return blk.planes == 256 and _os.environ.get('AOD_BOTTLENECK_FRAG', '1') != '0'
+
+
 def bottleneck128_applies(blk, x):
     """an identity bottleneck of the 128-plane stage (resnet.py:262-301: 512 -> 128 -> 128 -> 512, stride 1, no downsample branch) whose
     forward keeps nothing for a backward pass (inference / frozen): one launch (aod_bottleneck128_fwd)"""
@@ -822,9 +865,11 @@ def bottleneck128_train_fwd(x, blk):
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
     p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
     p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
+    fr = _frag_form(blk)
+    w1, w2, w3 = ((PREP.frag(q, 'f') for q in (p1, p2, p3)) if fr else (p1.wf, p2.wf, p3.wf))
     with torch.no_grad():
-        y, t1, t2 = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale,
-                                         p3.shift, keep=True)
+        y, t1, t2 = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, w1, p1.scale, p1.shift, w2, p2.scale, p2.shift, w3, p3.scale,
+                                         p3.shift, keep=True, frag=fr)
     return t1, t2, y
 
 
@@ -834,7 +879,9 @@ def bottleneck128_fwd(x, blk):
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
     p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
     p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
-    out = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale, p3.shift)
+    fr = _frag_form(blk)
+    w1, w2, w3 = ((PREP.frag(q, 'f') for q in (p1, p2, p3)) if fr else (p1.wf, p2.wf, p3.wf))
+    out = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, w1, p1.scale, p1.shift, w2, p2.scale, p2.shift, w3, p3.scale, p3.shift, frag=fr)
     return as_nchw(out, B, H, W)
 
 

@@ -434,7 +434,7 @@ def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_ro
     return out
 
 
-def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=False):
+def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=False, frag=False):
     """aod_bottleneck128_fwd / aod_bottleneck256_fwd (by the channel count of x: 512 / 1024): identity bottleneck of the 128- / 256-plane
     stage in one launch; keep=True also returns the intermediates t1, t2"""
     M, Cin = x_rows.shape
@@ -445,12 +445,12 @@ def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=
     t2 = torch.empty(M, Pl, dtype=torch.bfloat16, device=x_rows.device) if keep else None
     flops = 2.0 * M * (Cin * Pl + 9 * Pl * Pl + Pl * Cin)
     prof_flops('fwd', (M, Cin, Cin + 9 * Pl + Pl, 11, 1), flops,
-               lambda: call('aod_bottleneck128_fwd' if Pl == 128 else 'aod_bottleneck256_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3), ptr(b3),
+               lambda: call('aod_bottleneck128_fwd' if Pl == 128 else ('aod_bottleneck256f_fwd' if frag else 'aod_bottleneck256_fwd'), ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3), ptr(b3),
                             ptr(out), ptr(t1), ptr(t2), stream()))
     return (out, t1, t2) if keep else out
 
 
-def bottleneck_bwd(g_rows, B, H, W, wd3, wd2, wd1, act_t2, act_t1, act_x):
+def bottleneck_bwd(g_rows, B, H, W, wd3, wd2, wd1, act_t2, act_t1, act_x, frag=False):
     """aod_bottleneck_bwd: dgrad chain of an identity bottleneck (128 / 256 planes) in one launch -> (gx, gt2, gt1, colsum_x, colsum_t2, colsum_t1)"""
     M, Cin = g_rows.shape
     assert M == B * H * W and Cin in (512, 1024) and act_x.shape == g_rows.shape
@@ -463,8 +463,10 @@ def bottleneck_bwd(g_rows, B, H, W, wd3, wd2, wd1, act_t2, act_t1, act_x):
     cx, c2, c1 = zeros_f32(Cin, dev), zeros_f32(Pl, dev), zeros_f32(Pl, dev)
     flops = 2.0 * M * (Cin * Pl + 9 * Pl * Pl + Pl * Cin)
     prof_flops('dgrad', (M, Cin, Cin + 9 * Pl + Pl, 11, 1), flops,
-               lambda: call('aod_bottleneck_bwd', Pl, ptr(g_rows), B, H, W, ptr(wd3), ptr(wd2), ptr(wd1), ptr(act_t2), ptr(act_t1), ptr(act_x),
-                            ptr(gx), ptr(gt2), ptr(gt1), ptr(c2), ptr(c1), ptr(cx), stream()))
+               lambda: (call('aod_bottleneck256f_bwd', ptr(g_rows), B, H, W, ptr(wd3), ptr(wd2), ptr(wd1), ptr(act_t2), ptr(act_t1), ptr(act_x),
+                             ptr(gx), ptr(gt2), ptr(gt1), ptr(c2), ptr(c1), ptr(cx), stream()) if frag and Pl == 256 else
+                        call('aod_bottleneck_bwd', Pl, ptr(g_rows), B, H, W, ptr(wd3), ptr(wd2), ptr(wd1), ptr(act_t2), ptr(act_t1), ptr(act_x),
+                             ptr(gx), ptr(gt2), ptr(gt1), ptr(c2), ptr(c1), ptr(cx), stream())))
     return gx, gt2, gt1, cx, c2, c1
 
 

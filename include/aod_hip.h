@@ -120,6 +120,22 @@ int aod_bottleneck_bwd(int planes, const void* g, int B, int H, int W, const voi
                        const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
                        float* colsum_x, aod_stream_t stream);
 
+/* The 256-plane block with FRAGMENT-MAJOR filter images: the eight waves of a workgroup split the output channels, so a filter fragment is
+ * needed by exactly one wave, in the MFMA A-operand layout a 16-B load per lane delivers -- the filters stream global -> registers (a
+ * prefetch ring per wave) and never touch the LDS; the conv2 / conv3 K loops run without a barrier.  aod_frag_pack re-orders row-major
+ * packed filters ([rows][K] bf16: aod_pack_weight_fwd / _dgrad images; rows % 256 == 0, K % 64 == 0) into that load order for any number
+ * of filters in one launch: items_dev = device array of aod_frag_pack_item_bytes()-byte records { const void* src; void* dst; int32 rows,
+ * K, blk0, pad } with blk0 = first block of the item, an item owning ceil(rows * K / 2048) blocks.  Same results as the plain forms, bit
+ * for bit. */
+int aod_frag_pack_item_bytes(void);
+int aod_frag_pack(const void* items_dev, int nitems, int total_blocks, aod_stream_t stream);
+int aod_bottleneck256f_fwd(const void* x, int B, int H, int W, const void* w1f, const float* s1, const float* b1, const void* w2f,
+                           const float* s2, const float* b2, const void* w3f, const float* s3, const float* b3, void* y, void* t1, void* t2,
+                           aod_stream_t stream);
+int aod_bottleneck256f_bwd(const void* g, int B, int H, int W, const void* wd3f, const void* wd2f, const void* wd1f, const void* act_t2,
+                           const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
+                           float* colsum_x, aod_stream_t stream);
+
 /* Grouped launch: `ngroups` (<= 4) convolutions with IDENTICAL descriptor (geometry, C, N, filter) but their own operands share one
  * grid -- the cls / reg / evidence towers at one depth (Lambda_L2.py:85-103: three independent 4-conv stacks over the same pyramid).
  * Alone each tower conv leaves a third of its last round of workgroups idle; together their tiles fill whole rounds (3 x 341 tiles of

@@ -376,3 +376,46 @@ def test_meh_tower_forward_riding_with_the_cls_reg_launches_is_identical(built, 
     assert head._L_pre is None
     b = head.forward_L(other)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize('shape', [(16, 32, 32), (2, 13, 37), (8, 50, 84), (1, 4, 16), (3, 7, 129)])
+def test_register_streamed_bottleneck256_equals_the_ring_form_repeatedly(shape):
+    """aod_bottleneck256f_fwd (fragment-major filter images from aod_frag_pack, filters streamed global -> registers, barrier-free conv2 / conv3
+    K loops) against aod_bottleneck256_fwd (row-major packs through LDS rings) on random operands, five launches each: y, t1 and t2 identical
+    bits every time (the kernel keeps many loads in flight per wave; a wait that lets one through early shows up as run-to-run garbage)."""
+    import ctypes as C
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import call, ptr, stream, lib
+    B, H, W = shape
+    P, C4 = 256, 1024
+    g = torch.Generator(device='cuda').manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    w = [(rnd(P, C4) * 0.05).bfloat16(), (rnd(P, 9 * P) * 0.03).bfloat16(), (rnd(C4, P) * 0.05).bfloat16()]
+    sb = [(torch.rand(n, device='cuda', generator=g) + 0.5, rnd(n) * 0.1) for n in (P, P, C4)]
+
+    class Rec(C.Structure):
+        _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int32), ('K', C.c_int32), ('blk0', C.c_int32), ('pad_', C.c_int32)]
+    assert lib.aod_frag_pack_item_bytes() == C.sizeof(Rec)
+    frags = [torch.empty(t.numel(), dtype=torch.bfloat16, device='cuda') for t in w]
+    recs, blk = (Rec * 3)(), 0
+    for r, t, f in zip(recs, w, frags):
+        r.src, r.dst, r.rows, r.K, r.blk0 = t.data_ptr(), f.data_ptr(), t.shape[0], t.shape[1], blk
+        blk += (t.numel() + 2047) // 2048
+    tab = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).cuda()
+    call('aod_frag_pack', ptr(tab), 3, blk, stream())
+    # the image is a permutation of the pack: [step][wave][j][ks][lane][8]
+    f0 = frags[0].view(16, 8, 2, 2, 64, 8).cpu()
+    lane = torch.arange(64)
+    for (s_, w_, j_, ks_) in ((0, 0, 0, 0), (5, 3, 1, 0), (15, 7, 1, 1)):
+        rows = 32 * w_ + 8 * ((lane & 15) >> 2) + 4 * j_ + (lane & 3)
+        cols = 64 * s_ + 8 * (4 * ks_ + (lane >> 4))
+        ref = torch.stack([w[0].cpu()[r, c:c + 8] for r, c in zip(rows.tolist(), cols.tolist())])
+        assert torch.equal(f0[s_, w_, j_, ks_], ref)
+    for it in range(5):
+        x = rnd(B * H * W, C4).relu().bfloat16()
+        a = ho.bottleneck128_fwd(x, B, H, W, w[0], *sb[0], w[1], *sb[1], w[2], *sb[2], keep=True)
+        b = ho.bottleneck128_fwd(x, B, H, W, frags[0], *sb[0], frags[1], *sb[1], frags[2], *sb[2], keep=True, frag=True)
+        torch.cuda.synchronize()
+        for name, u, v in zip(('y', 't1', 't2'), a, b):
+            assert torch.equal(u, v), (name, it, int((u != v).sum()))
+        assert float(a[0].float().abs().mean()) > 1e-3
