@@ -1,5 +1,5 @@
 """Per-tile phase timing of the wide bottleneck kernels (debug build with -DAOD_TILE_TIMING: python tools/dbg/tile_timing.py build).
-  run on GPU:   AOD_HIP_LIB=tools/dbg/_build/libaodhip_dbg.so python tools/dbg/wide_timing.py [128|256] [fwd|bwd]"""
+  run on GPU:   AOD_HIP_LIB=tools/dbg/_build/libaodhip_dbg.so python tools/dbg/wide_timing.py [128|256] [fwd|bwd|frag]"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,22 @@ w1 = (rnd(P, C4) * 0.05).bfloat16(); w2 = (rnd(P, 9 * P) * 0.03).bfloat16(); w3 
 v = lambda n: (torch.rand(n, device='cuda', generator=g) + 0.5, rnd(n) * 0.1)
 (s1, b1), (s2, b2), (s3, b3) = v(P), v(P), v(C4)
 t1 = rnd(M, P).relu().bfloat16(); t2 = rnd(M, P).relu().bfloat16()
-if mode == 'fwd':
+if mode == 'frag':       # the register-streamed 256-plane kernel on fragment-major images
+    import ctypes as C
+    from aod_meh_hua_amd._C import call, ptr, stream
+
+    class Rec(C.Structure):
+        _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int32), ('K', C.c_int32), ('blk0', C.c_int32), ('pad_', C.c_int32)]
+    fr = []
+    for wt in (w1, w2, w3):
+        o = torch.empty(wt.numel(), dtype=torch.bfloat16, device='cuda')
+        r = (Rec * 1)()
+        r[0].src, r[0].dst, r[0].rows, r[0].K, r[0].blk0 = wt.data_ptr(), o.data_ptr(), wt.shape[0], wt.shape[1], 0
+        tab = torch.frombuffer(bytearray(bytes(r)), dtype=torch.uint8).cuda()
+        call('aod_frag_pack', ptr(tab), 1, (wt.numel() + 2047) // 2048, stream())
+        fr.append(o)
+    f = lambda: ho.bottleneck128_fwd(x, B, H, W, fr[0], s1, b1, fr[1], s2, b2, fr[2], s3, b3, keep=True, frag=True)
+elif mode == 'fwd':
     f = lambda: ho.bottleneck128_fwd(x, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=True)
 else:
     gy = (rnd(M, C4) * 0.1).bfloat16()
