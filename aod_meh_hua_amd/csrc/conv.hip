@@ -1043,7 +1043,7 @@ struct WgradParams {
   const RowRec* tab;
   int C, N, K, R, S, dil;
   int M;
-  int tiles_n, tiles_k, splits, rows_per_split, stagger;
+  int tiles_n, tiles_k, splits, rows_per_split, stagger, xcd_order;
   long long x_bytes, z_bytes, tab_bytes;
   long long slab_stride;     // > 0: split s STORES its partial tile into dw + s * slab_stride (deterministic, summed by the unpack); 0: fp32 atomics
 };
@@ -1075,8 +1075,13 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int wm = uw / WNC, wn = uw % WNC;
+  // bid_in runs (pixel split, tile) with the TILE fastest, over a range that one XCD executes contiguously (xcd_swizzle at the call site):
+  // the tiles of a split -- the nine taps of a 3x3 filter read the same dZ rows and the same x rows at shifted positions -- share that XCD's
+  // L2.  With the split fastest they were spread over all eight L2s and every operand row crossed HBM once per tile: 2.78 GB per grouped
+  // tower launch for 0.36 GB of operands, i.e. the kernel ran at the HBM rate (profiles/r03_pmc_passes.txt).
   int bid = bid_in;
-  const int split = bid % p.splits; bid /= p.splits;
+  const int ntile = p.tiles_n * p.tiles_k;
+  const int split = bid / ntile; bid -= split * ntile;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
   const int n0 = tile_n * (128 * TN), k0 = tile_k * (128 * TK);
   const int ms = split * p.rows_per_split;
@@ -1268,7 +1273,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
 // plus the unpack kernel's read of one more slab per split.
 template <int NW, int TN, int TK>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
-  wgrad_tile<NW, TN, TK>(p, blockIdx.x);
+  wgrad_tile<NW, TN, TK>(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
 }
 // Grouped launch: up to WG_MAXG weight gradients (ANY geometries, one tile form) share one grid.  Alone a backbone layer needs 100+ pixel
 // splits of its few 128 x 128 tiles to fill the chip -- a 512 x 128 filter (256 KB) leaves 30 MB of partial slabs for the unpack; three
@@ -1277,7 +1282,7 @@ constexpr int WG_MAXG = 4;
 struct WgradGroups { WgradParams g[WG_MAXG]; int wg0[WG_MAXG + 1]; int n; };
 template <int NW, int TN, int TK>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_grouped_kernel(const WgradGroups gp) {
-  const int b = blockIdx.x;
+  const int b = gp.g[0].xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   // (selects, not an indexed read of the argument block: a run-time index would move the whole array to scratch memory)
   if (b < gp.wg0[1]) wgrad_tile<NW, TN, TK>(gp.g[0], b);
   else if (b < gp.wg0[2]) wgrad_tile<NW, TN, TK>(gp.g[1], b - gp.wg0[1]);
@@ -1335,6 +1340,7 @@ static int wgrad_fill(const aod_conv_desc_t* d, const void* x, const void* dz, f
   p.tab_bytes = (long long)p.M * (long long)sizeof(RowRec);
   AOD_CHECK_ARG(p.x_bytes < 0xe0000000ll && p.z_bytes < 0xe0000000ll, "wgrad: operand larger than 3.5 GiB (32-bit buffer offsets)");
   { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
+  { static const char* dbg_x = getenv("AOD_WGRAD_XCD"); p.xcd_order = (dbg_x && dbg_x[0] == '0') ? 0 : 1; }      // (debug: 0 = launch order)
   return 0;
 }
 
