@@ -1290,10 +1290,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK
   else wgrad_tile<NW, TN, TK>(gp.g[3], b - gp.wg0[3]);
 }
 
-static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big) {
+static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big, int big_min_m = 49152) {
   // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
   static const char* dbg_big = getenv("AOD_WGRAD_256");
-  big = (N % 256 == 0 && K % 256 == 0 && M >= 49152) ? 1 : 0;      // (measured: 16 x 32 x 32 pixels lose 15 %, 16 x 64 x 64 gain 10 %)
+  // (measured, single launches: 16 x 32 x 32 pixels lose 15 % with the big tile, 16 x 64 x 64 gain 10 %; members of a GROUP get longer pixel
+  // runs per workgroup and take it from 16 384 pixels on: -0.11 ms per step, AOD_WGRAD_BIG_MINM overrides the group threshold)
+  big = (N % 256 == 0 && K % 256 == 0 && M >= big_min_m) ? 1 : 0;
   if (dbg_big && dbg_big[0] == '0') big = 0;
   const int T = big ? 256 : 128;
   tiles_n = (N + T - 1) / T;
@@ -1388,7 +1390,8 @@ static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int
   int steps[WG_MAXG], max_steps = 1;
   for (int g = 0; g < n; ++g) {
     int sp, r, b;
-    wgrad_plan(M[g], N[g], K[g], true, tiles_n[g], tiles_k[g], sp, r, b);
+    static const char* dbg_minm = getenv("AOD_WGRAD_BIG_MINM");
+    wgrad_plan(M[g], N[g], K[g], true, tiles_n[g], tiles_k[g], sp, r, b, n > 1 ? (dbg_minm ? atoi(dbg_minm) : 16384) : 49152);
     if (big >= 0 && b != big) return -1;
     big = b;
     tiles[g] = (long long)tiles_n[g] * tiles_k[g];
