@@ -451,7 +451,10 @@ extern "C" int aod_pre_nms_levels(int L, const float* const* cls, const float* c
 constexpr int TR = 1024;  // tranche of candidates sorted at a time (max_num <= 256 detections usually come from the first one)
 __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
                                                  float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
-                                                 long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat) {
+                                                 long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat, int kcache_n) {
+  // sort keys of the first kcache_n valid entries, built while they are compacted: the radix-select passes and the gathers then read LDS
+  // instead of two dependent global loads per key (vflat -> score); entries beyond the cache take the global path
+  extern __shared__ unsigned long long kcache[];
   __shared__ int hist[264];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[TR];
@@ -470,18 +473,22 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   __syncthreads();
   int base = 0;
   float mymax = -INFINITY;
-  // four consecutive flat entries per thread and iteration: one block scan per 4096 entries (the scan's two barriers dominate)
-  for (long long c0 = 0; c0 < NC; c0 += 4 * TB) {
-    const long long f0 = c0 + 4 * threadIdx.x;
-    bool v[4];
+  // eight consecutive flat entries per thread and iteration: one block scan per 8192 entries (the scan's two barriers dominate)
+  constexpr int NU = 8;
+  for (long long c0 = 0; c0 < NC; c0 += NU * TB) {
+    const long long f0 = c0 + NU * threadIdx.x;
+    bool v[NU];
+    float sv[NU];
     int cnt = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const long long f = f0 + u;
       v[u] = false;
+      sv[u] = 0.f;
       if (f < NC) {
         const int cand = (int)(f / C), cl = (int)(f - (long long)cand * C);
-        v[u] = sc[(long long)cand * (C + 1) + cl] > score_thr;
+        sv[u] = sc[(long long)cand * (C + 1) + cl];
+        v[u] = sv[u] > score_thr;
         if (v[u]) {
           const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
           mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
@@ -492,8 +499,12 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
     int tot;
     int pos = base + block_excl_scan(cnt, s_warp, tot);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (v[u]) vflat[pos++] = (int)(f0 + u);
+    for (int u = 0; u < NU; ++u)
+      if (v[u]) {
+        vflat[pos] = (int)(f0 + u);
+        if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+        ++pos;
+      }
     base += tot;
     __syncthreads();
   }
@@ -504,6 +515,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   // boxes are clipped to >= 0 so the int ordering of the float bits is valid; guard the (never expected) negative case
   const float off_unit = s_maxc + 1.f;
   auto key = [&](long long pidx) {
+    if (pidx < kcache_n) return kcache[pidx];
     const int f = vflat[pidx];
     const int cand = f / C, cl = f - cand * C;
     return ((unsigned long long)__float_as_uint(sc[(long long)cand * (C + 1) + cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pidx);
@@ -616,8 +628,16 @@ extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B
   if (B == 0) return 0;
   AOD_CHECK_ARG(boxes && scores && dets && det_labels && keep && num_det && ws, "nms: null pointer");
   AOD_CHECK_ARG(max_num >= 1 && max_num <= 256 && C >= 1, "nms: max_num must be in 1..256");
-  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
-                     (long long*)det_labels, (long long*)keep, num_det, (int*)ws);
+  // key cache: up to 12 288 valid (candidate, class) entries per image (96 KB of LDS beside the 16 KB of static arrays)
+  const long long nc = (long long)n * C;
+  const int kcache_n = (int)(nc < 12288 ? nc : 12288);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), (size_t)kcache_n * 8, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
+                     (long long*)det_labels, (long long*)keep, num_det, (int*)ws, kcache_n);
   AOD_LAUNCH_CHECK();
   return 0;
 }
