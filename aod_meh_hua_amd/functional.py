@@ -388,7 +388,7 @@ class _WgradQueue:
         keeps aliases); a parameter whose .grad exists, or that is used twice in one pass (the engine adds the two gradients when the second
         arrives), is not deferred -- and the second use flushes the queue first;
       * segmented backward passes (data parallelism) are separate engine runs: every segment's gradients are complete when its run returns."""
-    jobs, seen, armed = [], set(), False
+    jobs, seen, task = [], set(), -1
     enabled = _os.environ.get('AOD_WGRAD_GROUP', '1') != '0'
 
     @classmethod
@@ -399,16 +399,22 @@ class _WgradQueue:
 
     @classmethod
     def _end_of_pass(cls):
-        cls.armed = False
+        cls.task = -1
         cls.seen.clear()
         _S1_OF.clear()
         cls.flush()
 
     @classmethod
     def submit(cls, job, wid, defer):
-        if not cls.armed:
-            cls.armed = True
+        # one end-of-pass callback per autograd run, recognised by the engine's graph-task id: a pass that died with an exception never ran
+        # its callback -- its leftovers must not leak into the next pass (they are launched now: their tensors are still alive and nobody
+        # reads them), and the next pass must get a callback of its own
+        tid = torch._C._current_graph_task_id()
+        if tid != cls.task:
+            cls.flush()
+            cls.task = tid
             cls.seen.clear()
+            _S1_OF.clear()
             torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_pass)
         if wid in cls.seen or not (defer and cls.enabled):
             cls.flush()

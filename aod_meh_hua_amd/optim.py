@@ -34,6 +34,8 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None):
         if self._lr_dev and not torch.cuda.is_current_stream_capturing():
             self.device_lr()          # eager step between graph replays: the schedule may have changed group['lr'] since the last upload
+        from . import functional as _AF
+        _AF._WgradQueue.flush()       # (weight gradients still queued by a backward pass: launched before anything reads them; normally empty)
         touched, keep = [], []        # keep: contiguous gradient copies must outlive the launch that reads their raw pointers
         for gi, group in enumerate(self.param_groups):
             self._gi = gi

@@ -419,3 +419,53 @@ def test_register_streamed_bottleneck256_equals_the_ring_form_repeatedly(shape):
         for name, u, v in zip(('y', 't1', 't2'), a, b):
             assert torch.equal(u, v), (name, it, int((u != v).sum()))
         assert float(a[0].float().abs().mean()) > 1e-3
+
+
+def test_weight_gradient_queue_survives_an_aborted_backward_pass(built):
+    """functional._WgradQueue defers weight-gradient launches to the end of the autograd run.  A run that dies half-way (here: a tensor hook
+    raises inside the backbone's backward) never reaches its end-of-pass callback; the next run must neither inherit its queued jobs as its
+    own nor go without a callback: its gradients equal those of a run in a fresh state, bit for bit."""
+    model, sd = built
+    from aod_meh_hua_amd import functional as AF
+    H = W = 128
+    img = synth.images(2, H, W, seed=77).cuda()
+    gtb, gtl = synth.random_gts(2, H, W, seed=78, gmin=1, gmax=3)
+    data = dict(img=img, img_metas=synth.metas(2, H, W), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run(abort):
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        if abort:
+            def boom(g):
+                raise RuntimeError('boom')
+            orig = model.neck.forward
+
+            def hooked(xs):
+                xs[-1].register_hook(boom)           # gradient of C5: fires after the head's and the neck's weight gradients were queued
+                return orig(xs)
+            model.neck.forward = hooked
+        try:
+            out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+        finally:
+            if abort:
+                del model.neck.forward
+        if abort:
+            with pytest.raises(RuntimeError, match='boom'):
+                out['loss'].backward()
+            return None
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() if p.grad is not None else None for p in params]
+
+    ref = run(False)
+    run(True)
+    got = run(False)
+    assert not AF._WgradQueue.jobs
+    for a, b in zip(ref, got):
+        assert (a is None) == (b is None)
+        if a is not None and a.dim() == 4:
+            assert torch.equal(a, b)
+        elif a is not None:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(a.abs().max()) + 1e-12)
