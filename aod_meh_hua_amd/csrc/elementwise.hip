@@ -311,19 +311,35 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdChunk c, int bl
   // the scalar path): 20 B of traffic per parameter, nothing else
   const bool vec = ((((size_t)p) | ((size_t)g) | ((size_t)mbuf)) & 15) == 0;
   const long long n4 = vec ? n / 4 : 0;
-  for (long long i = (long long)bi * 256 + threadIdx.x; i < n4; i += (long long)blocks_per_tensor * 256) {
-    const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mv = first_step ? (f32x4){0.f, 0.f, 0.f, 0.f} : reinterpret_cast<const f32x4*>(mbuf)[i];
-    f32x4 po;
+  // four 16-B pieces of each array in flight per thread (one at a time made the big tensors -- 24 iterations per thread -- a chain of memory
+  // round trips: the launch with the tower filters took 100 us for 170 MB)
+  const long long stride = (long long)blocks_per_tensor * 256;
+  for (long long i0 = (long long)bi * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    f32x4 pv[4], gv[4], mv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float d = gv[u] * grad_scale + wd * pv[u];
-      const float b = first_step ? d : momentum * mv[u] + d;
-      mv[u] = b;
-      po[u] = pv[u] - lr * b;
+    for (int k = 0; k < 4; ++k) {
+      const long long i = i0 + k * stride;
+      if (i < n4) {
+        pv[k] = reinterpret_cast<const f32x4*>(p)[i]; gv[k] = reinterpret_cast<const f32x4*>(g)[i];
+        mv[k] = first_step ? (f32x4){0.f, 0.f, 0.f, 0.f} : reinterpret_cast<const f32x4*>(mbuf)[i];
+      }
     }
-    reinterpret_cast<f32x4*>(mbuf)[i] = mv;
-    reinterpret_cast<f32x4*>(p)[i] = po;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long i = i0 + k * stride;
+      if (i < n4) {
+        f32x4 po;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = gv[k][u] * grad_scale + wd * pv[k][u];
+          const float b = first_step ? d : momentum * mv[k][u] + d;
+          mv[k][u] = b;
+          po[u] = pv[k][u] - lr * b;
+        }
+        reinterpret_cast<f32x4*>(mbuf)[i] = mv[k];
+        reinterpret_cast<f32x4*>(p)[i] = po;
+      }
+    }
   }
   for (long long i = n4 * 4 + (long long)bi * 256 + threadIdx.x; i < n; i += (long long)blocks_per_tensor * 256) {
     const float pv = p[i];
