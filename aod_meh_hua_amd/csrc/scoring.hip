@@ -448,6 +448,17 @@ extern "C" int aod_pre_nms_levels(int L, const float* const* cls, const float* c
 
 // ---------------------------------------------------------------- S4: multiclass NMS, one block per image
 // workspace per image: vflat[n*C] ints (flat index of the p-th valid entry)
+#ifdef AOD_TILE_TIMING
+__device__ unsigned long long* g_nms_stamps = nullptr;      // debug build (tools/dbg/nms_timing.py): phase stamps of image 0
+#define NSTAMP(k) do { if (g_nms_stamps && threadIdx.x == 0 && blockIdx.x == 0) g_nms_stamps[k] = wall_clock64(); } while (0)
+__device__ __forceinline__ bool g_nms_stamps_on() { return g_nms_stamps != nullptr; }
+__device__ __forceinline__ void g_nms_stamps_extra(int nvalid, int nk) { g_nms_stamps[8] = nvalid; g_nms_stamps[9] = nk; }
+extern "C" int aod_dbg_set_nms_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nms_stamps), &buf, sizeof(buf)); }
+#else
+#define NSTAMP(k) do {} while (0)
+__device__ __forceinline__ bool g_nms_stamps_on() { return false; }
+__device__ __forceinline__ void g_nms_stamps_extra(int, int) {}
+#endif
 constexpr int TR = 1024;  // tranche of candidates sorted at a time (max_num <= 256 detections usually come from the first one)
 __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
                                                  float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
@@ -458,6 +469,8 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   __shared__ int hist[264];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[TR];
+  __shared__ float cbox[TR][4];      // the tranche's candidates in sorted order: raw box, class (gathered by all threads before the serial scan)
+  __shared__ int ccls[TR];
   __shared__ float kbox[256][4];
   __shared__ float karea[256];
   __shared__ int kcls[256];
@@ -468,47 +481,63 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   const float* sc = scores + (long long)b * n * (C + 1);
   int* vflat = ws_vflat + (long long)b * n * C;
   const long long NC = (long long)n * C;
+  NSTAMP(0);
   // 1. compaction of valid (score > thr) entries in flat order + max coordinate of their boxes
   if (threadIdx.x == 0) { s_nkept = 0; s_maxc = -INFINITY; }
   __syncthreads();
   int base = 0;
   float mymax = -INFINITY;
-  // eight consecutive flat entries per thread and iteration: one block scan per 8192 entries (the scan's two barriers dominate)
-  constexpr int NU = 8;
-  for (long long c0 = 0; c0 < NC; c0 += NU * TB) {
-    const long long f0 = c0 + NU * threadIdx.x;
-    bool v[NU];
-    float sv[NU];
+  // one candidate (row of C scores) per thread and iteration: count its valid classes, one block scan per 1024 candidates, then write its
+  // entries in class order -- flat (candidate, class) order as before, 4 scans instead of 10 for 3 765 x 20, and the box of a candidate
+  // is read once for the coordinate maximum instead of once per valid class (the scores of the second pass are cache hits)
+  for (int c0 = 0; c0 < n; c0 += TB) {
+    const int cand = c0 + (int)threadIdx.x;
     int cnt = 0;
+    const float* srow = sc + (long long)cand * (C + 1);
+    unsigned vm = 0;                 // C <= 24: the row stays in registers -- all its loads in flight at once (a run-time class loop issues one
+    float sv[24];                    // load per round trip), valid classes as a bit mask
+    if (cand < n) {
+      if (C <= 24) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const long long f = f0 + u;
-      v[u] = false;
-      sv[u] = 0.f;
-      if (f < NC) {
-        const int cand = (int)(f / C), cl = (int)(f - (long long)cand * C);
-        sv[u] = sc[(long long)cand * (C + 1) + cl];
-        v[u] = sv[u] > score_thr;
-        if (v[u]) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
-          mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
-          ++cnt;
-        }
+        for (int cl = 0; cl < 24; ++cl) sv[cl] = cl < C ? srow[cl] : -INFINITY;
+#pragma unroll
+        for (int cl = 0; cl < 24; ++cl) vm |= (sv[cl] > score_thr ? 1u : 0u) << cl;
+        cnt = __popc(vm);
+      } else {
+        for (int cl = 0; cl < C; ++cl) cnt += srow[cl] > score_thr ? 1 : 0;
+      }
+      if (cnt) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+        mymax = fmaxf(mymax, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
       }
     }
     int tot;
     int pos = base + block_excl_scan(cnt, s_warp, tot);
+    if (cnt) {
+      if (C <= 24) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      if (v[u]) {
-        vflat[pos] = (int)(f0 + u);
-        if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
-        ++pos;
+        for (int cl = 0; cl < 24; ++cl)
+          if ((vm >> cl) & 1u) {
+            vflat[pos] = cand * C + cl;
+            if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(sv[cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+            ++pos;
+          }
+      } else {
+        for (int cl = 0; cl < C; ++cl) {
+          const float v = srow[cl];
+          if (v > score_thr) {
+            vflat[pos] = cand * C + cl;
+            if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+            ++pos;
+          }
+        }
       }
+    }
     base += tot;
     __syncthreads();
   }
   const int nvalid = base;
+  NSTAMP(1);
   mymax = wave_max(mymax);
   if ((threadIdx.x & 63) == 0 && mymax > -INFINITY) atomicMax((int*)&s_maxc, __float_as_int(mymax));  // coords >= 0 after clipping
   __syncthreads();
@@ -526,6 +555,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
     if (s_nkept >= max_num) break;
     const int take = min(TR, nvalid - done);
     const unsigned long long kth = radix_select_kth(key, nvalid, upper, take, hist);
+    NSTAMP(2);
     int np2 = 64;
     while (np2 < take) np2 <<= 1;
     for (int i = threadIdx.x; i < np2; i += TB) keys[i] = 0ull;
@@ -547,6 +577,16 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
       }
     }
     bitonic_desc(keys, np2);
+    for (int i = threadIdx.x; i < take; i += TB) {
+      const int pidx = (int)(0xffffffffu - (unsigned)(keys[i] & 0xffffffffull));
+      const int f = vflat[pidx];
+      const int cand = f / C;
+      const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
+      cbox[i][0] = r[0]; cbox[i][1] = r[1]; cbox[i][2] = r[2]; cbox[i][3] = r[3];
+      ccls[i] = f - cand * C;
+    }
+    __syncthreads();
+    NSTAMP(3);
     // greedy scan by wave 0, 64 candidates per round
     if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
@@ -555,18 +595,15 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
         if (nk >= max_num) break;
         const int i = c0 + lane;
         const bool act = i < take;
-        float q[4] = {0, 0, 0, 0}, area = 0.f, scv = 0.f;
+        float q[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0}, area = 0.f, scv = 0.f;
         int cl = -1, pidx = 0;
         if (act) {
           const unsigned long long kv = keys[i];
           pidx = (int)(0xffffffffu - (unsigned)(kv & 0xffffffffull));
           scv = __uint_as_float((unsigned)(kv >> 32));
-          const int f = vflat[pidx];
-          const int cand = f / C;
-          cl = f - cand * C;
+          cl = ccls[i];
           const float off = (float)cl * off_unit;
-          const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
-          for (int u = 0; u < 4; ++u) q[u] = r[u] + off;
+          for (int u = 0; u < 4; ++u) { r[u] = cbox[i][u]; q[u] = r[u] + off; }
           area = (q[2] - q[0]) * (q[3] - q[1]);
         }
         bool sup = !act;
@@ -588,9 +625,6 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
           const int cs = __shfl(cl, s, 64);
           if (lane == s) {
             kbox[nk][0] = q[0]; kbox[nk][1] = q[1]; kbox[nk][2] = q[2]; kbox[nk][3] = q[3]; karea[nk] = area; kcls[nk] = cl;
-            const int f = vflat[pidx];
-            const int cand = f / C;
-            const f32x4 r = *reinterpret_cast<const f32x4*>(bx + (long long)cand * 4);
             float* o = dets + ((long long)b * max_num + nk) * 5;
             o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = scv;
             det_labels[(long long)b * max_num + nk] = cl;
@@ -609,6 +643,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
       if (lane == 0) s_nkept = nk;
     }
     __syncthreads();
+    NSTAMP(4);
     upper = kth;
     done += take;
   }
@@ -619,6 +654,8 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   for (int i = nk * 5 + threadIdx.x; i < max_num * 5; i += TB) dets[(long long)b * max_num * 5 + i] = 0.f;
   for (int i = nk + threadIdx.x; i < max_num; i += TB) { det_labels[(long long)b * max_num + i] = -1; keep[(long long)b * max_num + i] = -1; }
   if (threadIdx.x == 0) s_nvalid = nvalid;
+  NSTAMP(5);
+  if (g_nms_stamps_on()) { if (threadIdx.x == 0 && blockIdx.x == 0) g_nms_stamps_extra(nvalid, nk); }
 }
 
 extern "C" size_t aod_nms_ws_bytes(int B, int n, int C) { return (size_t)B * n * C * 4; }
