@@ -103,8 +103,17 @@ __global__ __launch_bounds__(1024) void hua_pairs_kernel(const HuaArgs p) {
       lvl = level_of(p, i);
       bool fg = p.any_fg[lvl * p.B + b] != 0;
       if (fg) {
-        float ms = 0.f;
-        for (int c = 0; c <= p.C; ++c) ms = fmaxf(ms, sc[(long long)i * (p.C + 1) + c]);   // SSD quirk: max incl. the bg column (0 for RetinaNet)
+        float ms = 0.f;                   // SSD quirk: max incl. the bg column (0 for RetinaNet)
+        const float* srow = sc + (long long)i * (p.C + 1);
+        if (p.C + 1 <= 24) {              // all loads of the row in flight at once (a run-time loop pays one round trip per class)
+          float sv[24];
+#pragma unroll
+          for (int c = 0; c < 24; ++c) sv[c] = c <= p.C ? srow[c] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 24; ++c) ms = fmaxf(ms, sv[c]);
+        } else {
+          for (int c = 0; c <= p.C; ++c) ms = fmaxf(ms, srow[c]);
+        }
         fg = ms > p.fg_thr;
       }
       if (fg && p.scale_mode) { mk[0] = 1ull; cnt = 1; }

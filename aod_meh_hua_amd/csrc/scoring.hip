@@ -220,7 +220,20 @@ __device__ void topk_block(const float* __restrict__ s, long long A, int k, int*
   int* const hist = L.hist;
   unsigned long long* const keys = L.keys;
   const long long ncache = A < (long long)cache_n ? A : (long long)cache_n;
-  for (long long i = threadIdx.x; i < ncache; i += TB) s_cache[i] = s[i];
+  {
+    // the row into LDS as 16-B pieces, up to twelve per thread requested before the first one is stored (one 4-B load per loop trip made
+    // the fill of a 36 864-anchor level a chain of 36 memory round trips)
+    const bool al = ((((size_t)s) | ((size_t)s_cache)) & 15) == 0;
+    const long long n4 = al ? ncache / 4 : 0;
+    for (long long i0 = threadIdx.x; i0 < n4; i0 += 12 * TB) {
+      f32x4 v[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (i0 + k * TB < n4) v[k] = reinterpret_cast<const f32x4*>(s)[i0 + k * TB];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) if (i0 + k * TB < n4) reinterpret_cast<f32x4*>(s_cache)[i0 + k * TB] = v[k];
+    }
+    for (long long i = n4 * 4 + threadIdx.x; i < ncache; i += TB) s_cache[i] = s[i];
+  }
   __syncthreads();
   auto key = [&](long long i) {
     const float v = i < ncache ? s_cache[i] : s[i];
