@@ -187,3 +187,43 @@ def test_ssd512_config_builds_the_seven_level_model():
     assert ag.base_sizes == [20, 51, 133, 215, 296, 378, 460]          # int(512 * {4, 10, 26, 42, 58, 74, 90} / 100)
     assert len(m.neck.extra_layers) == 5 and m.neck.extra_layers[-1][1].conv.kernel_size == (4, 4)
     assert len(m.bbox_head.cls_convs) == 7
+
+
+def test_wgrad_group_plan_is_host_logic_with_the_documented_properties(lib):
+    """aod_conv2d_wgrad_group_plan (host code of the C ABI, no launch): members of a group get FEWER pixel splits than alone, every member of a
+    group runs the same number of 64-pixel steps per workgroup, the grid fits the chip's slots, mixed tile forms are refused (return 1), and a
+    single member fills the slots too."""
+    from aod_meh_hua_amd.hipops import Seg, make_desc, out_segs
+    lib.aod_conv2d_wgrad_group_plan.restype = ctypes.c_int
+    lib.aod_conv2d_wgrad_splits.restype = ctypes.c_int
+
+    def desc(cin, cout, k, B, H, W):
+        src = [Seg(B, H, W, 0)]
+        return make_desc(cin, cout, k, k, 1, k // 2, 1, src, out_segs(src, k, k, 1, k // 2, 1), False, False, False)
+
+    def plan(ds):
+        n = len(ds)
+        out = (ctypes.c_int32 * n)()
+        rc = lib.aod_conv2d_wgrad_group_plan((ctypes.c_void_p * n)(*[ctypes.addressof(d) for d in ds]), n, out)
+        return rc, list(out)
+
+    # the three convs of a layer-2 identity bottleneck at 16 x 64 x 64 (128-tile form): 4 + 9 + 4 tiles
+    blk = [desc(128, 512, 1, 16, 64, 64), desc(128, 128, 3, 16, 64, 64), desc(512, 128, 1, 16, 64, 64)]
+    alone = [lib.aod_conv2d_wgrad_splits(ctypes.byref(d)) for d in blk]
+    rc, grp = plan(blk)
+    assert rc == 0 and all(g < a for g, a in zip(grp, alone)), (alone, grp)
+    assert len(set(grp)) == 1                                   # same pixel count -> same number of steps -> same splits
+    assert (4 + 9 + 4) * grp[0] <= 512 < (4 + 9 + 4) * (grp[0] + 2)
+    # one member through the group planner: it fills the slots (the single launches keep their own cost model: aod_conv2d_wgrad_splits)
+    rc, one = plan(blk[:1])
+    assert rc == 0 and 4 * one[0] <= 512 < 4 * (one[0] + 2) and alone[0] <= one[0]
+    # a head-tower conv (256 x 2304 over 87 296 pixels: the 256 x 256 tile) cannot share a grid with a 128-channel layer
+    tower = desc(256, 256, 3, 16, 64, 64)
+    rc, _ = plan([tower, blk[1]])
+    assert rc == 1
+    # four towers: 4 x 9 big tiles, the splits fill one round of the 256 CUs
+    rc, tw = plan([tower] * 4)
+    assert rc == 0 and 36 * tw[0] <= 256 < 36 * (tw[0] + 1)
+    # argument errors
+    rc, _ = plan([tower] * 5) if False else (lib.aod_conv2d_wgrad_group_plan(None, 1, None), None)
+    assert rc == -1
