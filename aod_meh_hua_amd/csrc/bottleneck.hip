@@ -352,10 +352,9 @@ extern "C" int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W,
   a.res = (const bf16_t*)res; a.y = (bf16_t*)y;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
   }
   hipLaunchKernelGGL(bottleneck64_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   AOD_LAUNCH_CHECK();

@@ -1367,12 +1367,11 @@ static int launch_wide(BnwArgs& a, hipStream_t st, bool frag = false) {
   const void* fn;
   if constexpr (PL == 128) fn = reinterpret_cast<const void*>(&bottleneck128_kernel<BWD>);
   else fn = reinterpret_cast<const void*>(&w256::bottleneck256_kernel<BWD>);
-  static bool attr_done = false;               // one flag per instantiation
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;               // one flag per instantiation
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (PL == 256)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w256r::bottleneck256r_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, w256r::LDS_BYTES);
-    attr_done = true;
   }
   if constexpr (PL == 128) hipLaunchKernelGGL(bottleneck128_kernel<BWD>, dim3(a.B * a.tiles_y * a.tiles_x), dim3(512), lds, st, a);
   else if (!frag) hipLaunchKernelGGL(w256::bottleneck256_kernel<BWD>, dim3(a.B * a.tiles_y * a.tiles_x), dim3(512), lds, st, a);

@@ -30,6 +30,16 @@ int aod_set_err(int code, const char* fmt, ...);
     if (e__ != hipSuccess) return aod_set_err(-3, "%s: %s", __func__, hipGetErrorString(e__)); \
   } while (0)
 
+// hipFuncSetAttribute is per DEVICE: a per-instantiation mask of the devices that already have the attribute (a bare `static bool` left a
+// second device of the same process launching with the default 64 KB dynamic-LDS limit)
+static inline bool aod_first_on_device(unsigned long long* mask) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+  if ((*mask >> d) & 1ull) return false;
+  *mask |= 1ull << d;
+  return true;
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 

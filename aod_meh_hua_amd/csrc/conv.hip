@@ -682,10 +682,9 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   const size_t epi_full = (size_t)BM * (BN + 4) * 4;
   const size_t epi = epi_full > 144 * 1024 ? epi_full / 2 : epi_full;      // (two epilogue passes for the 256 x 256 tile)
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
   return 0;
@@ -1347,14 +1346,13 @@ static int wgrad_fill(const aod_conv_desc_t* d, const void* x, const void* dz, f
 }
 
 static void wgrad_attrs() {
-  static bool attr_done = false;
-  if (attr_done) return;
+  static unsigned long long attr_done = 0;
+  if (!aod_first_on_device(&attr_done)) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-  attr_done = true;
 }
 
 static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,

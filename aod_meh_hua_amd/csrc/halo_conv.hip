@@ -331,10 +331,9 @@ template <int NB, int WPX, int R, bool OUT_F32>
 int launch_halo(const HaloArgs& a, hipStream_t st) {
   constexpr int LDS = 2 * PSLOT + R * 16 * NB * 128 + 1024;
   static_assert(LDS <= 160 * 1024 && 2 * PSLOT >= WPX * 1024, "LDS map (the column-sum staging overlays the halo slots)");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&halo_conv3x3_kernel<NB, WPX, R, OUT_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   hipLaunchKernelGGL((halo_conv3x3_kernel<NB, WPX, R, OUT_F32>), dim3(a.ntiles), dim3(512), LDS, st, a);
   return 0;

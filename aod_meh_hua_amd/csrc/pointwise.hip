@@ -345,10 +345,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int BM, int BN>
 int launch_pw(const PwArgs& a, hipStream_t st) {
   const size_t lds = (size_t)PW_NSTAGE * (BM + BN) * 128 + 3 * PW_NMAX * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   const long long ntiles = (long long)((a.M + BM - 1) / BM) * (a.N / BN);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);

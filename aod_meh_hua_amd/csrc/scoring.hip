@@ -274,10 +274,9 @@ extern "C" int aod_topk_stable(const float* score, int B, int64_t A, int k, int3
   AOD_CHECK_ARG(score && idx && k >= 1 && k <= 1024 && k <= A && out_pitch >= k, "topk: need 1 <= k <= min(1024, A)");
   // static LDS of the kernel: keys 8 KB + histogram 1 KB + scan; the rest of the 160 KB caches the row
   const int cache_n = (int)(A < 36864 ? A : 36864);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
-    attr_done = true;
   }
   hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TB), (size_t)cache_n * 4, (hipStream_t)stream, score, (long long)A, k, idx, (long long)out_pitch, cache_n);
   AOD_LAUNCH_CHECK();
@@ -441,11 +440,10 @@ extern "C" int aod_pre_nms_levels(int L, const float* const* cls, const float* c
   for (int i = 0; i < 4; ++i) { g.means[i] = means4 ? means4[i] : 0.f; g.stds[i] = stds4 ? stds4[i] : 1.f; }
   g.max_ratio = fabsf(logf(wh_ratio_clip));
   g.boxes = boxes; g.scores = scores; g.lam = lam; g.cand_anchor = cand_anchor; g.n_total = n_total; g.normalize = normalize;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_gather_levels_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_gather_levels_kernel<MAXC>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4);
-    attr_done = true;
   }
   const size_t srow = (size_t)256 * (C | 1) * 4, cache = (size_t)p.cache_n * 4;
   if (C <= 24) {
@@ -681,10 +679,9 @@ extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B
   // key cache: up to 12 288 valid (candidate, class) entries per image (96 KB of LDS beside the 16 KB of static arrays)
   const long long nc = (long long)n * C;
   const int kcache_n = (int)(nc < 12288 ? nc : 12288);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8);
-    attr_done = true;
   }
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), (size_t)kcache_n * 8, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
                      (long long*)det_labels, (long long*)keep, num_det, (int*)ws, kcache_n);

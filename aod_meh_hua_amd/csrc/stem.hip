@@ -176,10 +176,9 @@ extern "C" int aod_stem_pool_fwd(const void* x_s2d, const void* w_packed, const 
   a.B = B; a.H2 = H2; a.W2 = W2;
   a.H4 = (H2 - 1) / 2 + 1; a.W4 = (W2 - 1) / 2 + 1;          // max_pool2d(kernel 3, stride 2, padding 1)
   a.tiles_y = (a.H4 + PTH - 1) / PTH; a.tiles_x = (a.W4 + PTW - 1) / PTW;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
   }
   hipLaunchKernelGGL(stem_pool_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   AOD_LAUNCH_CHECK();

@@ -388,7 +388,7 @@ class _WgradQueue:
         keeps aliases); a parameter whose .grad exists, or that is used twice in one pass (the engine adds the two gradients when the second
         arrives), is not deferred -- and the second use flushes the queue first;
       * segmented backward passes (data parallelism) are separate engine runs: every segment's gradients are complete when its run returns."""
-    jobs, seen, task = [], set(), -1
+    jobs, seen, task, deferred = [], set(), -1, []
     enabled = _os.environ.get('AOD_WGRAD_GROUP', '1') != '0'
 
     @classmethod
@@ -398,35 +398,61 @@ class _WgradQueue:
             ho.wgrad_unpack_group(jobs)
 
     @classmethod
+    def _verify(cls):
+        """Every deferred gradient was handed to autograd UNWRITTEN on the assumption that AccumulateGrad installs the very tensor as .grad
+        (no read, no copy).  That is an implementation detail of the engine (use count, layout contract, grad mode): check it instead of
+        trusting it -- where .grad turned out to be another tensor (a clone taken before the launch filled ours), copy the finished values in."""
+        deferred, cls.deferred = cls.deferred, []
+        for _, pref, t in deferred:
+            p = pref()
+            if p is None or p.grad is None:
+                continue
+            g = p.grad
+            if g.data_ptr() != t.data_ptr() and g.shape == t.shape:
+                g.copy_(t)
+
+    @classmethod
     def _end_of_pass(cls):
         cls.task = -1
         cls.seen.clear()
         _S1_OF.clear()
         cls.flush()
+        cls._verify()
 
     @classmethod
-    def submit(cls, job, wid, defer):
-        # one end-of-pass callback per autograd run, recognised by the engine's graph-task id: a pass that died with an exception never ran
-        # its callback -- its leftovers must not leak into the next pass (they are launched now: their tensors are still alive and nobody
-        # reads them), and the next pass must get a callback of its own
+    def begin_pass(cls):
+        """one end-of-pass callback per autograd run, recognised by the engine's graph-task id: a pass that died with an exception never ran
+        its callback -- its leftovers must not leak into the next pass (they are launched now: their tensors are still alive and nobody
+        reads them), and the next pass must get a callback of its own.  Called by everything that leaves per-pass state behind (queued
+        jobs, _S1_OF entries), so that a pass without a trainable conv weight cleans up too."""
         tid = torch._C._current_graph_task_id()
         if tid != cls.task:
             cls.flush()
+            cls.deferred = []
             cls.task = tid
             cls.seen.clear()
             _S1_OF.clear()
-            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_pass)
+            if tid >= 0:
+                torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_pass)
+
+    @classmethod
+    def submit(cls, job, wid, defer):
+        cls.begin_pass()
         if wid in cls.seen or not (defer and cls.enabled):
             cls.flush()
             job.run_alone()
+            # a second use of a weight inside one pass: the engine ADDS the two gradients -- .grad is then no longer "our tensor or a clone
+            # of it", so the first use's entry must not be checked against it
+            cls.deferred = [e for e in cls.deferred if e[0] != wid]
             cls.seen.add(wid)
-            return
+            return False
         cls.seen.add(wid)
         if cls.jobs and ho.wgrad_group_splits(cls.jobs + [job]) is None:
             cls.flush()
         cls.jobs.append(job)
         if len(cls.jobs) == 4:
             cls.flush()
+        return True
 
 
 def _wgrad(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, w, O, I, dst, scale=None, bn=None, gamma=None):
@@ -439,8 +465,15 @@ def _wgrad(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, w, O, I, dst,
     job = ho.WgradJob(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, O, I, gw.detach(), scale=scale,
                       w=w.detach() if bn is not None else None, wdot=wdot.detach() if wdot is not None else None,
                       bn=tuple(t.detach() for t in bn) if bn is not None else None)
-    defer = R * S <= 9 and w.grad is None and (gamma is None or gamma.grad is None)
-    _WgradQueue.submit(job, id(w), defer)
+    # deferral hands autograd tensors that are written LATER (see _WgradQueue): only when nothing can read a gradient before the end-of-pass
+    # flush -- no hooks on the parameters, no anomaly mode (it checks every returned gradient for NaNs), no graph being built on the backward
+    hooked = lambda p: p is not None and bool(p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None))
+    defer = (R * S <= 9 and w.grad is None and (gamma is None or gamma.grad is None) and not torch.is_grad_enabled()
+             and not torch.is_anomaly_enabled() and not hooked(w) and not hooked(gamma))
+    if _WgradQueue.submit(job, id(w), defer):
+        _WgradQueue.deferred.append((id(w), _weakref.ref(w), gw))
+        if wdot is not None and gamma is not None:
+            _WgradQueue.deferred.append((id(w), _weakref.ref(gamma), wdot))
     return gw, wdot
 
 
@@ -530,6 +563,7 @@ class ConvFn(Function):
                 if Opad == O and len(y_segs) == 1:
                     # ... so a conv without ReLU at the end of that branch (the downsample conv + BN of a block's first bottleneck) needs no
                     # pass of its own for the column sums; the entry keeps dz alive, so its address cannot be handed out again meanwhile
+                    _WgradQueue.begin_pass()        # (registers the callback that empties _S1_OF even if no weight gradient is queued in this pass)
                     _S1_OF[dz.data_ptr()] = (s1, dz)
         x_segs = ctx.x_segs
         if need_w or need_bn:
@@ -865,8 +899,10 @@ def _frag_selfcheck(dev):
 
 
 def _frag_form(blk):
-    """the 256-plane block takes the register-streamed kernel with fragment-major filter images (AOD_BOTTLENECK_FRAG=0: the LDS-ring form)"""
-    if blk.planes != 256 or _os.environ.get('AOD_BOTTLENECK_FRAG', '1') == '0':
+    """AOD_BOTTLENECK_FRAG=1: the 256-plane block takes the register-streamed kernel with fragment-major filter images.  OFF by default
+    (round 4): logically equivalent variants of that kernel miscomputed a few lanes and the cause was never found, so
+    the LDS-ring form -- 0.15 ms per step slower, no such history -- is what ships; the opt-in still runs the self-check first."""
+    if blk.planes != 256 or _os.environ.get('AOD_BOTTLENECK_FRAG', '0') != '1':
         return False
     dev = blk.conv1.weight.device
     ok = _FRAG_OK.get(dev)

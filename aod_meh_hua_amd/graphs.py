@@ -127,7 +127,10 @@ class GraphedTrainStep:
             with AF.grad_cuts() as cl:
                 out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
             self.cur['cuts'] = list(reversed(cl))
-            assert len(cl) == self.nseg - 1, f'{len(cl)} gradient cuts for {self.nseg} bucket segments'
+            # the cuts the forward actually produced decide: when they do not match the bucket segments (a precision mode or model without
+            # cut points) the pass runs as whatever segments exist and ONE unsegmented all-reduce follows the last of them -- what the eager
+            # path (parallel.backward_and_sync) does in the same situation
+            self.cur['segmented'] = len(cl) == self.nseg - 1
         else:
             out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
         self.opt.zero_grad()
@@ -139,6 +142,8 @@ class GraphedTrainStep:
 
     def _seg_ak(self, k):
         """backward segment k >= 1: the backbone stage behind the k-th deepest cut"""
+        if k - 1 >= len(self.cur['cuts']):
+            return
         x, xc = self.cur['cuts'][k - 1]
         g, xc.grad = xc.grad, None
         if g is not None:
@@ -183,13 +188,16 @@ class GraphedTrainStep:
         if tag.startswith('a'):
             k = int(tag[1:] or 0)
             ent = self.sync.attach(main)
-            idx = [i for i in range(len(main)) if ent['seg_of'] is None or ent['seg_of'][i] == k]
+            whole = ent['seg_of'] is None or not cur.get('segmented', True)     # no per-segment buckets to send: one all-reduce at the end
+            if whole and ent['seg_of'] is not None and k < self.nseg - 1:
+                return
+            idx = [i for i in range(len(main)) if whole or ent['seg_of'][i] == k]
             if capturing:
                 src = cur.setdefault('src', [None] * len(main))
                 for i in idx:
                     src[i] = main[i].grad                                     # what this segment's captured kernels write
             else:
-                self.inflight.append(self.sync.start(main, sources=cur.get('src'), segment=k if ent['seg_of'] is not None else None))
+                self.inflight.append(self.sync.start(main, sources=cur.get('src'), segment=None if whole else k))
         elif tag == 'b':
             if capturing:
                 cur['src_L'] = [p.grad for p in meh]
