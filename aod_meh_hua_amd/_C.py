@@ -30,7 +30,7 @@ class ConvSeg(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('C', C.c_int32), ('N', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('stride', C.c_int32),
                 ('pad', C.c_int32), ('dil', C.c_int32), ('transposed', C.c_int32), ('relu', C.c_int32),
-                ('out_f32', C.c_int32), ('nseg', C.c_int32), ('seg', ConvSeg * 8)]
+                ('out_f32', C.c_int32), ('nseg', C.c_int32), ('x3', C.c_int32), ('seg', ConvSeg * 8)]
 
 
 P, I32, I64, F32, U64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -99,6 +99,15 @@ _SIGS = {
     'aod_ssd_loss_fwd': (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P, P]),
     'aod_ssd_loss_bwd': (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, F32, P, P, P, P, P, P]),
     'aod_synth_normal_images': (C.c_int, [P, I32, I64, U64, P, P]),
+    'aod_x3_split': (C.c_int, [P, P, I64, I32, P]),
+    'aod_x3_merge': (C.c_int, [P, P, I64, I32, P]),
+    'aod_x3_add': (C.c_int, [P, P, P, I64, P]),
+    'aod_x3_nchw_f32_to_s2d': (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    'aod_x3_maxpool3x3s2': (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    'aod_x3_upsample2x_add_to': (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_x3_upsample2x_add_bwd_set': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
+    'aod_x3_act_bwd': (C.c_int, [P, P, P, P, I64, I32, I32, P]),
+    'aod_x3_pad_cast_colsum': (C.c_int, [P, P, P, P, I64, I32, P]),
     'aod_sgd_multi': (C.c_int, [P, P, P, P, I32, F32, P, F32, F32, I32, F32, P]),
 }
 for _n, (_r, _a) in _SIGS.items():

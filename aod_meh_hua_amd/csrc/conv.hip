@@ -35,6 +35,7 @@ struct ConvKParams {
   int ngroups;        // > 1: grouped launch (aod_conv2d_grouped): grp[] replaces x / w / y / pre_shift / mask / colsum
   ConvGroup grp[4];
   int stagger;        // 8-wave forms: waves 4-7 run half a K-step behind waves 0-3 (see the K loop)
+  int x3;             // reference-precision mode (aod_conv_desc_t.x3): operands in the X-layout, three MFMAs per 32 channels (see X3 below)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
@@ -67,10 +68,20 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 
 // OPS: which optional epilogue operands the instance supports -- 0 none, 1 ReLU mask only, 2 residual and mask (their prefetch registers
 // are what pushes the 8-wave form into spills, so it exists without them)
-template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST>
+// X3: the REFERENCE-PRECISION form (fp32-equivalent products on the bf16 matrix pipe).  Every fp32 value v travels as a bf16 head and a
+// bf16 tail, v ~= h + l (h = bf16(v), l = bf16(v - h): 16 significant bits), in the X-LAYOUT: a tensor of C logical channels has
+// 2 * ceil32(C) bf16 columns, [h(0..31) | l(0..31) | h(32..63) | l(32..63) | ...].  A 64-column K-step of such an operand is then 32
+// channels whose heads are k-block 0 and whose tails are k-block 1, for the activations and for the packed filters alike, and
+//     x * w ~= xh * wh + xl * wh + xh * wl            (the dropped xl * wl is 2^-16 of the product)
+// is THREE MFMAs on fragments the unmodified staging already put into the LDS (the plain form issues two per K-step): same tiles, same
+// LDS-DMA gather, same barriers.  The epilogue computes in fp32 as before (BN / bias / residual = head + tail / mask / ReLU / column
+// sums) and writes head and tail of each value, 64 B apart.  p.N stays the LOGICAL output channel count (vector operands, fp32
+// destinations); p.C / p.K are the physical (X-layout) widths of the source and of the packed filter rows.
+template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST, bool X3>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(ST == 2 || (ST == 3 && NT == 256), "LDS stages: 2, or 3 for the 4-wave forms");
+  static_assert(!X3 || (NT == 256 && !GROUPED && BM <= 128), "X3: 4-wave ungrouped forms");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
   constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // the fp32 epilogue image of a 256 x 256 tile (266 KB) does not fit the LDS: it is written and stored in EP passes of EBM rows
   constexpr int EP = (BM * CP * 4 > 144 * 1024) ? 2 : 1;
   constexpr int EBM = BM / EP;
-  constexpr bool PREFETCH = EP == 1;       // residual / mask rows prefetched into registers before the K loop (not for the big tile: 16 x 8 regs)
+  constexpr bool PREFETCH = EP == 1 && !X3;       // residual / mask rows prefetched into registers before the K loop (not for the big tile: 16 x 8 regs; not in X3: twice the pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x;
@@ -327,9 +338,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // interior tiles of the common configuration (bf16 destination, N % 8 == 0, no post-scale / raw copy) take an epilogue without per-thread
   // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
   const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
+  // destination row pitch and column of logical channel n (elements): X-layout for the bf16 destinations of an X3 launch
+  const bool xout = X3 && !p.out_f32;
+  const int NP = xout ? ((p.N + 31) >> 5) << 6 : p.N;
+  auto xcol = [&](int n) { return xout ? ((n >> 5) << 6) + (n & 31) : n; };
   const long long drow_lin = linear ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
-  const long long lin_off = (drow_lin + m0 + er) * p.N + n0 + ec * 8;     // element offset of this thread's first row segment
-  const long long lin_step = (long long)(NT / NCH) * p.N;                // ... and the distance to its next one
+  const long long lin_off = (drow_lin + m0 + er) * NP + xcol(n0 + ec * 8);     // element offset of this thread's first row segment
+  const long long lin_step = (long long)(NT / NCH) * NP;                // ... and the distance to its next one
   auto prefetch_epilogue = [&](bool from_table) {
     const int n = n0 + ec * 8;
     if (fast) {
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         const int row = er + it * (NT / NCH);
         const bool ok = (m0 + row < p.M) && (n + 8 <= p.N);
         const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
-        const long long off = ok ? drow * p.N + n : 0;
+        const long long off = ok ? drow * NP + xcol(n) : 0;
         if (OPS > 1 && p.res && ok) pres[it] = *reinterpret_cast<const bf16x8*>(p.res + off);
         if (OPS > 0 && g_mask && ok) pmask[it] = *reinterpret_cast<const bf16x8*>(g_mask + off);
       }
@@ -441,6 +456,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       for (int j = 0; j < NI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
   };
+  // one K-step.  Plain: the two 32-deep k-blocks.  X3: k-block 0 = heads, k-block 1 = tails of the same 32 channels -> xh*wh, xl*wh, xh*wl
+  // (the tails of the activations are read while the head fragments stay in registers; the weight fragments are replaced last)
+  auto kstep = [&](const char* sa, const char* sb) {
+    frag_read(sa, sb, 0);
+    mfma_block();
+    if constexpr (X3) {
+      bf16x8 al[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WM + i * 16 + lr;
+        al[i] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfr[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WN + j * 16 + lr;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
+      }
+      mfma_block();
+    } else {
+      frag_read(sa, sb, 1);
+      mfma_block();
+    }
+  };
   if (ST == 3) {
     // Three-stage ring (4-wave forms whose K-step is shorter than a load: one stage ahead, every K-step waits out the rest of a
     // load latency).  Stage s + 2 is issued at step s, the wait before the barrier names how many younger LDS-DMA instructions may
@@ -456,10 +499,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       if (more2) gload(cur == 0 ? 2 : cur - 1);
       const char* sa = smem + cur * STAGE;
       const char* sb = sa + A_BYTES;
-      frag_read(sa, sb, 0);
-      mfma_block();
-      frag_read(sa, sb, 1);
-      mfma_block();
+      kstep(sa, sb);
       if (!have1) break;
       __builtin_amdgcn_sched_barrier(0);
       if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -479,10 +519,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
     static_assert(BK == 64, "two 32-deep k-blocks per K-step");
-    frag_read(sa, sb, 0);
-    mfma_block();
-    frag_read(sa, sb, 1);
-    if (!late) mfma_block(); else carried = true;
+    if constexpr (X3) kstep(sa, sb);
+    else {
+      frag_read(sa, sb, 0);
+      mfma_block();
+      frag_read(sa, sb, 1);
+      if (!late) mfma_block(); else carried = true;
+    }
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier: next tile is resident afterwards
   }
   if (late && carried) mfma_block();
@@ -530,8 +573,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // fast tiles: no per-thread predicates at all, only workgroup-uniform branches -- the general loop below costs ~500 instructions
   // per 16-B store, this one under 100
   if (fast) {
-    bf16_t* const yb = reinterpret_cast<bf16_t*>(g_y) + n0 + ec * 8;
-    bf16_t* const yl = reinterpret_cast<bf16_t*>(g_y) + lin_off + (long long)r0e * p.N;
+    bf16_t* const yb = reinterpret_cast<bf16_t*>(g_y) + xcol(n0 + ec * 8);
+    bf16_t* const yl = reinterpret_cast<bf16_t*>(g_y) + lin_off + (long long)r0e * NP;
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
       const int row = er + it * (NT / NCH);
@@ -546,11 +589,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += cb1[j];
-      const long long eoff = linear ? lin_off + (long long)r0e * p.N + it * lin_step : s_drow[r0e + row] * p.N + n0 + ec * 8;
+      const long long eoff = linear ? lin_off + (long long)r0e * NP + it * lin_step : s_drow[r0e + row] * NP + xcol(n0 + ec * 8);
       if (OPS > 1 && p.res) {
         const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + eoff);
+        if constexpr (X3) {
+          const bf16x8 rl = *reinterpret_cast<const bf16x8*>(p.res + eoff + 32);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j] + (float)rl[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        }
       }
       if (OPS > 0 && g_mask) {
         const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + eoff);
@@ -564,7 +613,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       bf16x8 ov;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { csum[j] += v[j]; ov[j] = (bf16_t)v[j]; }
-      *reinterpret_cast<bf16x8*>(linear ? yl + it * lin_step : yb + s_drow[r0e + row] * p.N) = ov;
+      bf16_t* const yo = linear ? yl + it * lin_step : yb + s_drow[r0e + row] * NP;
+      *reinterpret_cast<bf16x8*>(yo) = ov;
+      if constexpr (X3) {
+        bf16x8 ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ol[j] = (bf16_t)(v[j] - (float)ov[j]);
+        *reinterpret_cast<bf16x8*>(yo + 32) = ol;
+      }
     }
   } else
 #pragma unroll
@@ -583,13 +639,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
     for (int j = 0; j < 8; ++j) raw[j] = v[j];
     if (full) {
-      const long long off = drow * p.N + n;
+      const long long off = drow * NP + xcol(n);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
       if (OPS > 1 && p.res) {
         const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        if (xout) {
+          const bf16x8 rl = *reinterpret_cast<const bf16x8*>(p.res + off + 32);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rl[j];
+        }
       }
       if (OPS > 0 && g_mask) {
         const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + off);
@@ -620,6 +681,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(g_y) + off) = ov;
+        if (xout) {
+          bf16x8 ol;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ol[j] = (bf16_t)(v[j] - (float)ov[j]);
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(g_y) + off + 32) = ol;
+        }
       }
       if (p.zraw) {
         bf16x8 zv;
@@ -673,7 +740,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
 #undef g_colsum
 #undef AOD_GSEL
 
-template <int BM, int BN, int NT = 256, int OPS = 2, bool GROUPED = false, int ST = 2>
+template <int BM, int BN, int NT = 256, int OPS = 2, bool GROUPED = false, int ST = 2, bool X3 = false>
 static int launch_conv(const ConvKParams& p, hipStream_t st) {
   ConvKParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
@@ -684,9 +751,9 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   const size_t lds = (stage > epi ? stage : epi) + (size_t)BM * 8;     // staging | fp32 epilogue image, then the destination-row table
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST, X3>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
   return 0;
 }
 
@@ -696,7 +763,8 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
   AOD_CHECK_ARG(d->stride >= 1 && d->dil >= 1 && d->R >= 1 && d->S >= 1, "conv: bad geometry");
   p.C = d->C; p.N = d->N; p.R = d->R; p.S = d->S; p.K = d->R * d->S * d->C;
   p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.transposed = d->transposed;
-  p.relu = d->relu; p.out_f32 = d->out_f32; p.nseg = d->nseg;
+  p.relu = d->relu; p.out_f32 = d->out_f32; p.nseg = d->nseg; p.x3 = d->x3 ? 1 : 0;
+  if (p.x3) AOD_CHECK_ARG(d->C % 64 == 0, "conv (x3): X-layout source width %d must be a multiple of 64", d->C);
   long long m = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const aod_conv_seg_t& s = d->seg[i];
@@ -768,12 +836,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
           for (int j = 0; j < 8; ++j) raw[j] += n + j < p.N ? w[z * slab + j] : 0.f;
         }
       }
-      const long long off = drow * p.N + n;
+      // (X3 launches with a bf16 destination: X-layout rows, heads and tails 32 columns apart)
+      const bool xout = p.x3 && !p.out_f32;
+      const int NP = xout ? ((p.N + 31) >> 5) << 6 : p.N;
+      const long long off = drow * NP + (xout ? ((n >> 5) << 6) + (n & 31) : n);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (n + j >= p.N) { v[j] = 0.f; continue; }
         float u = raw[j] * cs1[j] + cb1[j];
-        if (p.res) u += (float)p.res[off + j];
+        if (p.res) u += xout ? (float)p.res[off + j] + (float)p.res[off + 32 + j] : (float)p.res[off + j];
         if (p.mask) u = ((float)p.mask[off + j] > 0.f) ? u : 0.f;
         if (p.post_scale) u *= cs2[j];
         if (p.relu) u = fmaxf(u, 0.f);
@@ -785,6 +856,12 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)v[j];
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off) = ov;
+        if (xout) {
+          bf16x8 ol;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ol[j] = (bf16_t)(v[j] - (float)ov[j]);
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.y) + off + 32) = ol;
+        }
       } else {
         for (int j = 0; j < 8 && n + j < p.N; ++j) {
           if (p.out_f32) reinterpret_cast<float*>(p.y)[off + j] = v[j];
@@ -829,6 +906,11 @@ static int conv_params(const aod_conv_desc_t* desc, const void* src, const void*
   int rc = fill_params(desc, p);
   if (rc) return rc;
   AOD_CHECK_ARG(!(desc->out_f32 && zraw), "conv: zraw needs a bf16 destination");
+  if (desc->x3) {
+    AOD_CHECK_ARG(!zraw && !post_scale, "conv (x3): zraw / post_scale are not supported");
+    AOD_CHECK_ARG(desc->out_f32 || desc->N % 32 == 0, "conv (x3): a bf16 (X-layout) destination needs N %% 32 == 0, got %d", desc->N);
+    AOD_CHECK_ARG(!(desc->out_f32 && (res || mask)), "conv (x3): residual / mask operands need an X-layout destination");
+  }
   p.x = (const bf16_t*)src; p.w = (const bf16_t*)w_packed; p.y = dst;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.res = (const bf16_t*)res; p.mask = (const bf16_t*)mask;
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
@@ -868,7 +950,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   if (p.M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // 1x1, stride 1: a plain GEMM over consecutive rows -- the persistent streaming kernel (pointwise.hip) when its launch heuristic wants it
-  if (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && !p.out_f32 && !p.zraw && !p.post_scale) {
+  if (!p.x3 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && !p.out_f32 && !p.zraw && !p.post_scale) {
     PwArgs a;
     const long long s0 = p.seg_src0[0], d0 = p.seg_dst0[0];
     a.x = p.x + s0 * p.C; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y) + d0 * p.N;
@@ -882,7 +964,8 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     const size_t need = (size_t)ks * p.M * p.N * 4;
     AOD_CHECK_ARG(workspace_bytes >= need, "conv: split-K workspace of %zu bytes, need %zu (aod_conv2d_ws_bytes)", workspace_bytes, need);
     p.ksplit = ks; p.ws = (float*)workspace;
-    if (p.N > 64) launch_conv<128, 128>(p, st); else launch_conv<128, 64>(p, st);
+    if (p.x3) { if (p.N > 64) launch_conv<128, 128, 256, 2, false, 2, true>(p, st); else launch_conv<128, 64, 256, 2, false, 2, true>(p, st); }
+    else if (p.N > 64) launch_conv<128, 128>(p, st); else launch_conv<128, 64>(p, st);
     AOD_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((p.M + 7) / 8, (p.N + 255) / 256), dim3(256), 0, st, p);
     AOD_LAUNCH_CHECK();
@@ -894,6 +977,17 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
+  if (p.x3) {
+    // X3: the 4-wave forms (three MFMAs per staged K-step: the staging-bound arguments for the 8-wave and 256 x 256 forms do not carry over)
+    if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
+    else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128, 256, 2, false, 2, true>(p, st);
+    else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128, 256, 2, false, 3, true>(p, st);
+    else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
+    else if (p.N > 64 && ntiles(128, 64) >= want && p.N % 128 != 0) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
+    else launch_conv<64, 64, 256, 2, false, 3, true>(p, st);
+    AOD_LAUNCH_CHECK();
+    return 0;
+  }
   // deep convs without a residual operand (forward and dgrad of the head towers, the 3x3 of the backbone): the 128 x 128 tile on 8
   // waves -- four waves per SIMD hide more of the K loop's waits than two (-4 % on the head-tower shape); with the residual's prefetch
   // registers as well the 8-wave form spills and loses
@@ -934,6 +1028,7 @@ extern "C" int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, cons
                                   aod_stream_t stream) {
   AOD_CHECK_ARG(desc && src && w_packed && dst && ngroups >= 1 && ngroups <= 4, "conv_grouped: 1..4 groups");
   AOD_CHECK_ARG(!desc->out_f32, "conv_grouped: bf16 destinations only");
+  AOD_CHECK_ARG(!desc->x3, "conv_grouped: no X3 form");
   ConvKParams p;
   int rc = conv_params(desc, src[0], w_packed[0], dst[0], nullptr, pre_shift ? pre_shift[0] : nullptr, nullptr, mask ? mask[0] : nullptr, nullptr,
                        nullptr, colsum ? colsum[0] : nullptr, p);
@@ -1042,7 +1137,7 @@ struct WgradParams {
   const RowRec* tab;
   int C, N, K, R, S, dil;
   int M;
-  int tiles_n, tiles_k, splits, rows_per_split, stagger, xcd_order;
+  int tiles_n, tiles_k, splits, rows_per_split, stagger, xcd_order, x3;
   long long x_bytes, z_bytes, tab_bytes;
   long long slab_stride;     // > 0: split s STORES its partial tile into dw + s * slab_stride (deterministic, summed by the unpack); 0: fp32 atomics
 };
@@ -1060,8 +1155,13 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 // CU.  256 x 256 tile (TN = TK = 2, 8 waves as 2 x 4, 128 x 64 per wave, one workgroup per CU): the fragment reads are 8-B transposed
 // reads, so the 128 x 128 form moves 768 B of LDS per MFMA -- more than the LDS delivers at the matrix pipe's rate; the big tile halves
 // that (and the LDS-DMA traffic per MFMA), like the 256 x 256 tile of the forward kernel.
-template <int NW, int TN, int TK>
+// X3 (aod_conv_desc_t.x3): dZ and X are X-layout rows, so the 128 x 128 tile of dW' = dZ'^T X' holds the four products of 64 x 64 logical
+// entries -- (zh, zl) x (xh, xl) in 32-wide bands.  The 2 x 2 wave grid gives every wave the 64 x 64 block [zh32 | zl32] x [xh32 | xl32]:
+// its zl x xl quarter (2^-16 of the result) is skipped, which leaves exactly the three products of the forward form; the unpack kernel adds
+// the three bands of every slab.
+template <int NW, int TN, int TK, bool X3>
 __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
+  static_assert(!X3 || (NW == 4 && TN == 1 && TK == 1), "X3: the 4-wave 128 x 128 form");
   constexpr int RPW = 4 * NW;          // pixel rows covered per pass of all waves
   constexpr int PASSES = 64 / RPW;
   constexpr int WNC = NW / 2;          // waves along the (tap, channel) axis
@@ -1217,8 +1317,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j) {
+        if (X3 && i >= NI / 2 && j >= NJ / 2) continue;       // tail x tail
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
   };
   for (int stp = 0; stp < nsteps; ++stp) {
     const int cur = stp & 1;
@@ -1270,32 +1372,32 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
 // MI355X): one 64-pixel step costs ~1.45 us with one workgroup per CU and ~1.7 us with two (both share the CU); every workgroup ends with
 // 64 KB of output -- fp32 atomics at ~1.3 TB/s chip-wide (0.05 us per workgroup) or, in slab mode, plain stores at ~5.5 TB/s (0.012 us)
 // plus the unpack kernel's read of one more slab per split.
-template <int NW, int TN, int TK>
+template <int NW, int TN, int TK, bool X3 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_kernel(const WgradParams p) {
-  wgrad_tile<NW, TN, TK>(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
+  wgrad_tile<NW, TN, TK, X3>(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
 }
 // Grouped launch: up to WG_MAXG weight gradients (ANY geometries, one tile form) share one grid.  Alone a backbone layer needs 100+ pixel
 // splits of its few 128 x 128 tiles to fill the chip -- a 512 x 128 filter (256 KB) leaves 30 MB of partial slabs for the unpack; three
 // layers together need a third of the splits each (longer pixel runs per workgroup, a third of the slab traffic, one launch).
 constexpr int WG_MAXG = 4;
 struct WgradGroups { WgradParams g[WG_MAXG]; int wg0[WG_MAXG + 1]; int n; };
-template <int NW, int TN, int TK>
+template <int NW, int TN, int TK, bool X3 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK > 1 ? 2 : NW / 2, TN * TK > 1 ? 2 : NW / 2))) void conv_wgrad_grouped_kernel(const WgradGroups gp) {
   const int b = gp.g[0].xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
   // (selects, not an indexed read of the argument block: a run-time index would move the whole array to scratch memory)
-  if (b < gp.wg0[1]) wgrad_tile<NW, TN, TK>(gp.g[0], b);
-  else if (b < gp.wg0[2]) wgrad_tile<NW, TN, TK>(gp.g[1], b - gp.wg0[1]);
-  else if (b < gp.wg0[3]) wgrad_tile<NW, TN, TK>(gp.g[2], b - gp.wg0[2]);
-  else wgrad_tile<NW, TN, TK>(gp.g[3], b - gp.wg0[3]);
+  if (b < gp.wg0[1]) wgrad_tile<NW, TN, TK, X3>(gp.g[0], b);
+  else if (b < gp.wg0[2]) wgrad_tile<NW, TN, TK, X3>(gp.g[1], b - gp.wg0[1]);
+  else if (b < gp.wg0[3]) wgrad_tile<NW, TN, TK, X3>(gp.g[2], b - gp.wg0[2]);
+  else wgrad_tile<NW, TN, TK, X3>(gp.g[3], b - gp.wg0[3]);
 }
 
-static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big, int big_min_m = 49152) {
+static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big, int big_min_m = 49152, int x3 = 0) {
   // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
   static const char* dbg_big = getenv("AOD_WGRAD_256");
   // (measured, single launches: 16 x 32 x 32 pixels lose 15 % with the big tile, 16 x 64 x 64 gain 10 %; members of a GROUP get longer pixel
   // runs per workgroup and take it from 16 384 pixels on: -0.11 ms per step, AOD_WGRAD_BIG_MINM overrides the group threshold)
   big = (N % 256 == 0 && K % 256 == 0 && M >= big_min_m) ? 1 : 0;
-  if (dbg_big && dbg_big[0] == '0') big = 0;
+  if ((dbg_big && dbg_big[0] == '0') || x3) big = 0;
   const int T = big ? 256 : 128;
   tiles_n = (N + T - 1) / T;
   tiles_k = (K + T - 1) / T;
@@ -1327,7 +1429,8 @@ static int wgrad_fill(const aod_conv_desc_t* d, const void* x, const void* dz, f
   if (rc) return rc;
   memset(&p, 0, sizeof(p));
   p.x = (const bf16_t*)x; p.dz = (const bf16_t*)dz; p.dw = dw; p.tab = (const RowRec*)row_table;
-  p.C = cp.C; p.N = cp.N; p.K = cp.K; p.R = cp.R; p.S = cp.S; p.dil = cp.dil; p.M = cp.M;
+  p.C = cp.C; p.N = cp.N; p.K = cp.K; p.R = cp.R; p.S = cp.S; p.dil = cp.dil; p.M = cp.M; p.x3 = cp.x3;
+  if (p.x3) AOD_CHECK_ARG(p.N % 64 == 0 && p.C % 64 == 0, "wgrad (x3): X-layout widths (dZ %d, x %d) must be multiples of 64", p.N, p.C);
   long long xrows = 0, zrows = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const aod_conv_seg_t& sg = d->seg[i];
@@ -1353,6 +1456,8 @@ static void wgrad_attrs() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
 }
 
 static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
@@ -1362,7 +1467,7 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   if (rc) return rc;
   if (p.M == 0) return 0;
   int splits, rps, big;
-  wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps, big);
+  wgrad_plan(p.M, p.N, p.K, slab_stride > 0, p.tiles_n, p.tiles_k, splits, rps, big, 49152, p.x3);
   const int tiles = p.tiles_n * p.tiles_k;
   p.splits = splits; p.rows_per_split = rps;
   p.slab_stride = slab_stride;
@@ -1372,7 +1477,10 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   }
   wgrad_attrs();
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
-  if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+  if (p.x3) {
+    AOD_CHECK_ARG(slab_stride > 0, "wgrad (x3): slab form only");
+    hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, true>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
+  } else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
   else if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL((conv_wgrad_kernel<8, 1, 1>), dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   AOD_LAUNCH_CHECK();
@@ -1382,14 +1490,14 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
 // Split plan of a GROUP (slab form): every workgroup of the launch runs the same number T of 64-pixel steps (the groups' tiles are the same
 // size, so that equalises their durations); T = the smallest for which the grid fits the chip's slots -- group g then gets ceil(steps_g / T)
 // splits.  All members must take the same tile form (`big` of wgrad_plan); returns that form, or -1 when they do not.
-static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int* tiles_n, int* tiles_k, int* splits, int* rps) {
+static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int* tiles_n, int* tiles_k, int* splits, int* rps, int x3 = 0) {
   int big = -1;
   long long tiles[WG_MAXG];
   int steps[WG_MAXG], max_steps = 1;
   for (int g = 0; g < n; ++g) {
     int sp, r, b;
     static const char* dbg_minm = getenv("AOD_WGRAD_BIG_MINM");
-    wgrad_plan(M[g], N[g], K[g], true, tiles_n[g], tiles_k[g], sp, r, b, n > 1 ? (dbg_minm ? atoi(dbg_minm) : 16384) : 49152);
+    wgrad_plan(M[g], N[g], K[g], true, tiles_n[g], tiles_k[g], sp, r, b, n > 1 ? (dbg_minm ? atoi(dbg_minm) : 16384) : 49152, x3);
     if (big >= 0 && b != big) return -1;
     big = b;
     tiles[g] = (long long)tiles_n[g] * tiles_k[g];
@@ -1422,8 +1530,9 @@ extern "C" int aod_conv2d_wgrad_group_plan(const aod_conv_desc_t* const* descs, 
     if (rc) return rc;
     AOD_CHECK_ARG(cp.M > 0, "wgrad_group_plan: empty member");
     M[g] = cp.M; N[g] = cp.N; K[g] = cp.K;
+    if (descs[g]->x3 != descs[0]->x3) return 1;      // (mixed precision modes never share a grid)
   }
-  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps);
+  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps, descs[0]->x3);
   if (big < 0) return 1;                       // mixed tile forms: launch the members one by one
   for (int g = 0; g < n; ++g) splits_out[g] = sp[g];
   return 0;
@@ -1441,8 +1550,10 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
     if (rc) return rc;
     AOD_CHECK_ARG(gp.g[g].M > 0, "wgrad_grouped: empty member");
     M[g] = gp.g[g].M; N[g] = gp.g[g].N; K[g] = gp.g[g].K;
+    AOD_CHECK_ARG(gp.g[g].x3 == gp.g[0].x3, "wgrad_grouped: members of different precision modes");
   }
-  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps);
+  const int x3 = gp.g[0].x3;
+  const int big = wgrad_plan_group(n, M, N, K, tn, tk, sp, rps, x3);
   AOD_CHECK_ARG(big >= 0, "wgrad_grouped: the members take different tile forms (aod_conv2d_wgrad_group_plan tells)");
   int wg = 0;
   for (int g = 0; g < n; ++g) {
@@ -1456,7 +1567,8 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
   for (int g = n; g <= WG_MAXG; ++g) gp.wg0[g] = g == n ? wg : 0x7fffffff;
   gp.n = n;
   wgrad_attrs();
-  if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  if (x3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<4, 1, 1, true>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
+  else if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
   else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 1, 1>), dim3(wg), dim3(512), 65536 + 4096, (hipStream_t)stream, gp);
   AOD_LAUNCH_CHECK();
   return 0;
@@ -1473,7 +1585,7 @@ extern "C" int aod_conv2d_wgrad_splits(const aod_conv_desc_t* d) {
   memset(&cp, 0, sizeof(cp));
   if (fill_params(d, cp) || cp.M == 0) return 0;
   int tn, tk, splits, rps, big;
-  wgrad_plan(cp.M, cp.N, cp.K, true, tn, tk, splits, rps, big);
+  wgrad_plan(cp.M, cp.N, cp.K, true, tn, tk, splits, rps, big, 49152, cp.x3);
   return splits;
 }
 
@@ -1541,6 +1653,7 @@ struct UnpackArgs {
   const float* dw; float* g; const float* scale; const float* w; float* wdot; const float* bn_s1; const float* bn_mean; const float* bn_invstd;
   long long slab_stride;
   int nslabs, O, I, RS, Ipad, accumulate;
+  int x3;      // slabs of an X3 wgrad launch: rows / columns in the X-layout; dW[o][c] = hh + hl + lh bands (the ll band was never computed)
 };
 __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* tile, float* red) {
   const float* __restrict__ dw = a.dw;
@@ -1554,8 +1667,20 @@ __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* t
     const int nc = min(UNP_CH, I - c0);
     for (int i = threadIdx.x; i < nc * RS; i += UNP_T) {
       const int rs = i / nc, c = i - rs * nc;                       // consecutive lanes on consecutive channels of one slab row
-      const float* src = dw + ((long long)oo * RS + rs) * Ipad + c0 + c;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                 // fixed association: ((s0+s4+..)+(s1+s5+..))+((s2+..)+(s3+..))
+      if (a.x3) {
+        // X-layout slabs: row of the heads of output channel oo, 32 rows further its tails; column of the heads of input channel cc, 32
+        // columns further its tails.  Per slab (zh.xh + zh.xl) + zl.xh, slabs in order: deterministic like the plain form.
+        const int cc = c0 + c;
+        const float* sh = dw + ((long long)(((oo >> 5) << 6) + (oo & 31)) * RS + rs) * Ipad + ((cc >> 5) << 6) + (cc & 31);
+        const float* sl_ = sh + (long long)32 * RS * Ipad;
+        for (int sl = 0; sl < nslabs; ++sl) {
+          const long long o = (long long)sl * slab_stride;
+          const float b = (sh[o] + sh[o + 32]) + sl_[o];
+          if ((sl & 3) == 0) v0 += b; else if ((sl & 3) == 1) v1 += b; else if ((sl & 3) == 2) v2 += b; else v3 += b;
+        }
+      } else {
+      const float* src = dw + ((long long)oo * RS + rs) * Ipad + c0 + c;
       int sl = 0;
       for (; sl + 4 <= nslabs; sl += 4) {
         const float a0 = src[(long long)sl * slab_stride], a1 = src[(long long)(sl + 1) * slab_stride];
@@ -1563,6 +1688,7 @@ __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* t
         v0 += a0; v1 += a1; v2 += a2; v3 += a3;
       }
       for (; sl < nslabs; ++sl) v0 += src[(long long)sl * slab_stride];
+      }
       tile[c * RS + rs] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
@@ -1609,8 +1735,8 @@ struct PrepItem {            // 16 x 8 bytes, filled by the host into a device t
   const float* w; const float* gamma; const float* beta; const float* mean; const float* var;
   bf16_t* wf; bf16_t* wd; float* scale; float* shift; float* invstd;
   int O, I, RS, Ipad, Opad, blk0;      // blk0: first block of this item
-  float eps; int pad_;
-  long long pad2_[2];
+  float eps; int flags;                // flags bit 0: X3 images (X-layout along the packed channel axis: Ipad / Opad are then the PHYSICAL
+  long long pad2_[2];                  // widths 2 * ceil32(I) / 2 * ceil32(O); head = bf16(v), tail = bf16(v - head), v = w (* BN scale, dgrad))
 };
 // One block = one 32 (out channels) x 32 (in channels) tile of one layer, all R*S taps: the fp32 master weights are read ONCE, coalesced
 // (for a fixed output channel the (c, tap) run is contiguous), staged in LDS and written out as both packed images in 64-byte runs.
@@ -1630,15 +1756,21 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
     const long long nf = (long long)it.O * it.RS * it.Ipad, nd = it.wd ? (long long)it.I * it.RS * it.Opad : 0;
     for (int u = 0; u < 8; ++u) {
       const long long i = (long long)lb * 2048 + u * 256 + t;
+      const bool x3 = it.flags & 1;
       if (i < nf) {
-        const int c = i % it.Ipad; const long long r1 = i / it.Ipad; const int rs = r1 % it.RS; const int oo = r1 / it.RS;
-        it.wf[i] = (c < it.I) ? (bf16_t)it.w[((long long)oo * it.I + c) * it.RS + rs] : (bf16_t)0.f;
+        const int cp = i % it.Ipad; const long long r1 = i / it.Ipad; const int rs = r1 % it.RS; const int oo = r1 / it.RS;
+        const int c = x3 ? ((cp >> 6) << 5) + (cp & 31) : cp;              // logical channel of physical column cp
+        const float v = (c < it.I) ? it.w[((long long)oo * it.I + c) * it.RS + rs] : 0.f;
+        const bf16_t h = (bf16_t)v;
+        it.wf[i] = (x3 && (cp & 32)) ? (bf16_t)(v - (float)h) : h;
       }
       if (i < nd) {
-        const int oo = i % it.Opad; const long long r1 = i / it.Opad; const int rs = r1 % it.RS; const int c = r1 / it.RS;
+        const int op = i % it.Opad; const long long r1 = i / it.Opad; const int rs = r1 % it.RS; const int c = r1 / it.RS;
+        const int oo = x3 ? ((op >> 6) << 5) + (op & 31) : op;
         float v = 0.f;
         if (oo < it.O) { v = it.w[((long long)oo * it.I + c) * it.RS + rs]; if (it.gamma) v *= it.gamma[oo] * rsqrtf(it.var[oo] + it.eps); }
-        it.wd[i] = (bf16_t)v;
+        const bf16_t h = (bf16_t)v;
+        it.wd[i] = (x3 && (op & 32)) ? (bf16_t)(v - (float)h) : h;
       }
       if (it.gamma && i < it.O) {
         const float inv = rsqrtf(it.var[i] + it.eps), sc = it.gamma[i] * inv;
@@ -1647,7 +1779,9 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
     }
     return;
   }
-  const int tiles_c = (it.Ipad + PREP_T - 1) / PREP_T;
+  const bool x3 = it.flags & 1;
+  const int Il = x3 ? it.Ipad >> 1 : it.Ipad, Ol = x3 ? it.Opad >> 1 : it.Opad;      // logical (padded) channel counts of the two images
+  const int tiles_c = (Il + PREP_T - 1) / PREP_T;
   const int to = lb / tiles_c, tc = lb - to * tiles_c;
   const int o0 = to * PREP_T, c0 = tc * PREP_T;
   const int RS = it.RS;
@@ -1694,11 +1828,19 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
   for (int u = t; u < PREP_T * RS * 4; u += 256) {
     const int oct = u & 3, q = u >> 2, ol = q / RS, rs = q - ol * RS;
     const int o = o0 + ol, c = c0 + oct * 8;
-    if (o < it.O && c < it.Ipad) {
+    if (o < it.O && c < Il) {
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (bf16_t)tl[ol * pitch + (oct * 8 + j) * RS + rs];
-      *reinterpret_cast<bf16x8*>(it.wf + ((long long)o * RS + rs) * it.Ipad + c) = v;
+      if (!x3) *reinterpret_cast<bf16x8*>(it.wf + ((long long)o * RS + rs) * it.Ipad + c) = v;
+      else {         // this tile's 32 channels = one head band + one tail band of the X-layout
+        bf16x8 l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = (bf16_t)(tl[ol * pitch + (oct * 8 + j) * RS + rs] - (float)v[j]);
+        bf16_t* d = it.wf + ((long long)o * RS + rs) * it.Ipad + 2 * c0 + oct * 8;
+        *reinterpret_cast<bf16x8*>(d) = v;
+        *reinterpret_cast<bf16x8*>(d + 32) = l;
+      }
     }
   }
   // dgrad image [I][RS][Opad] (x BN scale): runs of 32 output channels = 4 octets
@@ -1712,11 +1854,19 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const PrepItem* __restr
     for (int u = t; u < PREP_T * RS * 4; u += 256) {
       const int oct = u & 3, q = u >> 2, cl = q / RS, rs = q - cl * RS;
       const int c = c0 + cl, o = o0 + oct * 8;
-      if (c < it.I && o < it.Opad) {
+      if (c < it.I && o < Ol) {
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(tl[(oct * 8 + j) * pitch + cl * RS + rs] * s_sc[oct * 8 + j]);
-        *reinterpret_cast<bf16x8*>(it.wd + ((long long)c * RS + rs) * it.Opad + o) = v;
+        if (!x3) *reinterpret_cast<bf16x8*>(it.wd + ((long long)c * RS + rs) * it.Opad + o) = v;
+        else {
+          bf16x8 l;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) l[j] = (bf16_t)(tl[(oct * 8 + j) * pitch + cl * RS + rs] * s_sc[oct * 8 + j] - (float)v[j]);
+          bf16_t* d = it.wd + ((long long)c * RS + rs) * it.Opad + 2 * o0 + oct * 8;
+          *reinterpret_cast<bf16x8*>(d) = v;
+          *reinterpret_cast<bf16x8*>(d + 32) = l;
+        }
       }
     }
   }
@@ -1759,7 +1909,7 @@ extern "C" int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t
   if (O == 0) return 0;
   UnpackArgs a;
   a.dw = dw_slabs; a.g = g; a.scale = scale; a.w = w_oihw; a.wdot = wdot; a.bn_s1 = bn_s1; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
-  a.slab_stride = slab_stride; a.nslabs = nslabs; a.O = O; a.I = I; a.RS = R * S; a.Ipad = Ipad; a.accumulate = accumulate;
+  a.slab_stride = slab_stride; a.nslabs = nslabs; a.O = O; a.I = I; a.RS = R * S; a.Ipad = Ipad; a.accumulate = accumulate & 1; a.x3 = (accumulate >> 1) & 1;
   hipLaunchKernelGGL(unpack_wgrad_slabs_kernel, dim3(O), dim3(UNP_T), 0, (hipStream_t)stream, a);
   AOD_LAUNCH_CHECK();
   return 0;
@@ -1782,7 +1932,7 @@ extern "C" int aod_unpack_wgrad_slabs_grouped(int n, const float* const* dw_slab
     UnpackArgs& a = gp.g[i];
     a.dw = dw_slabs[i]; a.g = g[i]; a.scale = scale[i]; a.w = w_oihw[i]; a.wdot = wdot[i]; a.bn_s1 = bn_s1[i]; a.bn_mean = bn_mean[i];
     a.bn_invstd = bn_invstd[i];
-    a.slab_stride = slab_stride[i]; a.nslabs = nslabs[i]; a.O = O[i]; a.I = I[i]; a.RS = R[i] * S[i]; a.Ipad = Ipad[i]; a.accumulate = accumulate[i];
+    a.slab_stride = slab_stride[i]; a.nslabs = nslabs[i]; a.O = O[i]; a.I = I[i]; a.RS = R[i] * S[i]; a.Ipad = Ipad[i]; a.accumulate = accumulate[i] & 1; a.x3 = (accumulate[i] >> 1) & 1;
     gp.blk0[i] = blk;
     blk += O[i];
   }

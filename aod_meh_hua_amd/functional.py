@@ -72,7 +72,7 @@ class _FragRec(_C.Structure):
 
 
 class _PrepItem:
-    __slots__ = ('srcs', 'ver', 'wf', 'wd', 'scale', 'shift', 'invstd', 'eps', 'dims', 'nblk', 'fragf', 'fragd')
+    __slots__ = ('srcs', 'ver', 'wf', 'wd', 'scale', 'shift', 'invstd', 'eps', 'dims', 'nblk', 'fragf', 'fragd', 'x3')
 
 
 class ParamPrep:
@@ -92,7 +92,8 @@ class ParamPrep:
         return tuple(-1 if t is None else t._version for t in (r() if r is not None else None for r in it.srcs))
 
     def get(self, w, bn, cin_pad, eps):
-        it = self.items.get(id(w))
+        """cin_pad: width of the conv's input rows (bf16 mode: channels padded to 8; reference-precision mode: the X-layout width)"""
+        it = self.items.get((id(w), ho.X3))
         if it is not None and it.srcs[0]() is not w:
             it = None
         if it is None:
@@ -106,20 +107,29 @@ class ParamPrep:
         dev = w.device
         it = _PrepItem()
         it.srcs = [_weakref.ref(w)] + [(_weakref.ref(t) if t is not None else None) for t in (bn if bn is not None else (None,) * 4)]
-        opad = (O + 7) // 8 * 8
-        it.wf = torch.empty(O, R, S, cin_pad, dtype=torch.bfloat16, device=dev)
-        it.wd = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=dev) if cin_pad == I else None      # no dgrad through a padded stem
+        it.x3 = ho.X3
+        if it.x3:
+            assert cin_pad == ho.xw(I), f'x3: input rows of {cin_pad} columns for a filter with {I} input channels'
+            opad = ho.xw(O)
+            it.wf = torch.empty(O, R, S, cin_pad, dtype=torch.bfloat16, device=dev)
+            it.wd = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=dev) if I % 32 == 0 else None    # (dX would need an X-layout width)
+        else:
+            opad = (O + 7) // 8 * 8
+            it.wf = torch.empty(O, R, S, cin_pad, dtype=torch.bfloat16, device=dev)
+            it.wd = torch.empty(I, R, S, opad, dtype=torch.bfloat16, device=dev) if cin_pad == I else None      # no dgrad through a padded stem
         if bn is not None:
             it.scale, it.shift, it.invstd = (torch.empty(O, dtype=torch.float32, device=dev) for _ in range(3))
         else:
             it.scale = it.shift = it.invstd = None
         it.eps, it.dims, it.ver = float(eps), (O, I, R * S, cin_pad, opad), None
         it.fragf = it.fragd = None
-        if R * S <= 9:
+        if R * S <= 9 and it.x3:
+            it.nblk = (opad // 64) * (cin_pad // 64)                         # 32 x 32 LOGICAL channel tiles, each a head and a tail band
+        elif R * S <= 9:
             it.nblk = ((opad + 31) // 32) * ((cin_pad + 31) // 32)           # 32 x 32 channel tiles (aod_param_prep)
         else:
             it.nblk = (max(O * R * S * cin_pad, I * R * S * opad if it.wd is not None else 0, O) + 2047) // 2048
-        self.items[id(w)] = it
+        self.items[(id(w), it.x3)] = it
         self.dirty = True
         return it
 
@@ -178,7 +188,7 @@ class ParamPrep:
                 r.wf, r.wd = it.wf.data_ptr(), (it.wd.data_ptr() if it.wd is not None else None)
                 r.scale, r.shift, r.invstd = ((t.data_ptr() if t is not None else None) for t in (it.scale, it.shift, it.invstd))
                 r.O, r.I, r.RS, r.Ipad, r.Opad = it.dims
-                r.blk0, r.eps = blk, it.eps
+                r.blk0, r.eps, r.pad_ = blk, it.eps, int(it.x3)          # (pad_ = flags: bit 0 = X3 images)
                 blk += it.nblk
             host = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
             dev = self.order[stale[0]].wf.device
@@ -209,14 +219,55 @@ import os as _os
 _FUSE_ACT = _os.environ.get('AOD_FUSE_ACT', '1') != '0'      # debug switch for A/B timing
 
 
-# precision of the conv operands: 'bf16' (product) or 'bf16x3' (debug instrument: ~fp32 products on the same kernels, precision_x3.py)
+# precision of the conv stack: 'bf16' (bf16 operands, fp32 accumulation) or 'bf16x3' -- the REFERENCE-PRECISION mode: every activation,
+# gradient and packed filter travels as a bf16 head + tail pair (X-layout rows, hipops.xw) and every product is three MFMAs, in the same
+# kernels with the same fused epilogues (csrc/conv.hip "X3", csrc/x3_ops.hip): fp32-grade results at ~3x the matrix work.  In that mode a
+# tensor handed between modules has the logical shape [B, xw(C), H, W]; x3_to_f32() gives its fp32 [B, C, H, W] values.
 _PREC = _os.environ.get('AOD_CONV_PREC', 'bf16')
+ho.X3 = _PREC == 'bf16x3'
 
 
 def set_precision(p):
     global _PREC
     assert p in ('bf16', 'bf16x3')
     _PREC = p
+    ho.X3 = p == 'bf16x3'
+
+
+def x3_to_f32(x, channels=None):
+    """fp32 [B, C, H, W] values of an X-layout activation (identity cast in the bf16 mode and for fp32 tensors)"""
+    if not ho.X3 or x.dtype != torch.bfloat16:
+        return x.float()
+    B, Wd, H, W = x.shape
+    rows = ho.x3_merge(as_rows(x), channels)
+    return as_nchw(rows, B, H, W)
+
+
+class ForkFn(Function):
+    """Reference-precision mode: a tensor that feeds n consumers.  Autograd would add the n gradients with torch's bf16 add, which rounds
+    the heads and the tails of an X-layout tensor separately (8 significant bits); here the sum is formed on the values (aod_x3_add)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        tot = None
+        for g in gs:
+            if g is None:
+                continue
+            g = g.contiguous(memory_format=torch.channels_last)
+            tot = g if tot is None else as_nchw(ho.x3_add(as_rows(tot), as_rows(g)), g.shape[0], g.shape[2], g.shape[3])
+        return tot, None
+
+
+def fork(x, n):
+    """n handles of `x` for n consumers (fpn.py:163-202: a lateral feeds its output conv and the level below; Lambda_L2.py:85-94: a pyramid
+    level feeds the cls and the reg tower).  bf16 mode: x itself n times (autograd's own accumulation)."""
+    if not ho.X3 or n == 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * n
+    return list(ForkFn.apply(x, n))
 
 
 def get_precision():
@@ -276,7 +327,7 @@ _JUNCTIONS = []
 
 def share_input_grad(x):
     """mark `x` (a tensor that requires grad, about to feed several convs) as a gradient junction"""
-    if torch.is_grad_enabled() and x.requires_grad and _PREC == 'bf16' and _os.environ.get('AOD_GRAD_JUNCTIONS', '1') != '0':
+    if torch.is_grad_enabled() and x.requires_grad and _os.environ.get('AOD_GRAD_JUNCTIONS', '1') != '0':
         x._aod_acc = GradAcc(getattr(x, '_aod_slot', None) if _FUSE_ACT and _os.environ.get('AOD_JUNCTION_MASK', '1') != '0' else None)
         _JUNCTIONS.append(_weakref.ref(x._aod_acc))
     return x
@@ -320,7 +371,7 @@ class grad_cuts:
 def cut(x):
     """inside grad_cuts(): a detached copy of `x` (same memory) that requires grad; (x, copy) is recorded so that backward_segments() can
     resume the backward pass at `x` with the gradient that arrived at the copy.  Outside: x itself."""
-    if _CUTS is None or not torch.is_grad_enabled() or not x.requires_grad or _PREC != 'bf16':
+    if _CUTS is None or not torch.is_grad_enabled() or not x.requires_grad:
         return x
     xc = x.detach().requires_grad_()
     if getattr(x, '_aod_slot', None) is not None:
@@ -345,7 +396,7 @@ def backward_segments(loss, cuts, after=None):
 
 
 def _grad_rows(gouts, y_segs, O, device):
-    """the upstream gradient of a (level-batched) conv as one dense row tensor [M, O]"""
+    """the upstream gradient of a (level-batched) conv as one dense row tensor [M, O] (O = the row width of the conv's output)"""
     if len(gouts) == 1 and gouts[0] is not None:
         return as_rows(gouts[0])
     parts = []
@@ -471,9 +522,10 @@ def _wgrad(x_rows, x_segs, dz, dsegs, R, S, stride, pad, dil, alg, w, O, I, dst,
     defer = (R * S <= 9 and w.grad is None and (gamma is None or gamma.grad is None) and not torch.is_grad_enabled()
              and not torch.is_anomaly_enabled() and not hooked(w) and not hooked(gamma))
     if _WgradQueue.submit(job, id(w), defer):
-        _WgradQueue.deferred.append((id(w), _weakref.ref(w), gw))
-        if wdot is not None and gamma is not None:
-            _WgradQueue.deferred.append((id(w), _weakref.ref(gamma), wdot))
+        # (the job's ALIASES: a second reference to the returned tensors themselves would make the engine clone them -- see above)
+        _WgradQueue.deferred.append((id(w), _weakref.ref(w), job.gw))
+        if job.wdot is not None and gamma is not None:
+            _WgradQueue.deferred.append((id(w), _weakref.ref(gamma), job.wdot))
     return gw, wdot
 
 
@@ -520,15 +572,16 @@ class ConvFn(Function):
         O, I, R, S = w.shape
         cin = x_rows.shape[1]
         y_segs = ctx.y_segs
-        g_rows = _grad_rows(gouts, y_segs, O, w.device)
+        X = ho.X3
+        Opad = ho.xw(O) if X else (O + 7) // 8 * 8                   # row width of dZ
+        g_rows = _grad_rows(gouts, y_segs, O if (meta['out_f32'] or not X) else Opad, w.device)
         dsegs = dense_segs(y_segs)
-        Opad = (O + 7) // 8 * 8
         need_w = ctx.needs_input_grad[1]
         need_x = any(ctx.needs_input_grad[8:])
         need_res = ctx.has_res and ctx.needs_input_grad[7]
         gw = ggamma = gbeta = gbias = gres = None
-        if Opad != O:
-            # prediction convs (N = 180 / 36 / 9): pad + cast + column sums in one pass
+        if (meta['out_f32'] and X) or (Opad != O and not X):
+            # prediction convs (N = 180 / 36 / 9, fp32 outputs): pad + cast + column sums in one pass
             dz, gbias_v = ho.pad_cast_colsum(g_rows, Opad, a_rows if meta['relu'] else None)
             gm = None
         else:
@@ -560,7 +613,7 @@ class ConvFn(Function):
             else:
                 s = y_segs[0]
                 gres = as_nchw(dz, s.B, s.H, s.W)       # the residual branch sees gm itself
-                if Opad == O and len(y_segs) == 1:
+                if (Opad == O or X) and len(y_segs) == 1:
                     # ... so a conv without ReLU at the end of that branch (the downsample conv + BN of a block's first bottleneck) needs no
                     # pass of its own for the column sums; the entry keeps dz alive, so its address cannot be handed out again meanwhile
                     _WgradQueue.begin_pass()        # (registers the callback that empties _S1_OF even if no weight gradient is queued in this pass)
@@ -577,12 +630,12 @@ class ConvFn(Function):
         gxs = [None] * ctx.nx
         if need_x:
             wd = PREP.get(w, (gamma, None, mean, None) if ctx.has_bn else None, cin, meta['eps']).wd    # registered in forward
-            if I != cin:   # stem: channel-padded input; dX only for the real channels is never needed (image)
+            if ho.width(I) != cin or wd is None:   # stem: channel-padded input; dX only for the real channels is never needed (image)
                 raise RuntimeError('dgrad through a channel-padded input is not supported')
             xd = dense_segs(x_segs)
             in_slot = meta.get('in_slot')
             fuse = in_slot is not None and all(a.row0 == b.row0 for a, b in zip(x_segs, xd)) and all(ctx.needs_input_grad[8:])
-            s1_in = ho.zeros_f32(cin, dz.device) if fuse else None
+            s1_in = ho.zeros_f32(I, dz.device) if fuse else None
             res_g = in_slot.res_grad if in_slot is not None else None
             if res_g is not None and not fuse:
                 raise RuntimeError('a deferred residual gradient was left for a conv that cannot fuse it')
@@ -593,7 +646,7 @@ class ConvFn(Function):
                 res_g = acc.partial
                 if acc.arrived == acc.n - 1 and acc.slot is not None and dz.dtype == torch.bfloat16 and xd[0].row0 == x_segs[0].row0:
                     jslot = acc.slot            # last consumer: its epilogue finishes the producer's activation backward as well
-                    s1_in = ho.zeros_f32(cin, dz.device)
+                    s1_in = ho.zeros_f32(I, dz.device)
             ch, role = meta.get('chain') or (None, 0)
             dx = None
             if ch is not None and fuse and acc is None and dz.dtype == torch.bfloat16:
@@ -616,7 +669,7 @@ class ConvFn(Function):
                     if role == 1:
                         ch.meta.clear(), ch.x_rows.clear(), ch.prep.clear()
             if dx is None:
-                dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, cin, R, S, meta['stride'], meta['pad'], meta['dil'],
+                dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, I, R, S, meta['stride'], meta['pad'], meta['dil'],
                                           res=res_g, mask=x_rows if (fuse or jslot is not None) else None, colsum=s1_in, alg=(I, O))
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
@@ -659,10 +712,6 @@ def conv_bn_act(xs, w, bn=None, bias=None, res=None, stride=1, pad=0, dil=1, rel
     the `res` input of ONE later conv_bn_act call (ResNet identity block), whose residual gradient is then routed through this conv."""
     single = torch.is_tensor(xs)
     xl = [xs] if single else list(xs)
-    if _PREC == 'bf16x3':
-        from .precision_x3 import conv_bn_act_x3
-        outs = conv_bn_act_x3(xl, w, bn, bias, res, dict(stride=stride, pad=pad, dil=dil, relu=relu, eps=bn.eps if bn is not None else 0.0))
-        return outs[0] if single else list(outs)
     meta = dict(stride=stride, pad=pad, dil=dil, relu=relu, out_f32=out_f32, eps=bn.eps if bn is not None else 0.0, out=out, pre=pre)
     if chain is not None and torch.is_grad_enabled():
         meta['chain'] = chain
@@ -827,9 +876,8 @@ def conv_towers_nograd(xss, convs, relu=True):
 # --------------------------------------------------------------------------- stem helpers
 def image_to_nhwc(img, cpad=8):
     """fp32 NCHW image batch -> bf16 NHWC rows viewed as [B, cpad, H, W] (no grad: images are leaves)."""
-    if _PREC == 'bf16x3':
-        from .precision_x3 import image_to_nhwc_x3
-        return image_to_nhwc_x3(img)
+    if ho.X3:
+        raise NotImplementedError('reference-precision mode: the stem takes the space-to-depth image (fp32 NCHW input with even sides)')
     B, C, H, W = img.shape
     rows, _ = ho.nchw_to_rows(img.detach().float(), cpad)
     return as_nchw(rows, B, H, W)
@@ -990,7 +1038,7 @@ def _stem_w4(conv):
 
 def stem_s2d_applies(img, conv, bn):
     """the frozen 7x7 / stride-2 / pad-3 stem on an fp32 image with even sides (resnet.py:575-600 with frozen_stages >= 0)"""
-    return (_PREC == 'bf16' and _os.environ.get('AOD_STEM_S2D', '1') != '0' and img.dtype == torch.float32 and img.dim() == 4
+    return ((ho.X3 or _os.environ.get('AOD_STEM_S2D', '1') != '0') and img.dtype == torch.float32 and img.dim() == 4
             and img.shape[1] <= 4 and img.shape[2] % 2 == 0 and img.shape[3] % 2 == 0 and tuple(conv.weight.shape[2:]) == (7, 7)
             and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and tuple(conv.dilation) == (1, 1) and conv.bias is None
             and not conv.weight.requires_grad and not any(p.requires_grad for p in bn.parameters()) and not bn.training)
@@ -1003,7 +1051,7 @@ def stem_conv_s2d(img, conv, bn):
     O = conv.weight.shape[0]
     rows, segs = ho.nchw_to_s2d_rows(img.detach())
     w4 = _stem_w4(conv)
-    pi = PREP.get(w4, (bn.weight, bn.bias, bn.running_mean, bn.running_var), 16, bn.eps)
+    pi = PREP.get(w4, (bn.weight, bn.bias, bn.running_mean, bn.running_var), rows.shape[1], bn.eps)
     dst = [Seg(B, H // 2, W // 2, 0)]                 # (the natural output of a 4x4 / pad-2 filter has one more row and column)
     y, _ = ho.conv2d_rows(rows, segs, pi.wf, O, 4, 4, 1, 2, 1, pre_scale=pi.scale, pre_shift=pi.shift, relu=True, dst_segs=dst,
                           alg=(49.0 * Cc / 16.0, O))      # algorithmic FLOPs: the 7 x 7 x C filter
@@ -1013,7 +1061,7 @@ def stem_conv_s2d(img, conv, bn):
 def stem_pool_s2d(img, conv, bn):
     """max_pool_3x3_s2(relu(bn(conv7x7_s2(img)))) of the frozen stem in one launch after the layout kernel (aod_stem_pool_fwd): the
     64-channel conv output stays in LDS.  AOD_STEM_POOL_FUSE=0: conv and pool as separate launches."""
-    if _os.environ.get('AOD_STEM_POOL_FUSE', '1') == '0':
+    if ho.X3 or _os.environ.get('AOD_STEM_POOL_FUSE', '1') == '0':
         return max_pool_3x3_s2(stem_conv_s2d(img, conv, bn))
     B, Cc, H, W = img.shape
     O = conv.weight.shape[0]
@@ -1031,9 +1079,6 @@ def stem_pool_s2d(img, conv, bn):
 
 def max_pool_3x3_s2(x):
     """resnet.py:610 -- only used inside the frozen stem (no backward needed)."""
-    if _PREC == 'bf16x3':
-        from .precision_x3 import max_pool_x3
-        return max_pool_x3(x)
     assert not x.requires_grad, 'maxpool backward is not implemented (stem is frozen, resnet.py:612-628)'
     B, C, H, W = x.shape
     rows, s = ho.maxpool3x3s2(as_rows(x), Seg(B, H, W))
@@ -1065,7 +1110,7 @@ def pyramid_buffer(shapes, channels, device, dtype=torch.bfloat16):
     """One flat [sum(B*H*W), C] allocation + per-level [B,C,H,W] channels_last views (adjacent levels: a
     level-batched conv reads them as segments of ONE buffer, no copy, 32-bit offsets)."""
     rows = sum(b * h * w for b, h, w in shapes)
-    flat = torch.empty(rows, channels, device=device, dtype=dtype)
+    flat = torch.empty(rows, ho.width(channels) if dtype == torch.bfloat16 else channels, device=device, dtype=dtype)
     views, r = [], 0
     for b, h, w in shapes:
         views.append(as_nchw(flat[r:r + b * h * w], b, h, w))
@@ -1074,9 +1119,6 @@ def pyramid_buffer(shapes, channels, device, dtype=torch.bfloat16):
 
 
 def upsample_add(lateral, top):
-    if _PREC == 'bf16x3':
-        from .precision_x3 import upsample_add_x3
-        return upsample_add_x3(lateral, top)
     return UpsampleAddFn.apply(lateral, top)
 
 

@@ -14,6 +14,22 @@ from . import _C
 from ._C import ConvDesc, ConvSeg, call, lib, ptr, stream
 
 
+# Reference-precision mode (functional.set_precision('bf16x3'), csrc/conv.hip "X3"): bf16 activations / gradients are X-LAYOUT rows -- a
+# tensor of c logical channels has xw(c) = 2 * ceil32(c) columns [h(0..31) | l(0..31) | h(32..63) | ...], value = head + tail -- and the
+# descriptors carry x3 = 1.  The wrappers below take and return such rows when X3 is set; channel COUNTS passed to them (N, Cin) stay logical.
+X3 = False
+
+
+def xw(c):
+    """physical width (bf16 columns) of an X-layout row with c logical channels"""
+    return 2 * ((c + 31) // 32 * 32)
+
+
+def width(c):
+    """row width of a bf16 activation tensor with c channels in the current precision mode"""
+    return xw(c) if X3 else c
+
+
 _ROW_TABLES = {}     # wgrad row tables, one per conv geometry (shared by every layer / iteration with that geometry)
 
 
@@ -96,7 +112,7 @@ def make_desc(C_, N, R, S, stride, pad, dil, src_segs: Sequence[Seg], dst_segs: 
               relu=False, out_f32=False) -> ConvDesc:
     d = ConvDesc()
     d.C, d.N, d.R, d.S, d.stride, d.pad, d.dil = C_, N, R, S, stride, pad, dil
-    d.transposed, d.relu, d.out_f32, d.nseg = int(transposed), int(relu), int(out_f32), len(src_segs)
+    d.transposed, d.relu, d.out_f32, d.nseg, d.x3 = int(transposed), int(relu), int(out_f32), len(src_segs), int(X3)
     assert 1 <= len(src_segs) <= 8 and len(src_segs) == len(dst_segs)
     for i, (s, o) in enumerate(zip(src_segs, dst_segs)):
         d.seg[i] = ConvSeg(s.B, s.H, s.W, o.H, o.W, s.row0, o.row0)
@@ -146,7 +162,7 @@ HALO_ALL = os.environ.get('AOD_HALO_CONV', '1') == 'all'
 def _halo_applies(d, narrow, *unsupported, dgrad=False):
     """the halo-tile kernel (aod_halo_conv3x3) takes 3x3 / stride-1 / pad-1 convs whose narrow side has < 256 channels and that need none
     of the epilogue operands it does not implement"""
-    if not HALO_CONV or narrow >= 256 or any(u is not None for u in unsupported):
+    if not HALO_CONV or X3 or narrow >= 256 or any(u is not None for u in unsupported):
         return False
     if not HALO_ALL and (dgrad or narrow > 64):
         return False
@@ -161,7 +177,8 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     dst_segs = dst_segs or out_segs(src_segs, R, S, stride, pad, dil)
     rows = out_rows if out_rows is not None else sum(s.rows for s in dst_segs)
     if out is None:
-        out = torch.empty(rows, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
+        out = torch.empty(rows, N if out_f32 else width(N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_rows.device)
+    assert out.shape[1] == (N if out_f32 else width(N)), 'destination width does not match the precision mode'
     z = torch.empty(rows, N, dtype=torch.bfloat16, device=x_rows.device) if save_z else None
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, out_f32)
     if R == 3 and not save_z and _halo_applies(d, N, pre_scale, res, mask, post_scale):
@@ -224,7 +241,7 @@ def conv2d_dgrad_rows(dz_rows, dz_segs, x_segs, w_dgrad, Cin, R, S, stride=1, pa
     Npad = dz_rows.shape[1]
     rows = x_rows_total if x_rows_total is not None else sum(s.rows for s in x_segs)
     if out is None:
-        out = torch.empty(rows, Cin, dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz_rows.device)
+        out = torch.empty(rows, Cin if out_f32 else width(Cin), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz_rows.device)
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, out_f32)
     if R == 3 and _halo_applies(d, Npad, res, post_scale, dgrad=True):
         _prof('dgrad', d, lambda: call('aod_halo_conv3x3', C.byref(d), ptr(dz_rows), ptr(w_dgrad), ptr(out), None, ptr(mask), ptr(colsum), stream()), alg)
@@ -306,7 +323,7 @@ def wgrad_unpack_group(jobs):
     ws = [j.w.contiguous() if (j.wdot is not None and j.w is not None) else None for j in jobs]
     call('aod_unpack_wgrad_slabs_grouped', n, pv(slabs), I32A(*splits), I64A(*strides), pv([j.gw for j in jobs]), I32A(*[j.O for j in jobs]),
          I32A(*[j.I for j in jobs]), I32A(*[j.R for j in jobs]), I32A(*[j.S for j in jobs]), I32A(*[j.x_rows.shape[1] for j in jobs]),
-         I32A(*[0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
+         I32A(*[2 if X3 else 0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
          pv([j.bn[1] if j.bn else None for j in jobs]), pv([j.bn[2] if j.bn else None for j in jobs]), stream())
 
 
@@ -318,6 +335,7 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     nslabs = 0
     if dw is None and R * S <= 9 and SLAB_WGRAD:
         nslabs = int(lib.aod_conv2d_wgrad_splits(C.byref(d)))
+    assert not X3 or nslabs, 'x3 weight gradients exist in the slab form only (at most 9 taps)'
     if dw is None and nslabs == 0:
         dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     tab = _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, x_rows.device)
@@ -385,7 +403,7 @@ def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, sc
             grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
         if wdot is None:
             wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
-        call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(accumulate), ptr(scale),
+        call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(bool(accumulate)) | (2 if X3 else 0), ptr(scale),
              ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
              ptr(bn[2]) if bn else None, stream())
         return (grad_oihw, wdot) if want_wdot else grad_oihw
@@ -416,8 +434,8 @@ def nchw_to_rows(img_f32, cpad=8):
 def nchw_to_s2d_rows(img_f32):
     """fp32 [B, C <= 4, H, W] (H, W even) -> space-to-depth bf16 rows [B * H/2 * W/2, 16] (aod_nchw_f32_to_s2d_bf16)"""
     B, Cc, H, W = img_f32.shape
-    out = torch.empty(B * (H // 2) * (W // 2), 16, dtype=torch.bfloat16, device=img_f32.device)
-    call('aod_nchw_f32_to_s2d_bf16', ptr(img_f32.contiguous()), ptr(out), B, Cc, H, W, stream())
+    out = torch.empty(B * (H // 2) * (W // 2), width(16), dtype=torch.bfloat16, device=img_f32.device)
+    call('aod_x3_nchw_f32_to_s2d' if X3 else 'aod_nchw_f32_to_s2d_bf16', ptr(img_f32.contiguous()), ptr(out), B, Cc, H, W, stream())
     return out, [Seg(B, H // 2, W // 2, 0)]
 
 
@@ -480,7 +498,7 @@ def maxpool3x3s2(x_rows, seg: Seg):
     Cc = x_rows.shape[1]
     oh, ow = out_hw(seg.H, seg.W, 3, 3, 2, 1, 1)
     out = torch.empty(seg.B * oh * ow, Cc, dtype=torch.bfloat16, device=x_rows.device)
-    call('aod_maxpool3x3s2', ptr(x_rows), ptr(out), seg.B, seg.H, seg.W, Cc, stream())
+    call('aod_x3_maxpool3x3s2' if X3 else 'aod_maxpool3x3s2', ptr(x_rows), ptr(out), seg.B, seg.H, seg.W, Cc, stream())
     return out, Seg(seg.B, oh, ow, 0)
 
 
@@ -493,14 +511,14 @@ def upsample_add_(dst_rows, dst_seg: Seg, src_rows, src_seg: Seg):
 def upsample_add(lat_rows, dst_seg: Seg, top_rows, src_seg: Seg):
     """out = lateral + nearest_upsample(top), out of place (aod_upsample2x_add_to)"""
     out = torch.empty_like(lat_rows)
-    call('aod_upsample2x_add_to', ptr(top_rows), ptr(lat_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, lat_rows.shape[1], dst_seg.H, dst_seg.W, stream())
+    call('aod_x3_upsample2x_add_to' if X3 else 'aod_upsample2x_add_to', ptr(top_rows), ptr(lat_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, lat_rows.shape[1], dst_seg.H, dst_seg.W, stream())
     return out
 
 
 def upsample_add_bwd(g_dst_rows, dst_seg: Seg, src_seg: Seg):
     """g_top = adjoint of the nearest upsample applied to g (written, not accumulated: no zero fill)"""
     out = torch.empty(src_seg.rows, g_dst_rows.shape[1], dtype=torch.bfloat16, device=g_dst_rows.device)
-    call('aod_upsample2x_add_bwd_set', ptr(g_dst_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, g_dst_rows.shape[1], dst_seg.H, dst_seg.W, stream())
+    call('aod_x3_upsample2x_add_bwd_set' if X3 else 'aod_upsample2x_add_bwd_set', ptr(g_dst_rows), ptr(out), dst_seg.B, src_seg.H, src_seg.W, g_dst_rows.shape[1], dst_seg.H, dst_seg.W, stream())
     return out
 
 
@@ -519,6 +537,12 @@ def add_relu(a, b):
 def act_bwd(g, a=None, z=None, scale=None, mean=None, invstd=None, relu=True, want_gm=False, want_dz=True):
     """Returns (dz, gm, dbeta, dgamma).  g [M, N] bf16 or fp32."""
     M, N = g.shape
+    if X3:          # X rows in, X rows out; column sums over the N / 2 logical channels (aod_x3_act_bwd)
+        assert z is None and scale is None and not want_gm and g.dtype == torch.bfloat16
+        dz = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_dz else None
+        dbeta = zeros_f32(N // 2, g.device)
+        call('aod_x3_act_bwd', ptr(g), ptr(a), ptr(dz), ptr(dbeta), M, N, int(relu), stream())
+        return dz, None, dbeta, None
     dz = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_dz else None
     gm = torch.empty(M, N, dtype=torch.bfloat16, device=g.device) if want_gm else None
     dbeta = zeros_f32(N, g.device)
@@ -583,6 +607,12 @@ def meh_loss_bwd(lam, loss_noR, bbox_w4, g, out_bf16=False, A=1, pitch=None, gra
 def pad_cast_colsum(g, npad, relu_out=None):
     M, N = g.shape
     assert relu_out is None or relu_out.dtype == torch.float32
+    if X3:          # fp32 head gradients -> X rows of xw(N) columns (npad is that width)
+        assert g.dtype == torch.float32 and npad == xw(N)
+        dz = torch.empty(M, npad, dtype=torch.bfloat16, device=g.device)
+        cs = zeros_f32(npad // 2, g.device)
+        call('aod_x3_pad_cast_colsum', ptr(g), ptr(relu_out), ptr(dz), ptr(cs), M, N, stream())
+        return dz, cs
     dz = torch.empty(M, npad, dtype=torch.bfloat16, device=g.device)
     cs = zeros_f32(npad, g.device)
     call('aod_pad_cast_colsum', ptr(g), ptr(relu_out), ptr(dz), ptr(cs), M, N, npad, int(g.dtype == torch.float32), stream())
@@ -612,3 +642,26 @@ def max_iou_assign(anchors, valid, gts, gt_count, gt_labels, pos_thr=0.5, neg_th
          ptr(bbox_w), ptr(num_pos), ptr(ws), 0 if level_start is None else len(level_start) - 1,
          None if level_start is None else (C.c_int64 * len(level_start))(*level_start), stream())
     return assigned, labels, label_w, bbox_t, bbox_w, num_pos
+
+
+def x3_split(t_f32):
+    """fp32 [M, C] -> X rows [M, xw(C)] (aod_x3_split)"""
+    M, Cc = t_f32.shape
+    out = torch.empty(M, xw(Cc), dtype=torch.bfloat16, device=t_f32.device)
+    call('aod_x3_split', ptr(t_f32.contiguous()), ptr(out), M, Cc, stream())
+    return out
+
+
+def x3_merge(x_rows, Cc=None):
+    """X rows [M, 2 * Cp] -> fp32 [M, C] (C defaults to the padded count Cp)"""
+    M, Wd = x_rows.shape
+    Cc = Cc or Wd // 2
+    out = torch.empty(M, Cc, dtype=torch.float32, device=x_rows.device)
+    call('aod_x3_merge', ptr(x_rows.contiguous()), ptr(out), M, Cc, stream())
+    return out
+
+
+def x3_add(a, b):
+    out = torch.empty_like(a)
+    call('aod_x3_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    return out

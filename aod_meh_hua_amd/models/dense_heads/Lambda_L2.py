@@ -59,7 +59,7 @@ class Lambda_L2Net(L_AnchorHead):
     def forward(self, feats, **kwargs):
         """Lambda_L2.py:79-94, all levels per launch.  Returns (cls_scores[L], bbox_preds[L]) fp32 [B, A*C, h, w]."""
         feats = list(feats)
-        cls_feat, reg_feat = feats, feats
+        cls_feat, reg_feat = (list(t) for t in zip(*[AF.fork(f, 2) for f in feats]))      # (every level feeds both towers)
         if len(self.cls_convs) == len(self.reg_convs) and all(m.with_activation for m in list(self.cls_convs) + list(self.reg_convs)):
             # the two towers advance together: one grouped launch per depth (functional.ConvPairFn)
             # training: the MEH tower's forward (forward_L below, on the same -- detached -- pyramid, run by train_step_L right after this pass)

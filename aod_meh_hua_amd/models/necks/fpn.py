@@ -50,7 +50,9 @@ class FPN(BaseModule):
         laterals = [lc(inputs[i + self.start_level], shared_input=True) for i, lc in enumerate(self.lateral_convs)]
         n = len(laterals)
         for i in range(n - 1, 0, -1):
-            laterals[i - 1] = AF.upsample_add(laterals[i - 1], laterals[i])
+            # (a merged lateral feeds its own output conv AND the level below: AF.fork -- a no-op handle in the bf16 mode)
+            laterals[i], top = AF.fork(laterals[i], 2)
+            laterals[i - 1] = AF.upsample_add(laterals[i - 1], top)
         # all output levels live in ONE pyramid buffer so that the head's level-batched convs read them in place
         from ...hipops import out_hw
         shapes = [(l.shape[0], l.shape[2], l.shape[3]) for l in laterals]
@@ -72,5 +74,6 @@ class FPN(BaseModule):
                 src = outs[-1]
             outs.append(self.fpn_convs[n](src, out=slots[n], shared_input=self.add_extra_convs == 'on_input'))
             for i in range(n + 1, self.num_outs):
-                outs.append(self.fpn_convs[i](outs[-1], out=slots[i]))
+                outs[-1], src = AF.fork(outs[-1], 2)              # (an extra level is an output of the neck and the next extra conv's input)
+                outs.append(self.fpn_convs[i](src, out=slots[i]))
         return tuple(outs)

@@ -49,6 +49,12 @@ typedef struct {
   int32_t relu;           /* apply max(v, 0) last                                             */
   int32_t out_f32;        /* destination dtype: 0 bf16, 1 fp32                                */
   int32_t nseg;
+  int32_t x3;             /* 1: reference-precision mode.  bf16 operands are in the X-LAYOUT: a tensor of c logical channels has
+                             2*ceil32(c) bf16 columns [h(0..31) | l(0..31) | h(32..63) | ...], value = head + tail (h = bf16(v),
+                             l = bf16(v - h)); three MFMAs per 32 channels (xh*wh + xl*wh + xh*wl) give fp32-grade products.  C is then
+                             the PHYSICAL source width (multiple of 64), N the LOGICAL output channel count; a bf16 destination,
+                             res and mask are X-layout rows of 2*ceil32(N) columns, an fp32 destination has N columns.  (Fills the
+                             padding the struct had in front of seg[]: the layout of the other fields is unchanged.) */
   aod_conv_seg_t seg[8];
 } aod_conv_desc_t;
 
@@ -185,7 +191,9 @@ int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int 
                      const float* scale, const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean,
                      const float* bn_invstd, aod_stream_t stream);
 
-/* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 9 taps. */
+/* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 9 taps.
+ * `accumulate`: bit 0 = add into grad_oihw; bit 1 = the slabs come from an x3 launch (aod_conv_desc_t.x3): rows and columns are in the
+ * X-layout (Ipad = the physical width 2*ceil32(I)) and dW[o][c] = sum over slabs of the (head, head) + (head, tail) + (tail, head) bands. */
 int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t slab_stride, float* grad_oihw, int O, int I, int R, int S, int Ipad,
                            int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
                            const float* bn_mean, const float* bn_invstd, aod_stream_t stream);
@@ -199,7 +207,9 @@ int aod_unpack_wgrad_slabs_grouped(int n, const float* const* dw_slabs, const in
 /* Batched re-derivation of everything the conv launches read from the parameters, for ALL layers in one launch (after an optimizer
  * step every trainable layer is stale): items_dev = device array of `nitems` records of aod_param_prep_item_bytes() bytes,
  *   { const float* w_oihw, gamma, beta, mean, var;  void* w_fwd_packed, w_dgrad_packed;  float* scale, shift, invstd;
- *     int32 O, I, RS, Ipad, Opad, blk0;  float eps;  int32 pad;  int64 pad[2] }
+ *     int32 O, I, RS, Ipad, Opad, blk0;  float eps;  int32 flags;  int64 pad[2] }
+ * flags bit 0: X3 images for aod_conv_desc_t.x3 launches -- the packed channel axis of both images is in the X-layout (Ipad / Opad =
+ * the physical widths 2*ceil32(I) / 2*ceil32(O); head = bf16(v), tail = bf16(v - head)) and an item owns ceil32(O)/32 * ceil32(I)/32 blocks.
  * gamma == NULL: conv without BatchNorm (plain packs); w_dgrad_packed == NULL: no dgrad image.  With BN the dgrad image carries
  * scale[o] = gamma*rsqrt(var+eps) (see aod_pack_weight_dgrad) and scale/shift/invstd receive the folded eval-mode BN vectors
  * (resnet.py:647-656).  blk0 = first block of the item; an item owns ceil(Opad/32)*ceil(Ipad/32) blocks (32 x 32 channel tiles), or
@@ -393,6 +403,26 @@ int aod_synth_normal_images(float* dst, int B, int64_t elems_per_image, uint64_t
 int aod_sgd_multi(void* const* params, void* const* grads, void* const* moms, const int64_t* sizes, int ntensors,
                   float lr, const float* lr_dev, float momentum, float weight_decay, int first_step, float grad_scale,
                   aod_stream_t stream);
+
+/* ------------------------------------------------------------------ reference-precision mode (aod_conv_desc_t.x3): row kernels on
+ * X-layout tensors (csrc/x3_ops.hip).  The reference computes every one of these in fp32 (README.md:13-25); here a value is the fp32 sum of
+ * its bf16 head and tail and is written back as such a pair.  `C` = PHYSICAL width (bf16 columns, multiple of 64) unless stated. */
+/* fp32 [M][C logical] <-> X rows [M][2*ceil32(C)] (pad channels zero) */
+int aod_x3_split(const float* src, void* dst, int64_t M, int C, aod_stream_t stream);
+int aod_x3_merge(const void* src, float* dst, int64_t M, int C, aod_stream_t stream);
+/* out = a + b over n bf16 elements of X rows: autograd's gradient accumulation where a tensor feeds several consumers (fpn.py:163-202,
+ * Lambda_L2.py:85-94) */
+int aod_x3_add(const void* a, const void* b, void* out, int64_t n, aod_stream_t stream);
+/* aod_nchw_f32_to_s2d_bf16 with X rows of 64 columns (the 16 slots as one 32-channel band) */
+int aod_x3_nchw_f32_to_s2d(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);
+/* aod_maxpool3x3s2 / aod_upsample2x_add_to / aod_upsample2x_add_bwd_set on X rows */
+int aod_x3_maxpool3x3s2(const void* src, void* dst, int B, int H, int W, int C, aod_stream_t stream);
+int aod_x3_upsample2x_add_to(const void* top, const void* lateral, void* out, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+int aod_x3_upsample2x_add_bwd_set(const void* g_dst, void* g_src, int B, int h, int w, int C, int H, int W, aod_stream_t stream);
+/* dz = g * [a > 0] (relu != 0; dz may be NULL), colsum[c] += sum_m of it over the C/2 logical channels (aod_act_bwd's masked-gradient part) */
+int aod_x3_act_bwd(const void* g, const void* a, void* dz, float* colsum, int64_t M, int C, int relu, aod_stream_t stream);
+/* aod_pad_cast_colsum: fp32 head gradients [M][N] (* [relu_out > 0]) -> X rows of 2*ceil32(N) columns + column sums fp32 [ceil32(N)] */
+int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, aod_stream_t stream);
 
 #ifdef __cplusplus
 }

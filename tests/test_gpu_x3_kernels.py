@@ -1,0 +1,191 @@
+"""GPU: the reference-precision kernels (aod_conv_desc_t.x3, csrc/conv.hip "X3", csrc/x3_ops.hip) one by one against torch fp32 on the same
+values.  An X-layout tensor carries 16 significant bits per value and a product drops the tail x tail term (2^-16), so the tolerances below
+are 1e-4 of the result's scale -- two orders of magnitude under what the bf16 mode's tests allow (5e-2)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def x3_mode():
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision('bf16x3')
+    yield
+    AF.set_precision('bf16')
+
+
+def _x(t_nchw):
+    """fp32 [B,C,H,W] -> X rows"""
+    from aod_meh_hua_amd import hipops as ho
+    B, C, H, W = t_nchw.shape
+    return ho.x3_split(t_nchw.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous())
+
+
+def _f(rows, B, H, W, C):
+    from aod_meh_hua_amd import hipops as ho
+    return ho.x3_merge(rows, C).view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def _err(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-30))
+
+
+def test_split_merge_round_trip_keeps_16_bits():
+    from aod_meh_hua_amd import hipops as ho
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for C in (20, 64, 180):
+        t = torch.randn(1000, C, device='cuda', generator=g) * 3
+        x = ho.x3_split(t)
+        assert x.shape == (1000, ho.xw(C)) and x.dtype == torch.bfloat16
+        back = ho.x3_merge(x, C)
+        assert float(((back - t).abs() / t.abs().clamp_min(1e-20)).max()) < 2 ** -15
+        # pad channels are zero
+        if C % 32:
+            full = ho.x3_merge(x)
+            assert float(full[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=2, C=64, O=64, H=32, W=32, R=3, stride=1, pad=1, relu=True, bn=True, res=False),       # 64 x 64 / 64 x 128 tiles
+    dict(B=2, C=256, O=64, H=24, W=40, R=1, stride=1, pad=0, relu=True, bn=True, res=False),
+    dict(B=2, C=64, O=256, H=24, W=40, R=1, stride=1, pad=0, relu=True, bn=True, res=True),      # residual = head + tail
+    dict(B=4, C=128, O=128, H=64, W=64, R=3, stride=2, pad=1, relu=True, bn=True, res=False),     # 128 x 128 tile, stride 2
+    dict(B=2, C=512, O=256, H=8, W=8, R=3, stride=2, pad=1, relu=False, bn=False, res=False),     # small output, deep K (split-K)
+    dict(B=2, C=2048, O=256, H=8, W=8, R=3, stride=2, pad=1, relu=False, bn=False, res=False),    # P6 shape: split-K
+    dict(B=2, C=256, O=180, H=16, W=16, R=3, stride=1, pad=1, relu=False, bn=False, res=False, out_f32=True),     # prediction conv
+    dict(B=2, C=256, O=9, H=16, W=16, R=3, stride=1, pad=1, relu=True, bn=False, res=False, out_f32=True),
+])
+def test_x3_conv_forward_dgrad_wgrad_against_fp32(case):
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd.mmcv_lite import BatchNorm2d
+    c = dict(out_f32=False)
+    c.update(case)
+    B, C, O, H, W, R = c['B'], c['C'], c['O'], c['H'], c['W'], c['R']
+    g = torch.Generator(device='cuda').manual_seed(5)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    x = rnd(B, C, H, W)
+    w = (rnd(O, C, R, R) / (C * R * R) ** 0.5).requires_grad_()
+    bn = None
+    bias = None
+    if c['bn']:
+        bn = BatchNorm2d(O).cuda().eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(O, device='cuda', generator=g) + 0.5); bn.bias.copy_(rnd(O) * 0.1)
+            bn.running_mean.copy_(rnd(O) * 0.1); bn.running_var.copy_(torch.rand(O, device='cuda', generator=g) + 0.5)
+    else:
+        bias = (rnd(O) * 0.1).requires_grad_()
+    oh, ow = ho.out_hw(H, W, R, R, c['stride'], c['pad'], 1)
+    res = rnd(B, O, oh, ow) if c['res'] else None
+    # ---- HIP, X-layout
+    xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+    rx = AF.as_nchw(_x(res), B, oh, ow) if res is not None else None
+    y = AF.conv_bn_act(xx, w, bn=bn, bias=bias, res=rx, stride=c['stride'], pad=c['pad'], relu=c['relu'], out_f32=c['out_f32'])
+    yf = y if c['out_f32'] else _f(AF.as_rows(y), B, oh, ow, O)
+    # ---- torch fp32
+    xr = x.clone().requires_grad_()
+    wr = w.detach().clone().requires_grad_()
+    z = F.conv2d(xr, wr, bias.detach() if bias is not None else None, c['stride'], c['pad'])
+    if bn is not None:
+        z = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    if res is not None:
+        z = z + res
+    if c['relu']:
+        # the ReLU of the HIP output decides the mask on both sides: an output within rounding distance of zero may have either sign, and
+        # a flipped mask bit changes the gradients of a 3 x 3 neighbourhood by O(1) -- that is the activation, not the arithmetic under test
+        z = z * (yf.detach() > 0).float()
+    assert _err(yf, z) < 1e-4, ('forward', _err(yf, z))
+    # ---- backward
+    gy = rnd(B, O, oh, ow)
+    if c['out_f32']:
+        y.backward(gy)
+    else:
+        y.backward(AF.as_nchw(_x(gy), B, oh, ow))
+    z.backward(gy)
+    torch.cuda.synchronize()
+    if C % 32 == 0:
+        gx = _f(AF.as_rows(xx.grad), B, H, W, C)
+        assert _err(gx, xr.grad) < 1e-4, ('dgrad', _err(gx, xr.grad))
+    assert _err(w.grad, wr.grad) < 1e-4, ('wgrad', _err(w.grad, wr.grad))
+    if bn is not None:
+        # eval-mode BN parameter gradients through the fused path (<w, dW> and the column sums)
+        zz = F.conv2d(x, w.detach(), None, c['stride'], c['pad'])
+        assert bn.weight.grad is not None and bn.bias.grad is not None
+        gm = gy * (yf.detach() > 0) if c['relu'] else gy
+        ref_beta = gm.sum((0, 2, 3))
+        ref_gamma = (gm * (zz - bn.running_mean[None, :, None, None]) * torch.rsqrt(bn.running_var + bn.eps)[None, :, None, None]).sum((0, 2, 3))
+        assert _err(bn.bias.grad, ref_beta) < 1e-4 and _err(bn.weight.grad, ref_gamma) < 2e-4, (_err(bn.bias.grad, ref_beta), _err(bn.weight.grad, ref_gamma))
+    else:
+        gm = gy * (yf.detach() > 0) if c['relu'] else gy
+        assert _err(bias.grad, gm.sum((0, 2, 3))) < 1e-4
+
+
+def test_x3_row_kernels_against_fp32():
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd.hipops import Seg
+    g = torch.Generator(device='cuda').manual_seed(9)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    B, C, H, W = 2, 64, 18, 22
+    x = rnd(B, C, H, W)
+    # max-pool
+    out, s = ho.maxpool3x3s2(_x(x), Seg(B, H, W))
+    assert _err(_f(out, B, s.H, s.W, C), F.max_pool2d(x, 3, 2, 1)) < 2e-5
+    # upsample-add and its adjoint
+    top = rnd(B, C, H // 2, W // 2)
+    up = ho.upsample_add(_x(x), Seg(B, H, W), _x(top), Seg(B, H // 2, W // 2))
+    ref = x + F.interpolate(top, size=(H, W), mode='nearest')
+    assert _err(_f(up, B, H, W, C), ref) < 2e-5
+    gb = ho.upsample_add_bwd(_x(x), Seg(B, H, W), Seg(B, H // 2, W // 2))
+    tr = top.clone().requires_grad_()
+    (F.interpolate(tr, size=(H, W), mode='nearest') * x).sum().backward()
+    assert _err(_f(gb, B, H // 2, W // 2, C), tr.grad) < 2e-5
+    # activation backward + column sums
+    a = torch.relu(rnd(B, C, H, W))
+    dz, _, s1, _ = ho.act_bwd(_x(x), _x(a), relu=True)
+    refdz = x * (a > 0)
+    assert _err(_f(dz, B, H, W, C), refdz) < 2e-5 and _err(s1[:C], refdz.sum((0, 2, 3))) < 1e-5
+    _, _, s1b, _ = ho.act_bwd(_x(x), None, relu=False, want_dz=False)
+    assert _err(s1b[:C], x.sum((0, 2, 3))) < 1e-5
+    # head-gradient cast (+ fused ReLU of retina_L) and column sums
+    for N in (180, 36, 9):
+        gg = rnd(500, N)
+        ro = rnd(500, N) if N == 9 else None
+        dzp, cs = ho.pad_cast_colsum(gg, ho.xw(N), ro)
+        refg = gg * (ro > 0) if ro is not None else gg
+        assert _err(ho.x3_merge(dzp, N), refg) < 2e-5 and _err(cs[:N], refg.sum(0)) < 1e-5
+        if N % 32:
+            assert float(ho.x3_merge(dzp)[:, N:].abs().max()) == 0.0
+    # fan-in add
+    y = rnd(B, C, H, W)
+    assert _err(ho.x3_merge(ho.x3_add(_x(x), _x(y)), C), (x + y).permute(0, 2, 3, 1).reshape(-1, C)) < 2e-5
+    # fork: two consumers, gradients added on the values
+    xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+    p, q = AF.fork(xx, 2)
+    g1, g2 = rnd(B, C, H, W), rnd(B, C, H, W)
+    torch.autograd.backward([p, q], [AF.as_nchw(_x(g1), B, H, W), AF.as_nchw(_x(g2), B, H, W)])
+    assert _err(_f(AF.as_rows(xx.grad), B, H, W, C), g1 + g2) < 2e-5
+
+
+def test_x3_stem_against_fp32():
+    """frozen stem in the reference-precision mode: space-to-depth image (X rows of 64 columns) -> 4x4 conv + BN + ReLU -> max-pool"""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.mmcv_lite import BatchNorm2d, Conv2d
+    g = torch.Generator(device='cuda').manual_seed(3)
+    conv = Conv2d(3, 64, 7, stride=2, padding=3, bias=False).cuda()
+    bn = BatchNorm2d(64).cuda().eval()
+    for q in list(conv.parameters()) + list(bn.parameters()):
+        q.requires_grad_(False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(64, 3, 7, 7, device='cuda', generator=g) * 0.05)
+        bn.running_mean.copy_(torch.randn(64, device='cuda', generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(64, device='cuda', generator=g) + 0.5)
+    img = torch.randn(2, 3, 64, 96, device='cuda', generator=g)
+    assert AF.stem_s2d_applies(img, conv, bn)
+    y = AF.stem_pool_s2d(img, conv, bn)
+    ref = F.max_pool2d(torch.relu(F.batch_norm(F.conv2d(img, conv.weight, None, 2, 3), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)), 3, 2, 1)
+    got = AF.x3_to_f32(y, 64)
+    assert got.shape == ref.shape and _err(got, ref) < 1e-4, _err(got, ref)
