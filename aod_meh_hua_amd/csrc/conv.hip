@@ -1155,13 +1155,14 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
 // CU.  256 x 256 tile (TN = TK = 2, 8 waves as 2 x 4, 128 x 64 per wave, one workgroup per CU): the fragment reads are 8-B transposed
 // reads, so the 128 x 128 form moves 768 B of LDS per MFMA -- more than the LDS delivers at the matrix pipe's rate; the big tile halves
 // that (and the LDS-DMA traffic per MFMA), like the 256 x 256 tile of the forward kernel.
-// X3 (aod_conv_desc_t.x3): dZ and X are X-layout rows, so the 128 x 128 tile of dW' = dZ'^T X' holds the four products of 64 x 64 logical
-// entries -- (zh, zl) x (xh, xl) in 32-wide bands.  The 2 x 2 wave grid gives every wave the 64 x 64 block [zh32 | zl32] x [xh32 | xl32]:
-// its zl x xl quarter (2^-16 of the result) is skipped, which leaves exactly the three products of the forward form; the unpack kernel adds
-// the three bands of every slab.
+// X3 (aod_conv_desc_t.x3): dZ and X are X-layout rows, so a tile of dW' = dZ'^T X' holds the four products (zh, zl) x (xh, xl) of its
+// logical entries in 32-wide bands.  A wave's block starts on a 64-column boundary in both directions and is a whole number of
+// [h32 | l32] band pairs (4-wave 128 x 128 form: 64 x 64 per wave; 8-wave 256 x 256 form: 128 x 64): its zl x xl quarter (2^-16 of the
+// result) is skipped at compile time, which leaves exactly the three products of the forward form; the unpack kernel adds the three bands
+// of every slab.
 template <int NW, int TN, int TK, bool X3>
 __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
-  static_assert(!X3 || (NW == 4 && TN == 1 && TK == 1), "X3: the 4-wave 128 x 128 form");
+  static_assert(!X3 || (NW == 4 && TN == 1 && TK == 1) || (NW == 8 && TN == 2 && TK == 2), "X3: wave blocks must be whole [h32 | l32] band pairs");
   constexpr int RPW = 4 * NW;          // pixel rows covered per pass of all waves
   constexpr int PASSES = 64 / RPW;
   constexpr int WNC = NW / 2;          // waves along the (tap, channel) axis
@@ -1318,7 +1319,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if (X3 && i >= NI / 2 && j >= NJ / 2) continue;       // tail x tail
+        if (X3 && (i & 3) >= 2 && (j & 3) >= 2) continue;       // tail x tail (16-row groups 2, 3 of every four = a tail band)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       }
   };
@@ -1397,7 +1398,7 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
   // (measured, single launches: 16 x 32 x 32 pixels lose 15 % with the big tile, 16 x 64 x 64 gain 10 %; members of a GROUP get longer pixel
   // runs per workgroup and take it from 16 384 pixels on: -0.11 ms per step, AOD_WGRAD_BIG_MINM overrides the group threshold)
   big = (N % 256 == 0 && K % 256 == 0 && M >= big_min_m) ? 1 : 0;
-  if ((dbg_big && dbg_big[0] == '0') || x3) big = 0;
+  if (dbg_big && dbg_big[0] == '0') big = 0;
   const int T = big ? 256 : 128;
   tiles_n = (N + T - 1) / T;
   tiles_k = (K + T - 1) / T;
@@ -1458,6 +1459,8 @@ static void wgrad_attrs() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
 }
 
 static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
@@ -1479,7 +1482,8 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
   if (p.x3) {
     AOD_CHECK_ARG(slab_stride > 0, "wgrad (x3): slab form only");
-    hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, true>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
+    if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2, true>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, true>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   } else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
   else if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL((conv_wgrad_kernel<8, 1, 1>), dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
@@ -1507,10 +1511,34 @@ static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int
   static const char* dbg_slots = getenv("AOD_WGRAD_SLOTS");      // (debug: grid size the group plan aims at, small-tile form)
   const int slots = big ? 256 : (dbg_slots ? atoi(dbg_slots) : 512);
   int T = 1;
-  for (; T < max_steps; ++T) {
+  bool fits = false;
+  for (; T <= max_steps; ++T) {
     long long tot = 0;
     for (int g = 0; g < n; ++g) tot += tiles[g] * ((steps[g] + T - 1) / T);
-    if (tot <= slots) break;
+    if (tot <= slots) { fits = true; break; }
+  }
+  // more tiles than workgroup slots even with ONE split each (the X-layout tiles of the x3 mode are four times as many): a group would run
+  // as several rounds of workgroups that each walk the whole pixel axis -- its members are better off alone, with their own splits
+  if (!fits) { if (n > 1) return -1; T = max_steps; }
+  if (x3 && n > 1) {
+    // x3: a member often has so many tiles that the group gets one or two splits and fills the slots badly (4 tower filters = 144 big tiles:
+    // one split each, 144 of 256 workgroup slots, 1 364 steps; alone each: 36 tiles x 7 splits = 252 slots, 195 steps).  Estimated duration
+    // = rounds of the slots x steps per workgroup; group only if that does not lose against the members launched one by one.
+    auto cost = [&](int g0, int g1) {
+      long long best = -1;
+      for (int t = 1; t <= max_steps; ++t) {
+        long long tot = 0;
+        for (int g = g0; g < g1; ++g) tot += tiles[g] * ((steps[g] + t - 1) / t);
+        const long long c = ((tot + slots - 1) / slots) * t;
+        if (best < 0 || c < best) best = c;
+        if (tot <= slots / 2) break;         // (fewer workgroups than half the slots from here on: longer t only costs)
+      }
+      return best;
+    };
+    long long alone = 0;
+    for (int g = 0; g < n; ++g) alone += cost(g, g + 1);
+    const long long grouped = (long long)T;    // (one round by construction)
+    if (grouped * 10 > alone * 11) return -1;
   }
   for (int g = 0; g < n; ++g) {
     rps[g] = T * 64;
@@ -1567,7 +1595,8 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
   for (int g = n; g <= WG_MAXG; ++g) gp.wg0[g] = g == n ? wg : 0x7fffffff;
   gp.n = n;
   wgrad_attrs();
-  if (x3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<4, 1, 1, true>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
+  if (x3 && big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2, true>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  else if (x3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<4, 1, 1, true>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
   else if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
   else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 1, 1>), dim3(wg), dim3(512), 65536 + 4096, (hipStream_t)stream, gp);
   AOD_LAUNCH_CHECK();

@@ -558,6 +558,7 @@ class ConvFn(Function):
         ctx.meta, ctx.x_segs, ctx.y_segs = meta, x_segs, y_segs
         ctx.has_bn, ctx.has_bias, ctx.has_res = gamma is not None, bias is not None, res is not None
         ctx.nx = len(xs)
+        ctx.scope = ho.SCOPE
         ctx.save_for_backward(w, gamma, mean, scale, invstd, x_rows, y_rows if meta['relu'] else None)
         if meta.get('chain') is not None:
             ch, role = meta['chain']
@@ -567,6 +568,11 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        with ho.scope(ctx.scope):          # (bench.py's per-part listing: the backward launches count for the part their forward ran in)
+            return ConvFn._backward(ctx, *gouts)
+
+    @staticmethod
+    def _backward(ctx, *gouts):
         w, gamma, mean, scale, invstd, x_rows, a_rows = ctx.saved_tensors
         meta = ctx.meta
         O, I, R, S = w.shape

@@ -33,8 +33,24 @@ def width(c):
 _ROW_TABLES = {}     # wgrad row tables, one per conv geometry (shared by every layer / iteration with that geometry)
 
 
-# ---- optional per-launch profiling (bench.py): (kind, tile, flops, start_event, end_event) on the CURRENT stream
+# ---- optional per-launch profiling (bench.py): (kind, tile, flops, start_event, end_event, scope) on the CURRENT stream
 PROFILE = None
+SCOPE = 'head'          # which part of the network the launches belong to ('backbone' | 'neck' | 'head'): the detector sets it around its
+                        # sub-modules and a conv's backward restores the scope of its forward -- only read while PROFILE is on
+
+
+class scope:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global SCOPE
+        self.prev, SCOPE = SCOPE, self.name
+
+    def __exit__(self, *exc):
+        global SCOPE
+        SCOPE = self.prev
+        return False
 
 
 def _prof(kind, desc, fn, alg=None):
@@ -53,7 +69,7 @@ def _prof(kind, desc, fn, alg=None):
     e0.record()
     r = fn()
     e1.record()
-    PROFILE.append((kind, (m, desc.N, desc.R * desc.S * desc.C, desc.R * desc.S, desc.stride), flops, e0, e1))
+    PROFILE.append((kind, (m, desc.N, desc.R * desc.S * desc.C, desc.R * desc.S, desc.stride), flops, e0, e1, SCOPE))
     return r
 
 
@@ -65,7 +81,7 @@ def prof_flops(kind, shape, flops, fn):
     e0.record()
     r = fn()
     e1.record()
-    PROFILE.append((kind, shape, float(flops), e0, e1))
+    PROFILE.append((kind, shape, float(flops), e0, e1, SCOPE))
     return r
 
 
@@ -267,15 +283,20 @@ def _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, device):
 class WgradJob:
     """One weight gradient waiting for its launch: operands of conv2d_wgrad_rows + destinations of unpack_wgrad (all preallocated)."""
     __slots__ = ('x_rows', 'x_segs', 'dz', 'dz_segs', 'R', 'S', 'stride', 'pad', 'dil', 'alg', 'O', 'I', 'gw', 'scale', 'w', 'wdot', 'bn',
-                 'desc')
+                 'desc', 'scope')
 
     def __init__(self, x_rows, x_segs, dz, dz_segs, R, S, stride, pad, dil, alg, O, I, gw, scale=None, w=None, wdot=None, bn=None):
         self.x_rows, self.x_segs, self.dz, self.dz_segs = x_rows, x_segs, dz, dz_segs
         self.R, self.S, self.stride, self.pad, self.dil, self.alg, self.O, self.I = R, S, stride, pad, dil, alg, O, I
         self.gw, self.scale, self.w, self.wdot, self.bn = gw, scale, w, wdot, bn
         self.desc = make_desc(x_rows.shape[1], dz.shape[1], R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
+        self.scope = SCOPE
 
     def run_alone(self):
+        with scope(self.scope):
+            self._run_alone()
+
+    def _run_alone(self):
         dw = conv2d_wgrad_rows(self.x_rows, self.x_segs, self.dz, self.dz_segs, self.R, self.S, self.stride, self.pad, self.dil, alg=self.alg)
         unpack_wgrad(dw, self.O, self.I, grad_oihw=self.gw, scale=self.scale, w_oihw=self.w, want_wdot=self.wdot is not None, bn=self.bn,
                      wdot=self.wdot)
@@ -317,6 +338,8 @@ def wgrad_unpack_group(jobs):
         call('aod_conv2d_wgrad_grouped', PA(*[C.addressof(j.desc) for j in jobs]), n, pv([j.x_rows for j in jobs]), pv([j.dz for j in jobs]),
              pv(slabs), I32A(*splits), I64A(*strides), pv(tabs), stream())
     ms = [sum(sg.B * sg.H * sg.W for sg in j.dz_segs) for j in jobs]
+    global SCOPE
+    SCOPE, prev_scope = jobs[0].scope, SCOPE            # (a group is listed under its first member's part of the network)
     flops = sum(2.0 * m * j.R * j.S * (j.alg[0] * j.alg[1] if j.alg is not None else j.dz.shape[1] * j.x_rows.shape[1]) for m, j in zip(ms, jobs))
     # (per-shape listings show the group as one line: rows of the first member, summed N x K)
     prof_flops('wgrad', (ms[0], sum(j.dz.shape[1] for j in jobs), sum(j.R * j.S * j.x_rows.shape[1] for j in jobs), 10 + n, 1), flops, launch)
@@ -325,6 +348,7 @@ def wgrad_unpack_group(jobs):
          I32A(*[j.I for j in jobs]), I32A(*[j.R for j in jobs]), I32A(*[j.S for j in jobs]), I32A(*[j.x_rows.shape[1] for j in jobs]),
          I32A(*[2 if X3 else 0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
          pv([j.bn[1] if j.bn else None for j in jobs]), pv([j.bn[2] if j.bn else None for j in jobs]), stream())
+    SCOPE = prev_scope
 
 
 def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, dil=1, dw=None, alg=None):

@@ -23,9 +23,12 @@ class SSL_L_SingleStageDetector(SSLBase_L_Detector):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
 
     def extract_feat(self, img):
-        x = self.backbone(img)
+        from ... import hipops as ho
+        with ho.scope('backbone'):
+            x = self.backbone(img)
         if self.with_neck:
-            x = self.neck(x)
+            with ho.scope('neck'):
+                x = self.neck(x)
         return x
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, **kwargs):

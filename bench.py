@@ -4,9 +4,13 @@
 Default workload (BASELINE.json configs[1]): RetinaNet-R50-FPN + MEH/HUA, synthetic VOC 512x512, 20 classes, 16 images
 per GPU.  One "step" = one AL work unit over one batch of synthetic images resident in HBM: the full training iteration of
 MyEpochBasedRunnerLambda.run_iter (main forward + backward + SGD, then MEH forward + backward + SGD) on 16 images PLUS the HUA scoring
-pass over 16 OTHER images (forward + MEH forward + top-k + NMS + Dirichlet sampling + aggregation -> one score per image), i.e. the
-metric "images/sec train + HUA-score".  value = (16 trained + 16 scored) * steps / time; `phase_rates` holds the two phases separately
-and the AL-cycle rate N / (T_train + T_score) of SURVEY 8d.
+pass over 16 images of the same shape (forward + MEH forward + top-k + NMS + Dirichlet sampling + aggregation -> one score per image),
+i.e. the metric "images/sec train + HUA-score".  value = SURVEY 8(d)'s AL-cycle rate N / (T_train + T_score) = 16 * GPUs * steps / time
+(images through BOTH phases per second); `phase_rates` holds the two phases separately (>= 50 iterations each).
+
+Arithmetic: --precision bf16x3 (default) is the REFERENCE-PRECISION mode -- the reference is fp32 end to end, so the headline is measured
+with fp32-grade products (bf16 head/tail pairs, three MFMAs per product, aod_meh_hua_amd/precision_x3.py); --precision bf16 is the fast
+mode with plain bf16 operands.  The line carries the other mode's figures under precision.other_mode (N = 1).
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
     python bench.py --config r101coco                        BASELINE configs[4] at N = 1: R101, 80 classes, 8 x 800x1344 per GPU
@@ -51,7 +55,11 @@ def parse():
     ap.add_argument('--mode', default='train+score', choices=['train', 'score', 'train+score', 'pool'])
     ap.add_argument('--pool', type=int, default=10000, help='--mode pool: number of pool images (all ranks together)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-precision-check', action='store_true', help='skip the bf16x3 debug-precision iterations after the timed region (profiling runs)')
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'],
+                    help='arithmetic of the conv stack: bf16x3 = reference precision (fp32-grade products from bf16 head/tail pairs; the default, the '
+                         'reference is fp32), bf16 = plain bf16 operands (faster, residuals ~1e-2)')
+    ap.add_argument('--phase-iters', type=int, default=50, help='iterations of each per-phase rate (SURVEY 8d: >= 50)')
+    ap.add_argument('--no-precision-check', action='store_true', help='skip the short run in the OTHER precision mode after the timed region (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--shapes', default=None, help='write the per-shape conv breakdown of the instrumented step to this file')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
@@ -190,6 +198,53 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')).returncode
 
 
+def measured_peaks(dev):
+    """the vendor peaks re-measured on THIS box inside the run -- a library bf16 GEMM (hipBLASLt through torch.matmul, 8192^3,
+    random operands) and a stream copy (1 GiB, torch's copy kernel) -- about 2 s together.  Calibration only: nothing of the product path
+    goes through either."""
+    try:
+        g = torch.Generator(device=dev).manual_seed(1)
+        n = 8192
+        a = torch.randn(n, n, device=dev, generator=g).bfloat16()
+        b = torch.randn(n, n, device=dev, generator=g).bfloat16()
+        for _ in range(3):
+            torch.matmul(a, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 40
+        e0.record()
+        for _ in range(reps):
+            torch.matmul(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        gemm = 2.0 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        del a, b
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_(generator=g)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        e0.record()
+        for _ in range(20):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy = 2.0 * src.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        return dict(gemm_bf16_tflops=round(gemm, 1), gemm='torch.matmul (hipBLASLt) 8192^3 bf16, random operands', stream_copy_GBs=round(copy, 1),
+                    stream_copy='1 GiB fp32 device-to-device copy, read + write bytes')
+    except Exception as e:      # noqa: BLE001
+        return dict(error=f'{type(e).__name__}: {e}'[:200])
+
+
+PRECISIONS = {
+    # mode -> (dtype string of the line, MFMA instructions per algorithmic product, description)
+    'bf16x3': ('bf16x3', 3, 'reference precision: activations / gradients / filters as bf16 head + tail pairs, xh*wh + xl*wh + xh*wl on the bf16 '
+                            'MFMA into fp32 accumulators (16-bit significands, fp32-grade results: golden train step and scoring at 1e-4); '
+                            'fp32 losses / geometry / scoring / optimizer'),
+    'bf16': ('bf16', 1, 'bf16 x bf16 -> fp32 MFMA convolutions (8-bit significands: narrower than the fp32 reference, residuals ~1e-2); fp32 '
+                        'losses / geometry / scoring / optimizer'),
+}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -219,9 +274,11 @@ def main():
     if world > 1:
         comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=dist.get_world_size())
         assert comm['ranks'] == args.gpus
+    from aod_meh_hua_amd import functional as AF
     from aod_meh_hua_amd import hipops as ho
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
     import aod_meh_hua_amd.scoring  # noqa: F401      (the HIP scoring pass is part of the product: no fallback)
+    AF.set_precision(args.precision)
     model, cfg = build_model(dev, cd)
     broadcast_model(model)
     # The pool is scored with a FROZEN copy of the model whose classification head is "trained-like" (SURVEY 8d C3): the training phase
@@ -239,48 +296,10 @@ def main():
     gsync = GradSync()
     data = synth_batch(B, H, W, dev, seed=20 + rank, classes=cd['classes'])
     do_train, do_score = 'train' in args.mode, 'score' in args.mode
+    phases = int(do_train) + int(do_score)
 
     from aod_meh_hua_amd.graphs import GraphedScore, GraphedTrainStep
-    use_graph = not args.no_graph
-    gstep = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync if world > 1 else None, Labeled=True, Pseudo=False)
-    gscore = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'})
     data_dev = dict(data, gt_bboxes=[b.to(dev) for b in data['gt_bboxes']], gt_labels=[l.to(dev) for l in data['gt_labels']])
-
-    state = dict(graph_ok=use_graph)
-
-    def step(it=0, do_train=do_train, do_score=do_score, graph=None):
-        """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python."""
-        graph = state['graph_ok'] if graph is None else graph
-        if graph:
-            if do_train:
-                gstep(data)
-            if do_score:
-                ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                _, unc = gscore(pool['img'], pool['img_metas'], ids)
-                if world > 1:
-                    gather_scores(unc, B * world)
-            return
-        if do_train:
-            model.train()
-            out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
-            opt.zero_grad()
-            out['loss'].backward()
-            pending = gsync.start(opt.param_groups[0]['params'])       # overlaps the MEH step (disjoint parameters, detached inputs)
-            lossL = model.train_step_L(prev, head_out, feat_out)
-            opt_L.zero_grad()
-            lossL['loss'].backward()
-            pending.wait()
-            opt.step()
-            gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
-            opt_L.step()
-        if do_score:
-            pool_model.eval()
-            with torch.no_grad():
-                ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                _, unc = pool_model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **SCORE_KW)
-                unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
-                if world > 1:
-                    gather_scores(unc, B * world)
 
     def barrier():
         if world > 1:
@@ -288,116 +307,179 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_graph:        # capture up front; if the runtime refuses (it must not take the bench down), fall back to the eager path on ALL ranks
-        ok = 1
-        try:
-            step(0)
-        except Exception as e:      # noqa: BLE001
-            ok = 0
-            print(f'[bench] HIP-graph capture failed on rank {rank}: {type(e).__name__}: {e}; falling back to eager launches', file=sys.stderr)
+    def measure(precision, steps, warmup, use_graph, phase_iters):
+        """Everything the line says about ONE precision mode: the timed region (warm-up, barrier, `steps` steps, barrier; max over ranks), the
+        per-phase rates and one instrumented eager step for the roofline blocks."""
+        AF.set_precision(precision)
+        gstep = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync if world > 1 else None, Labeled=True, Pseudo=False)
+        gscore = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'})
+        state = dict(graph_ok=use_graph)
+
+        def step(it=0, do_train=do_train, do_score=do_score, graph=None):
+            """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python."""
+            graph = state['graph_ok'] if graph is None else graph
+            if graph:
+                if do_train:
+                    gstep(data)
+                if do_score:
+                    ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                    _, unc = gscore(pool['img'], pool['img_metas'], ids)
+                    if world > 1:
+                        gather_scores(unc, B * world)
+                return
+            if do_train:
+                model.train()
+                out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
+                opt.zero_grad()
+                out['loss'].backward()
+                pending = gsync.start(opt.param_groups[0]['params'])       # overlaps the MEH step (disjoint parameters, detached inputs)
+                lossL = model.train_step_L(prev, head_out, feat_out)
+                opt_L.zero_grad()
+                lossL['loss'].backward()
+                pending.wait()
+                opt.step()
+                gsync.all_reduce_grads(opt_L.param_groups[0]['params'])
+                opt_L.step()
+            if do_score:
+                pool_model.eval()
+                with torch.no_grad():
+                    ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                    _, unc = pool_model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **SCORE_KW)
+                    unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
+                    if world > 1:
+                        gather_scores(unc, B * world)
+
+        if use_graph:        # capture up front; if the runtime refuses (it must not take the bench down), fall back to the eager path on ALL ranks
+            ok = 1
+            try:
+                step(0)
+            except Exception as e:      # noqa: BLE001
+                ok = 0
+                print(f'[bench] HIP-graph capture failed on rank {rank}: {type(e).__name__}: {e}; falling back to eager launches', file=sys.stderr)
+            if world > 1:
+                import torch.distributed as dist
+                t_ok = torch.tensor([ok], device=dev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = int(t_ok)
+            state['graph_ok'] = use_graph = bool(ok)
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
-            t_ok = torch.tensor([ok], device=dev)
-            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-            ok = int(t_ok)
-        state['graph_ok'] = use_graph = bool(ok)
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    phases = int(do_train) + int(do_score)
-    imgs_per_step = B * world * phases
-    value = imgs_per_step * args.steps / dt
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
 
-    # ---- per-phase rates (outside the timed region; SURVEY 8d reports train / score separately beside the combined rate)
-    phase = {}
-    for name, tr_, sc_ in (('train', True, False), ('score', False, True)):
-        if (tr_ and not do_train) or (sc_ and not do_score):
-            continue
-        k = max(3, min(args.steps, 10))
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(k):
-            step(args.warmup + args.steps + i, tr_, sc_)
-        barrier()
-        d = time.perf_counter() - t1
-        phase[name + '_img_per_s'] = round(B * world * k / d, 1)
-        phase[name + '_ms_per_batch'] = round(d / k * 1e3, 3)
-    if do_train and do_score:
-        # AL-cycle rate N_total / (T_train + T_score) when the SAME N images are first trained on and then scored
-        phase['al_cycle_img_per_s'] = round(B * world / ((phase['train_ms_per_batch'] + phase['score_ms_per_batch']) * 1e-3), 1)
+        # ---- per-phase rates (outside the timed region; SURVEY 8d: >= 50 iterations, train / score separately beside the combined rate)
+        phase = {}
+        for name, tr_, sc_ in (('train', True, False), ('score', False, True)):
+            if (tr_ and not do_train) or (sc_ and not do_score):
+                continue
+            k = phase_iters
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(k):
+                step(warmup + steps + i, tr_, sc_)
+            barrier()
+            d = time.perf_counter() - t1
+            phase[name + '_img_per_s'] = round(B * world * k / d, 1)
+            phase[name + '_ms_per_batch'] = round(d / k * 1e3, 3)
+            phase['iterations'] = k
+        if do_train and do_score:
+            # SURVEY 8d: AL-cycle rate N_total / (T_train + T_score) when the SAME N images are first trained on and then scored
+            phase['al_cycle_img_per_s'] = round(B * world / ((phase['train_ms_per_batch'] + phase['score_ms_per_batch']) * 1e-3), 1)
 
-    # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv launch
-    roof = None
-    barrier()
-    if rank == 0:
-        ho.PROFILE, ho.BYTES_PROFILE = [], []
-    # The eager step is enqueued from Python far more slowly than the device executes it; an event pair around a launch would then span
-    # the idle time until the launch arrives (~10 us per small kernel).  A device-side spin keeps the stream busy while the host enqueues
-    # the whole step, so that the events are processed back to back and a pair brackets nothing but its kernel (the rocprofv3 averages
-    # under profiles/ are the cross-check).
-    torch.cuda._sleep(int(0.6 * 2.0e9))
-    step(args.warmup + args.steps, graph=False)              # EVERY rank (the step contains collectives); HIP events need the eager path
-    barrier()
-    if rank == 0:
-        agg = {}
-        for kind, shape, flops, e0, e1 in ho.PROFILE:
-            a = agg.setdefault(kind, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += flops
-        if args.shapes:
-            by = {}
-            for kind, shape, flops, e0, e1 in ho.PROFILE:
-                a = by.setdefault((kind,) + tuple(shape), [0, 0.0, flops])
+        # ---- roofline of the dominant kernel: one extra instrumented step, HIP events around every conv launch
+        roof = None
+        barrier()
+        if rank == 0:
+            ho.PROFILE, ho.BYTES_PROFILE = [], []
+        # The eager step is enqueued from Python far more slowly than the device executes it; an event pair around a launch would then span
+        # the idle time until the launch arrives (~10 us per small kernel).  A device-side spin keeps the stream busy while the host enqueues
+        # the whole step, so that the events are processed back to back and a pair brackets nothing but its kernel (the rocprofv3 averages
+        # under profiles/ are the cross-check).
+        torch.cuda._sleep(int(0.6 * 2.0e9))
+        step(warmup + steps, graph=False)              # EVERY rank (the step contains collectives); HIP events need the eager path
+        barrier()
+        if rank == 0:
+            mfma_per_product = PRECISIONS[precision][1]
+            peak = PEAK_BF16_TFLOPS / mfma_per_product      # algorithmic (fp32-grade) FLOP/s the matrix pipe can deliver in this mode
+            agg, parts = {}, {}
+            for kind, shape, flops, e0, e1, scope in ho.PROFILE:
+                t_ = e0.elapsed_time(e1) * 1e-3
+                a = agg.setdefault(kind, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += t_; a[2] += flops
+                part = 'backbone_fpn' if scope in ('backbone', 'neck') else 'heads'
+                q = parts.setdefault(part, {}).setdefault(kind, [0, 0.0, 0.0])
+                q[0] += 1; q[1] += t_; q[2] += flops
+            if args.shapes and precision == args.precision:
+                by = {}
+                for kind, shape, flops, e0, e1, scope in ho.PROFILE:
+                    a = by.setdefault((kind, scope) + tuple(shape), [0, 0.0, flops])
+                    a[0] += 1
+                    a[1] += e0.elapsed_time(e1) * 1e3
+                with open(args.shapes, 'w') as f:
+                    f.write(f'# precision {precision}; TFLOP/s = algorithmic (2*M*R*S*Cin*Cout) / time\n')
+                    f.write('kind   part          M       N     K   RS st   n   us_each   TFLOP/s   GB/s(act in+out)\n')
+                    for (kind, scope, m, n, k, rs, st), (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                        c = k // rs
+                        m_in = m * st * st if kind == 'fwd' else m
+                        byts = 2.0 * (m_in * (c if kind != 'dgrad' else n) + m * (n if kind != 'dgrad' else c)) if kind != 'wgrad' else 2.0 * (m_in * c + m * n)
+                        f.write(f'{kind:6s} {scope:9s}{m:8d}{n:6d}{k:6d}{rs:4d}{st:3d}{cnt:4d}{us / cnt:10.1f}{fl / (us / cnt) / 1e6:10.1f}{byts / (us / cnt) / 1e3:10.1f}   total {us:8.1f}\n')
+            sec = {}
+            for name, nbytes, e0, e1 in ho.BYTES_PROFILE:
+                a = sec.setdefault(name, [0, 0.0, 0.0])
                 a[0] += 1
-                a[1] += e0.elapsed_time(e1) * 1e3
-            with open(args.shapes, 'w') as f:
-                f.write('kind      M       N     K   RS st   n   us_each   TFLOP/s   GB/s(act in+out)\n')
-                for (kind, m, n, k, rs, st), (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-                    c = k // rs
-                    m_in = m * st * st if kind == 'fwd' else m
-                    byts = 2.0 * (m_in * (c if kind != 'dgrad' else n) + m * (n if kind != 'dgrad' else c)) if kind != 'wgrad' else 2.0 * (m_in * c + m * n)
-                    f.write(f'{kind:6s}{m:8d}{n:6d}{k:6d}{rs:4d}{st:3d}{cnt:4d}{us / cnt:10.1f}{fl / (us / cnt) / 1e6:10.1f}{byts / (us / cnt) / 1e3:10.1f}   total {us:8.1f}\n')
-        sec = {}
-        for name, nbytes, e0, e1 in ho.BYTES_PROFILE:
-            a = sec.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += nbytes
-        ho.PROFILE = ho.BYTES_PROFILE = None
-        kind = max(agg, key=lambda k: agg[k][1])
-        n, tsec, fl = agg[kind]
-        # HBM-side bytes per launch of the dominant kernel class: separate rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass of THIS build
-        # (tools/profile/pmc_passes.sh; corrected as MI355X_MICROARCH.md prescribes: 128 B per non-32B read request on gfx950), null when the
-        # committed summary belongs to another build
-        traffic, traffic_src = None, None
-        pm = pmc_summary('pmc_traffic.json')
-        if pm:
-            # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants, fused forward kernels)
-            pref = ('conv_wgrad_kernel',) if kind == 'wgrad' else ('conv_igemm_kernel', 'bottleneck', 'stem_pool_kernel', 'pw_gemm_kernel', 'pred_conv')
-            ks = [k for k in pm['kernels'] if any(q in k for q in pref)]
-            nl = sum(pm['kernels'][k]['launches'] for k in ks)
-            if nl:
-                traffic = round(sum((pm['kernels'][k]['read_MB_per_launch'] + pm['kernels'][k]['write_MB_per_launch']) * pm['kernels'][k]['launches'] for k in ks) / nl * 1e6)
-                traffic_src = f'profiles/pmc_traffic.json @ kernels {pm["kernels_sha16"]}'
-        roof = dict(bound='mfma', kernel={'fwd': 'conv_igemm_kernel (forward)', 'dgrad': 'conv_igemm_kernel (dgrad)', 'wgrad': 'conv_wgrad_kernel'}[kind],
-                    achieved=round(fl / tsec / 1e12, 2), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s', frac=round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4),
-                    traffic=traffic, traffic_source=traffic_src, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
-                    flops_rule='algorithmic: 2*M*R*S*Cin*Cout of the reference layer (channel pads of the stem / prediction convs excluded)',
-                    all={k: dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 1)) for k, v in agg.items()},
-                    # the HBM-bound row kernels of the same step: algorithmic bytes / summed launch time (HIP events), fraction of 8 TB/s
-                    secondary={k: dict(bound='hbm', launches=v[0], us=round(v[1] * 1e6, 1), achieved=round(v[2] / v[1] / 1e9, 1), peak=PEAK_HBM_GBS,
-                                       unit='GB/s', frac=round(v[2] / v[1] / 1e9 / PEAK_HBM_GBS, 4)) for k, v in sec.items() if v[1] > 0})
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += nbytes
+            ho.PROFILE = ho.BYTES_PROFILE = None
+            kind = max(agg, key=lambda k: agg[k][1])
+            n, tsec, fl = agg[kind]
+            # HBM-side bytes per launch of the dominant kernel class: separate rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass of THIS build
+            # (tools/profile/pmc_passes.sh; corrected as MI355X_MICROARCH.md prescribes: 128 B per non-32B read request on gfx950), null when the
+            # committed summary belongs to another build or another precision mode
+            traffic, traffic_src = None, None
+            pm = pmc_summary('pmc_traffic.json')
+            if pm and pm.get('precision', 'bf16') == precision:
+                # (launch-weighted over the instances of the kernel: 4- / 8-wave forms, epilogue-operand variants, fused forward kernels)
+                pref = ('conv_wgrad_kernel',) if kind == 'wgrad' else ('conv_igemm_kernel', 'bottleneck', 'stem_pool_kernel', 'pw_gemm_kernel', 'pred_conv')
+                ks = [k for k in pm['kernels'] if any(q in k for q in pref)]
+                nl = sum(pm['kernels'][k]['launches'] for k in ks)
+                if nl:
+                    traffic = round(sum((pm['kernels'][k]['read_MB_per_launch'] + pm['kernels'][k]['write_MB_per_launch']) * pm['kernels'][k]['launches'] for k in ks) / nl * 1e6)
+                    traffic_src = f'profiles/pmc_traffic.json @ kernels {pm["kernels_sha16"]}'
+            rate = lambda v: dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflop=round(v[2] / 1e12, 3), tflops=round(v[2] / v[1] / 1e12, 1),
+                                  frac=round(v[2] / v[1] / 1e12 / peak, 4))
+            tot = lambda d: [sum(v[0] for v in d.values()), sum(v[1] for v in d.values()), sum(v[2] for v in d.values())]
+            roof = dict(bound='mfma', kernel={'fwd': 'conv_igemm_kernel (forward)', 'dgrad': 'conv_igemm_kernel (dgrad)', 'wgrad': 'conv_wgrad_kernel'}[kind],
+                        achieved=round(fl / tsec / 1e12, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(fl / tsec / 1e12 / peak, 4),
+                        peak_rule=(f'{PEAK_BF16_TFLOPS:.0f} TFLOP/s dense bf16 MFMA / {mfma_per_product} MFMA per algorithmic product in the {precision} mode'
+                                   + (' (the fp32 matrix pipe itself peaks at 157 TFLOP/s)' if mfma_per_product > 1 else '')),
+                        mfma_issued_tflops=round(fl / tsec / 1e12 * mfma_per_product, 1),
+                        traffic=traffic, traffic_source=traffic_src, launches_per_step=n, avg_launch_us=round(tsec / n * 1e6, 2),
+                        flops_rule='algorithmic: 2*M*R*S*Cin*Cout of the reference layer (channel pads of the stem / prediction convs excluded; one '
+                                   'multiply-add per product whatever the mode issues)',
+                        all={k: rate(v) for k, v in agg.items()},
+                        # north_star's target stack: every conv launch of the backbone (stem included) and the neck, forward alone and with its backward
+                        backbone_fpn={**{k: rate(v) for k, v in parts.get('backbone_fpn', {}).items()}, 'total': rate(tot(parts.get('backbone_fpn', {'-': [0, 1e-30, 0.0]})))},
+                        heads={**{k: rate(v) for k, v in parts.get('heads', {}).items()}, 'total': rate(tot(parts.get('heads', {'-': [0, 1e-30, 0.0]})))},
+                        # the HBM-bound row kernels of the same step: algorithmic bytes / summed launch time (HIP events), fraction of 8 TB/s
+                        secondary={k: dict(bound='hbm', launches=v[0], us=round(v[1] * 1e6, 1), achieved=round(v[2] / v[1] / 1e9, 1), peak=PEAK_HBM_GBS,
+                                           unit='GB/s', frac=round(v[2] / v[1] / 1e9 / PEAK_HBM_GBS, 4)) for k, v in sec.items() if v[1] > 0})
+        del gstep, gscore
+        return dict(dt=dt, steps=steps, phase=phase, roof=roof, use_graph=use_graph)
+
+    main_m = measure(args.precision, args.steps, args.warmup, not args.no_graph, args.phase_iters)
+    dt, use_graph = main_m['dt'], main_m['use_graph']
+    # SURVEY 8(d): the combined figure is the AL-cycle rate N / (T_train + T_score) -- a step trains on B images per GPU and scores B (other)
+    # images per GPU, i.e. B images per GPU pass through BOTH phases per step
+    value = B * world * args.steps / dt
 
     hua = None
     if do_score:
@@ -405,42 +487,32 @@ def main():
         hua.update(head_scale=round(cal_k, 3), fg_anchor_frac_at_calibration=round(cal_frac, 5))
         assert hua['pairs_per_img'] > 0, 'degenerate HUA phase: no (candidate, object) pair in the scoring batch'
 
-    prec = None
-    if rank == 0 and world == 1 and not args.no_precision_check:
-        # The SAME metric at the reference's arithmetic: both phases in the bf16x3 mode (every conv operand split into a bf16 head and tail,
-        # three MFMA products summed in the fp32 accumulator: ~fp32-exact products on the same implicit-GEMM / dgrad / wgrad kernels, fp32
-        # activations; aod_meh_hua_amd/precision_x3.py), captured into HIP graphs and replayed like the headline.  The golden train-step and
-        # scoring tests hold in this mode at 1e-4 (tests/test_gpu_precision_x3.py); the headline stays bf16.
-        from aod_meh_hua_amd import functional as AF
-        AF.set_precision('bf16x3')
-        g3 = s3 = None
+    # ---- the other precision mode, same workload, same run (N = 1 only: a figure beside the line, not part of `value`)
+    other = None
+    if world == 1 and not args.no_precision_check:
+        om_ = 'bf16' if args.precision == 'bf16x3' else 'bf16x3'
         try:
-            g3 = GraphedTrainStep(model, opt, opt_L, grad_sync=None, Labeled=True, Pseudo=False) if do_train else None
-            s3 = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'}) if do_score else None
-
-            def step3(i):
-                if g3 is not None:
-                    g3(data)
-                if s3 is not None:
-                    s3(pool['img'], pool['img_metas'], torch.arange(B, device=dev) + i * B)
-            step3(0)                                  # capture
-            step3(1)
-            torch.cuda.synchronize()
-            k3 = 4
-            t1 = time.perf_counter()
-            for i in range(k3):
-                step3(2 + i)
-            torch.cuda.synchronize()
-            d3 = (time.perf_counter() - t1) / k3
-            prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_value=round(imgs_per_step / world / d3, 1), bf16x3_ms_per_step=round(d3 * 1e3, 2),
-                        bf16x3_phases=args.mode, launch='hip-graph replay',
-                        note='same metric with ~fp32-exact conv products (operands split into bf16 head + tail, 3 MFMA products per term, fp32 '
-                             'activations): the reference-precision figure; residuals vs the fp32 reference fall from ~1e-2 to ~1e-5')
+            m2 = measure(om_, 20, 3, not args.no_graph, 20)
+            r2 = m2['roof'] or {}
+            other = dict(mode=om_, arithmetic=PRECISIONS[om_][2], value=round(B * 20 / m2['dt'], 2), ms_per_step=round(m2['dt'] / 20 * 1e3, 3),
+                         phase_rates=m2['phase'], launch='hip-graph replay' if m2['use_graph'] else 'eager',
+                         roofline={k: r2.get(k) for k in ('kernel', 'achieved', 'peak', 'frac', 'peak_rule', 'all', 'backbone_fpn', 'heads')})
         except Exception as e:      # noqa: BLE001
-            prec = dict(headline='bf16 operands, fp32 accumulate', bf16x3_value=None, error=f'{type(e).__name__}: {e}'[:300])
+            other = dict(mode=om_, value=None, error=f'{type(e).__name__}: {e}'[:300])
         finally:
-            AF.set_precision('bf16')
-            del g3, s3
+            AF.set_precision(args.precision)
+    prec = dict(headline=args.precision, arithmetic=PRECISIONS[args.precision][2], other_mode=other)
+    x3 = (dict(ms=round(dt / args.steps * 1e3, 3), v=round(value, 2)) if args.precision == 'bf16x3'
+          else (dict(ms=other.get('ms_per_step'), v=other.get('value')) if other else None))
+    if x3:       # (the keys round 3's line carried for the reference-precision figure)
+        prec.update(bf16x3_ms_per_step=x3['ms'], bf16x3_value=x3['v'], bf16x3_phases=args.mode)
+
+    peaks = measured_peaks(dev) if rank == 0 else None
+    roof = main_m['roof']
+    if roof is not None:
+        roof['measured_peaks'] = peaks
+        if peaks and peaks.get('gemm_bf16_tflops'):
+            roof['frac_of_measured_gemm'] = round(roof['achieved'] * PRECISIONS[args.precision][1] / peaks['gemm_bf16_tflops'], 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -449,18 +521,20 @@ def main():
     if rank == 0:
         line = dict(metric=cd['metric'], value=round(value, 2), unit='images/sec',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
-                    scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                    scaling='weak', vs_baseline=None, dtype=PRECISIONS[args.precision][0], data='synthetic',
                     config=dict(workload=f'{cd["name"]}, bs={B}/GPU: '
                                          + ' + '.join((['train iteration (main fwd/bwd/SGD + MEH fwd/bwd/SGD)'] if do_train else [])
                                                       + (['HUA scoring pass'] if do_score else [])),
-                                value_definition=(f'images through BOTH phases per second: each step trains on {B} images/GPU and HUA-scores {B} other '
-                                                  'images/GPU (pool scored by a frozen copy with a calibrated, trained-like head)') if phases == 2
+                                value_definition=(f'SURVEY 8(d) AL-cycle rate N / (T_train + T_score): images per second through BOTH phases -- each step trains '
+                                                  f'on {B} images/GPU and HUA-scores {B} images/GPU (other images of the same shape; pool scored by a frozen '
+                                                  'copy with a calibrated, trained-like head); value = images/GPU * GPUs * steps / time') if phases == 2
                                 else f'images per second through the {args.mode} phase',
+                                value_both_phases=round(value * phases, 2),
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
                                 parallelism=f'dp{world}', collective_ranks=comm['ranks'], collective_backend=comm['backend'],
                                 phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
-                                arithmetic='bf16 x bf16 -> fp32 MFMA convolutions; fp32 losses / geometry / scoring / optimizer'),
-                    phase_rates=phase, hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)
+                                arithmetic=PRECISIONS[args.precision][2]),
+                    phase_rates=main_m['phase'], hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
@@ -519,7 +593,7 @@ def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac, 
             pass
         line = dict(metric='images/sec HUA pool scoring, RetinaNet-R50 VOC 512^2' if cd['depth'] == 50 else 'images/sec HUA pool scoring', value=round(args.pool / dt, 2),
                     unit='images/sec', n_gpus=world, steps=nb, warmup=args.warmup, ms_per_step=round(dt / max(nb, 1) * 1e3, 3), higher_is_better=True,
-                    scaling='strong', vs_baseline=None, dtype='bf16', data='synthetic',
+                    scaling='strong', vs_baseline=None, dtype=PRECISIONS[args.precision][0], data='synthetic',
                     config=dict(workload=f'{cd["name"]}: HUA unlabeled-pool scoring only, {args.pool} on-device Philox(seed=20, image id) images, '
                                          f'contiguous shard per rank, batches of {B}, one score all-gather',
                                 pool=args.pool, global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], parallelism=f'dp{world}',
@@ -540,7 +614,7 @@ def cpu_baseline(args, cd, do_train, do_score):
     (2, 2) -- the reference's own torch.set_num_threads(2) and samples_per_gpu=2 (tools/train_RetinaNet.py:77, Config_RetinaNet.py:127) --,
     (16, 2), (all host cores capped at 64, 2) and (16, B); per cell the training iteration, the scoring forward and the HUA stage (pre-NMS +
     NMS + ComputeObjUnc on planted, trained-like head outputs so that the stage is not empty; timed at batch 2 and scaled by images for the
-    batch-B cell) are timed separately.  `value` = the best cell's images/sec through both phases, computed like the GPU line's value.
+    batch-B cell) are timed separately.  `value` = the best cell's AL-cycle rate N / (T_train + T_score), computed like the GPU line's value.
     torch's CPU kernels stop scaling well below the 256 host threads of the GPU box, which is why the all-core cell is not the best one."""
     from oracle import model as om
     from tests import synth
@@ -611,13 +685,13 @@ def cpu_baseline(args, cd, do_train, do_score):
                 ref = next((c for c in out_cells if c['threads'] == thr and c['batch'] == 2), out_cells[-1])
                 cell['hua_stage_s'], cell['hua_stage_scaled_from_batch_2'] = round(ref['hua_stage_s'] * Bc / 2, 3), True
         tt = cell.get('train_s', 0.0) + cell.get('score_forward_s', 0.0) + cell.get('hua_stage_s', 0.0)
-        cell['img_per_s'] = round(Bc * (int(do_train) + int(do_score)) / tt, 3)
+        cell['img_per_s'] = round(Bc / tt, 3)                   # AL-cycle rate, like the GPU line's value: Bc images through the timed phases
         out_cells.append(cell)
     best = max(out_cells, key=lambda c: c['img_per_s'])
     return dict(value=best['img_per_s'], unit='images/sec', cores=best['threads'], kind='port',
                 sample=f'oracle/model.py (fp32 torch CPU ops) at {H}x{W}: per cell (threads, batch) one to five timed iterations of the training '
-                       f'iteration, the scoring forward and the HUA stage (planted trained-like head outputs); value = best cell, '
-                       f'{best["batch"]} images trained + {best["batch"]} scored per ({best.get("train_s", 0)} + {best.get("score_forward_s", 0)} + {best.get("hua_stage_s", 0)}) s',
+                       f'iteration, the scoring forward and the HUA stage (planted trained-like head outputs); value = best cell = AL-cycle rate, '
+                       f'{best["batch"]} images trained and scored per ({best.get("train_s", 0)} + {best.get("score_forward_s", 0)} + {best.get("hua_stage_s", 0)}) s',
                 host_cores=ncpu, cells=out_cells)
 
 

@@ -90,7 +90,7 @@ def test_x3_conv_forward_dgrad_wgrad_against_fp32(case):
     wr = w.detach().clone().requires_grad_()
     z = F.conv2d(xr, wr, bias.detach() if bias is not None else None, c['stride'], c['pad'])
     if bn is not None:
-        z = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        z = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight.detach(), bn.bias.detach(), False, 0.0, bn.eps)
     if res is not None:
         z = z + res
     if c['relu']:
