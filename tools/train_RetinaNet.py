@@ -47,11 +47,19 @@ def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size
     p.add_argument('--resume-from')
     p.add_argument('--load-from')
     p.add_argument('--bbox-head')
+    p.add_argument('--uncertainty', help='uncertainty type (accepted like the reference accepts it, tools/train_RetinaNet.py:56: never read there either)')
     p.add_argument('--no-validate', default=False, help='whether not to evaluate during training')
-    p.add_argument('--gpu-ids', type=int, default=[0], nargs='+')
-    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    group_gpus = p.add_mutually_exclusive_group()
+    group_gpus.add_argument('--gpus', type=int, default=None, help='number of gpus to use (only applicable to non-distributed training)')
+    group_gpus.add_argument('--gpu-ids', type=int, default=None, nargs='+', help='ids of gpus to use (only applicable to non-distributed training)')
+    p.add_argument('--deterministic', action='store_true',
+                   help='the reference sets cuDNN to deterministic here; the HIP kernels reduce in a fixed order already (slab-ordered weight '
+                        'gradients, ordered split-K) except the fp32-atomic column sums of bias / BN-shift gradients -- the flag is accepted and logged')
+    p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none', help='job launcher')
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--Unc-type', type=str)
+    p.add_argument('--precision', choices=['bf16x3', 'bf16'], default=None,
+                   help='arithmetic of the conv stack (default: AOD_CONV_PREC or bf16): bf16x3 = reference precision, bf16 = fast mode')
     p.add_argument('--synthetic', type=int, default=0, help='run on a synthetic VOC-shaped pool of this many images')
     p.add_argument('--synthetic-size', type=int, default=default_size)
     p.add_argument('--cycles', type=int, default=None, help='override the number of AL cycles')
@@ -59,6 +67,34 @@ def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size
     args = p.parse_args()
     os.environ.setdefault('LOCAL_RANK', str(args.local_rank))
     return args
+
+
+def init_dist(launcher, backend='nccl', **kwargs):
+    """mmcv.runner.init_dist as the reference calls it (tools/train_RetinaNet.py:119-121): one process per GPU; 'nccl' is RCCL over xGMI on
+    ROCm.  pytorch: the environment of torch.distributed.run; slurm: rank / size from SLURM_PROCID / SLURM_NTASKS, the first host of
+    SLURM_NODELIST as the rendezvous address (mmcv: `scontrol show hostname`), local rank = rank modulo the visible devices; mpi: the
+    OMPI_COMM_WORLD_* variables."""
+    import subprocess
+    import torch.distributed as dist
+    if launcher == 'slurm':
+        rank, world = int(os.environ['SLURM_PROCID']), int(os.environ['SLURM_NTASKS'])
+        if 'MASTER_ADDR' not in os.environ:
+            try:
+                os.environ['MASTER_ADDR'] = subprocess.getoutput(f"scontrol show hostname {os.environ['SLURM_NODELIST']} | head -n1").strip() or '127.0.0.1'
+            except KeyError:
+                os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ.setdefault('MASTER_PORT', str(kwargs.pop('port', 29500)))
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank % max(torch.cuda.device_count(), 1)))
+    elif launcher == 'mpi':
+        os.environ.update(RANK=os.environ['OMPI_COMM_WORLD_RANK'], WORLD_SIZE=os.environ['OMPI_COMM_WORLD_SIZE'],
+                          LOCAL_RANK=os.environ.get('OMPI_COMM_WORLD_LOCAL_RANK', '0'))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(kwargs.pop('port', 29500)))
+    elif launcher != 'pytorch':
+        raise ValueError(f'Invalid launcher type: {launcher}')
+    kwargs.pop('port', None)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    dist.init_process_group(backend=backend, **kwargs)
 
 
 def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
@@ -77,13 +113,18 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
     mkdir_or_exist(cfg.work_dir)
     cfg.save_dir = osp.join(cfg.work_dir, 'model_save')
     mkdir_or_exist(cfg.save_dir)
-    cfg.gpu_ids = args.gpu_ids
+    # train_RetinaNet.py:107-110: --gpu-ids wins, else range(--gpus) (default: one device)
+    cfg.gpu_ids = args.gpu_ids if args.gpu_ids is not None else list(range(args.gpus or 1))
+    if args.precision:
+        from aod_meh_hua_amd import functional as AF
+        AF.set_precision(args.precision)
     distributed = args.launcher != 'none'
+    if distributed:
+        init_dist(args.launcher, **cfg.dist_params)                          # (sets RANK / LOCAL_RANK / WORLD_SIZE for slurm and mpi)
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(cfg.dist_params.get('backend', 'nccl'))      # 'nccl' == RCCL over xGMI on ROCm
         cfg.gpu_ids = list(range(dist.get_world_size()))
     rank = int(os.environ.get('RANK', 0))
     if editCfg:
@@ -109,6 +150,9 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
     timestamp = time.strftime('%Y%m%d_%H%M%S', time.localtime())
     logger = get_root_logger(log_file=osp.join(cfg.work_dir, f'{timestamp}.log'), log_level=cfg.log_level)
     meta = dict(exp_name=osp.basename(args.config))
+    if args.deterministic:
+        logger.info('--deterministic: weight gradients and split-K sums are reduced in a fixed order by construction; bias / BN-shift column sums '
+                    'use fp32 atomics (last-bit run-to-run differences)')
     # train_RetinaNet.py:139-141: 8 loader workers when started from a shell, else 0; here: 8 for real image data (AOD_WORKERS overrides), 0 for
     # the synthetic pool (its samples are generated in-process)
     cfg.data.workers_per_gpu = 0 if args.synthetic else int(os.environ.get('AOD_WORKERS', 8))
