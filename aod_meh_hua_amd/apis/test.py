@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from ..mmcv_lite import DataContainer, ProgressBar
-from ..parallel import gather_scores, get_dist_info, shard_range
+from ..parallel import gather_scores, gather_scores_indexed, get_dist_info, shard_batches, shard_range
 
 
 class Uncertainty_fns:
@@ -42,6 +42,9 @@ import weakref as _weakref
 _GSCORE = _weakref.WeakKeyDictionary()
 
 
+_SHARD_STATE = dict(interleaved=False, imbalance=None)       # pool partition across ranks (single_gpu_uncertainty)
+
+
 def calculate_uncertainty(cfg, *args, **kwargs):
     """test.py:65-70."""
     return getattr(Uncertainty_fns, cfg.uncertainty_pool)(cfg, *args, **kwargs)
@@ -51,23 +54,20 @@ def _unwrap(x):
     return x.data if isinstance(x, DataContainer) else x
 
 
-def _shard_batches(dataset, lo, hi, bs, collate, workers):
-    """(idxs, collated batch) over this rank's block [lo, hi) of the pool.  workers > 0: worker processes decode / resize / normalise the
+def _shard_batches(dataset, batches, collate, workers):
+    """(idxs, collated batch) over this rank's batches (lists of global image indices) of the pool.  workers > 0: worker processes decode / resize / normalise the
     images ahead of the GPU (the reference builds its pool loader with cfg.data.workers_per_gpu workers, tools/train_RetinaNet.py:224-225,
     mmdet/datasets/builder.py:76-139) into PINNED host memory, `prefetch` batches deep, so that the H2D copy of batch i + 1 and the host work
     of batches i + 2.. overlap the scoring graph of batch i; at ~4 000 images/s of GPU rate a single-process PIL decode + resize would bound
     the pool loop by more than 10x.  workers == 0: the synchronous loop (same batches, same order)."""
-    starts = list(range(lo, hi, bs))
-    if workers <= 0 or not starts:
-        for s in starts:
-            idxs = list(range(s, min(s + bs, hi)))
+    if workers <= 0 or not batches:
+        for idxs in batches:
             yield idxs, collate([dataset[i] for i in idxs])
         return
-    from torch.utils.data import DataLoader, Subset
-    dl = DataLoader(Subset(dataset, range(lo, hi)), batch_size=bs, shuffle=False, num_workers=workers, collate_fn=collate, pin_memory=False,
-                    prefetch_factor=4, drop_last=False)
-    for s, batch in zip(starts, dl):
-        yield list(range(s, min(s + bs, hi))), batch
+    from torch.utils.data import DataLoader
+    dl = DataLoader(dataset, batch_sampler=batches, num_workers=workers, collate_fn=collate, pin_memory=False, prefetch_factor=4)
+    for idxs, batch in zip(batches, dl):
+        yield idxs, batch
 
 
 def _pin(x):
@@ -85,14 +85,18 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
     dataset = data_loader.dataset
     N = len(dataset)
     rank, world = get_dist_info()
-    lo, hi, per = shard_range(N, rank, world)
     bs = data_loader.batch_size or 1
+    # partition of the pool over the ranks (parallel.shard_batches): AOD_POOL_SHARD = contiguous | interleaved | auto (default: contiguous
+    # until a pass measured more than 5 % imbalance between the ranks' loop times -- then every later pass of this process strides the batches)
+    import os
+    shard_mode = os.environ.get('AOD_POOL_SHARD', 'auto')
+    interleaved = shard_mode == 'interleaved' or (shard_mode == 'auto' and _SHARD_STATE['interleaved'])
+    my_batches = shard_batches(N, bs, rank, world, interleaved)
     collate = data_loader.collate_fn
-    prog_bar = ProgressBar(hi - lo)
+    prog_bar = ProgressBar(sum(len(b) for b in my_batches))
     chunks, conf_chunks = [], []
     kwargs.setdefault('scaleUnc', False)
     # HIP-graph replay of the scoring batch (graphs.GraphedScore) while batches keep one shape; side-effect options stay eager
-    import os
     plain = not any(kwargs.get(k) for k in ('showNMS', 'saveUnc', 'saveMaxConf', 'scaleUnc', 'draw'))
     others = []
     gscore = None
@@ -109,13 +113,19 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
                 gscore = cache[key] = GraphedScore(model, rescale=True, isEval=False, batchIdx=0, **kwargs)
     dev = next(model.parameters()).device
     device_side = hasattr(dataset, 'device_batch')       # images produced on the device (datasets.DevicePhiloxPool): no host collate / H2D
-    all_ids = torch.arange(lo, max(hi, lo), dtype=torch.int64).to(dev)
+    my_idx = [i for b in my_batches for i in b]
+    all_ids = torch.tensor(my_idx, dtype=torch.int64).to(dev)             # GLOBAL image ids: they key the Philox streams of the HUA sampler
     workers = int(os.environ.get('AOD_POOL_WORKERS', getattr(data_loader, 'num_workers', 0) or 0))
-    batches = ((list(range(s, min(s + bs, hi))), None) for s in range(lo, hi, bs)) if device_side else \
-        _shard_batches(dataset, lo, hi, bs, collate, workers)
+    batches = ((idxs, None) for idxs in my_batches) if device_side else _shard_batches(dataset, my_batches, collate, workers)
+    timed = world > 1 and dev.type == 'cuda' and torch.distributed.is_available() and torch.distributed.is_initialized()
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    pos = 0
     for idxs, data in batches:
         s = idxs[0]
-        image_ids = all_ids[s - lo:s - lo + len(idxs)]
+        image_ids = all_ids[pos:pos + len(idxs)]
+        pos += len(idxs)
         if device_side:
             data = dataset.device_batch(idxs, dev, image_ids=image_ids)
         else:
@@ -136,10 +146,22 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
         prog_bar.update(len(idxs))
     dev = next(model.parameters()).device
     local = torch.cat(chunks) if chunks else torch.zeros(0, device=dev)
+    if timed:           # load balance of this pass: every rank learns every rank's loop time and takes the same decision for the next pass
+        import torch.distributed as dist
+        ev1.record()
+        ev1.synchronize()
+        t = torch.tensor([ev0.elapsed_time(ev1)], device=dev)
+        ts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        ts = torch.cat(ts)
+        _SHARD_STATE['imbalance'] = float((ts.max() - ts.min()) / ts.max().clamp_min(1e-9))
+        if _SHARD_STATE['imbalance'] > 0.05:
+            _SHARD_STATE['interleaved'] = True
+    gather = (lambda v: gather_scores_indexed(v, my_idx, N)) if interleaved else (lambda v: gather_scores(v, N))
     if kwargs.get('saveMaxConf'):
         conf = torch.cat(conf_chunks) if conf_chunks else torch.zeros(0, device=dev)
-        return gather_scores(local, N), gather_scores(conf, N)
-    return gather_scores(local, N)
+        return gather(local), gather(conf)
+    return gather(local)
 
 
 @torch.no_grad()

@@ -942,7 +942,8 @@ def _frag_selfcheck(dev):
     tab = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(dev)
     ho.call('aod_frag_pack', ho.ptr(tab), 3, blk, ho.stream())
     ok = True
-    for _ in range(3):
+    # the bench shape three times, then ragged shapes (partial tiles in both directions, odd image counts: what keep-ratio VOC batches produce)
+    for B, H, W in ((B, H, W),) * 3 + ((2, 13, 37), (3, 7, 129), (1, 38, 50)):
         x = rnd(B * H * W, C4).relu().bfloat16()
         a = ho.bottleneck128_fwd(x, B, H, W, ws[0], *sb[0], ws[1], *sb[1], ws[2], *sb[2], keep=True)
         b = ho.bottleneck128_fwd(x, B, H, W, frags[0], *sb[0], frags[1], *sb[1], frags[2], *sb[2], keep=True, frag=True)

@@ -189,6 +189,46 @@ def shard_range(n_total, rank=None, world=None):
     return lo, min(lo + per, n_total), per
 
 
+def shard_batches(n_total, bs, rank=None, world=None, interleaved=False):
+    """This rank's batches of the pool as lists of GLOBAL image indices.  Contiguous (SURVEY 8e default): the shard_range block cut into
+    batches.  Interleaved: global batch k (images [k*bs, (k+1)*bs)) goes to rank k mod W -- the per-image work of the HUA stage varies with
+    the number of (candidate, object) pairs, and pools are often ordered (by video, by scene): striding the batches evens that out
+    ('interleaved rather than contiguous assignment if imbalance > 5 %').  The image ids key the Philox streams, so either
+    partition gives bit-identical scores."""
+    if rank is None:
+        rank, world = get_dist_info()
+    if not interleaved:
+        lo, hi, _ = shard_range(n_total, rank, world)
+        return [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
+    nb = math.ceil(n_total / bs) if n_total else 0
+    return [list(range(k * bs, min((k + 1) * bs, n_total))) for k in range(rank, nb, world)]
+
+
+def gather_scores_indexed(local_scores, local_idx, n_total):
+    """Scores of an arbitrary index set per rank -> the full [N] vector on every rank: ONE all-gather of the padded (index, score) pairs
+    (indices travel as fp32-exact int32 bit patterns in a second tensor; pad slots carry index -1)."""
+    rank, world = get_dist_info()
+    dev = local_scores.device
+    idx = torch.as_tensor(local_idx, dtype=torch.int64, device=dev)
+    full = torch.zeros(n_total, dtype=local_scores.dtype, device=dev)
+    if world == 1:
+        full[idx] = local_scores
+        return full
+    cnt = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+    per = int(cnt)
+    sbuf = local_scores.new_zeros(per)
+    ibuf = torch.full((per,), -1, dtype=torch.int64, device=dev)
+    sbuf[:idx.numel()], ibuf[:idx.numel()] = local_scores, idx
+    so, io = [torch.empty_like(sbuf) for _ in range(world)], [torch.empty_like(ibuf) for _ in range(world)]
+    dist.all_gather(so, sbuf)
+    dist.all_gather(io, ibuf)
+    sc, ix = torch.cat(so), torch.cat(io)
+    ok = ix >= 0
+    full[ix[ok]] = sc[ok]
+    return full
+
+
 def gather_scores(local_scores, n_total):
     """local_scores: 1-D fp32 tensor of this rank's block (len <= ceil(N/W)).  Returns the full [N] tensor on
     every rank."""

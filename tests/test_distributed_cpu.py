@@ -20,6 +20,12 @@ def _worker(rank, world, port, n_total, q):
     # each rank "scores" its block with a function of the GLOBAL image index only
     local = torch.tensor([float(i * i % 17) + 0.25 for i in range(lo, hi)])
     full = gather_scores(local, n_total)
+    # the interleaved partition (batches of 3 striding over the ranks) scores the same images and gathers the same vector
+    from aod_meh_hua_amd.parallel import gather_scores_indexed, shard_batches
+    mine = [i for b in shard_batches(n_total, 3, interleaved=True) for i in b]
+    full_i = gather_scores_indexed(torch.tensor([float(i * i % 17) + 0.25 for i in mine]), mine, n_total)
+    assert torch.equal(full_i, full), (full_i, full)
+    assert [i for b in shard_batches(n_total, 3) for i in b] == list(range(lo, hi))       # contiguous form = the shard_range block
     # gradient averaging: rank r holds grads r+1 on two tensors spanning two buckets
     p1, p2 = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))
     p1.grad, p2.grad = torch.full((5,), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))
@@ -78,4 +84,7 @@ def test_single_process_paths_are_noops():
     assert get_dist_info() == (0, 1) and shard_range(10) == (0, 10, 10)
     x = torch.arange(5.0)
     assert torch.equal(gather_scores(x, 5), x)
+    from aod_meh_hua_amd.parallel import gather_scores_indexed, shard_batches
+    assert shard_batches(7, 3, 0, 2, interleaved=True) == [[0, 1, 2], [6]] and shard_batches(7, 3, 1, 2, interleaved=True) == [[3, 4, 5]]
+    assert torch.equal(gather_scores_indexed(torch.tensor([1., 2., 3.]), [4, 0, 2], 5), torch.tensor([2., 0., 3., 0., 1.]))
     GradSync().all_reduce_grads([torch.nn.Parameter(torch.zeros(2))])

@@ -44,3 +44,21 @@ def test_two_rank_replicas_stay_equal_and_match_a_mean_gradient_run():
     # per-rank shape sequences differ: the ranks mixed eager / capture / replay differently and still agree (graphs.py)
     assert out['mixed_replicas_equal'], out
     assert out['mixed_modes'][0] != out['mixed_modes'][1] and any(m == 'graph' for ms in out['mixed_modes'] for m in ms), out
+
+
+def test_two_rank_bench_over_rccl_when_two_devices_are_visible():
+    """The first multi-GPU lease must exercise RCCL before the driver's scaling bench does: with >= 2 visible devices, two ranks on two
+    GPUs over backend 'nccl' (= RCCL over xGMI) run the data-parallel bench step -- bucketed gradient all-reduces between the per-segment
+    graphs, score all-gather -- and the pool mode (sharded scoring + one all-gather).  Skipped on a 1-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:            # (counting devices does not initialise the GPU)
+        pytest.skip('needs two visible devices')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('AOD_BENCH_ONE_GPU', None)
+    for extra, port in ((['--steps', '3', '--warmup', '1'], '29551'), (['--mode', 'pool', '--pool', '64'], '29553')):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', port, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '2', '--size', '128', '--no-cpu-baseline', *extra]
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['collective_backend'] == 'nccl (RCCL)', out['config']

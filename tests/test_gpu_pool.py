@@ -80,7 +80,17 @@ def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch
             parts.append(single_gpu_uncertainty(pool_model, Loader(ds, 16), **KW).cpu().numpy())
             lo, hi, _ = shard_range(N_POOL, r, 2)
             assert parts[-1].shape == (hi - lo,)
+        # ... and of the INTERLEAVED partition (AOD_POOL_SHARD=interleaved: global batch k -> rank k mod 2)
+        monkeypatch.setenv('AOD_POOL_SHARD', 'interleaved')
+        monkeypatch.setattr(apis_test, 'gather_scores_indexed', lambda local, idx, n_total: (local, idx))
+        inter = np.full(N_POOL, np.nan, np.float32)
+        for r in range(2):
+            monkeypatch.setattr(apis_test, 'get_dist_info', lambda r=r: (r, 2))
+            v, idx = single_gpu_uncertainty(pool_model, Loader(ds, 16), **KW)
+            assert idx[:16] == list(range(16 * r, 16 * r + 16))
+            inter[np.array(idx)] = v.cpu().numpy()
         monkeypatch.undo()
+    assert np.array_equal(inter, u16)
     assert u16.shape == (N_POOL,) and np.isfinite(u16).all()
     assert (u16 > 0).sum() >= N_POOL // 2, 'degenerate pool: the calibrated head should give most images a non-zero score'
     assert np.array_equal(u16, u5), np.abs(u16 - u5).max()
