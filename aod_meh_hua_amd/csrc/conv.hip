@@ -81,7 +81,7 @@ template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST, bool X3>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(ST == 2 || (ST == 3 && NT == 256), "LDS stages: 2, or 3 for the 4-wave forms");
-  static_assert(!X3 || (NT == 256 && !GROUPED && BM <= 128), "X3: 4-wave ungrouped forms");
+  static_assert(!X3 || NT == 256 || (NT == 512 && BM == 256), "X3: the 4-wave forms and the 8-wave 256 x 256 tile");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
   constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   };
   // one K-step.  Plain: the two 32-deep k-blocks.  X3: k-block 0 = heads, k-block 1 = tails of the same 32 channels -> xh*wh, xl*wh, xh*wl
   // (the tails of the activations are read while the head fragments stay in registers; the weight fragments are replaced last)
-  auto kstep = [&](const char* sa, const char* sb) {
+  // (`defer`: a late wave of the staggered 8-wave form leaves the LAST product of the step to the top of the next iteration, like the
+  // plain form leaves its second k-block)
+  auto kstep = [&](const char* sa, const char* sb, bool defer) {
     frag_read(sa, sb, 0);
     mfma_block();
     if constexpr (X3) {
@@ -478,10 +480,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         const int row = wn * WN + j * 16 + lr;
         bfr[j] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
       }
-      mfma_block();
+      if (!defer) mfma_block();
     } else {
       frag_read(sa, sb, 1);
-      mfma_block();
+      if (!defer) mfma_block();
     }
   };
   if (ST == 3) {
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       if (more2) gload(cur == 0 ? 2 : cur - 1);
       const char* sa = smem + cur * STAGE;
       const char* sb = sa + A_BYTES;
-      kstep(sa, sb);
+      kstep(sa, sb, false);
       if (!have1) break;
       __builtin_amdgcn_sched_barrier(0);
       if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + A_BYTES;
     static_assert(BK == 64, "two 32-deep k-blocks per K-step");
-    if constexpr (X3) kstep(sa, sb);
+    if constexpr (X3) { kstep(sa, sb, late); carried = late; }
     else {
       frag_read(sa, sb, 0);
       mfma_block();
@@ -978,7 +980,18 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
   if (p.x3) {
-    // X3: the 4-wave forms (three MFMAs per staged K-step: the staging-bound arguments for the 8-wave and 256 x 256 forms do not carry over)
+    // X3: the 256 x 256 tile under the same fill rule as the plain form (a K-step of the 128 x 128 tile asks the L2 -> LDS path for 64 KB
+    // per 1 536 matrix-pipe cycles per CU -- more than it delivers --, the big tile for half of that), else the 4-wave forms
+    {
+      static const char* dbg_t256x = getenv("AOD_TILE_256");
+      const long long t256 = ntiles(256, 256);
+      const bool fits = t256 >= 240 && t256 * 100 >= ((t256 + 255) / 256) * 256 * 92;
+      if (!(dbg_t256x && dbg_t256x[0] == '0') && !p.res && !p.out_f32 && p.N % 256 == 0 && p.K >= 2048 && fits) {
+        if (!p.mask) launch_conv<256, 256, 512, 0, false, 2, true>(p, st); else launch_conv<256, 256, 512, 1, false, 2, true>(p, st);
+        AOD_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
     else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128, 256, 2, false, 2, true>(p, st);
     else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128, 256, 2, false, 3, true>(p, st);
@@ -1028,7 +1041,7 @@ extern "C" int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, cons
                                   aod_stream_t stream) {
   AOD_CHECK_ARG(desc && src && w_packed && dst && ngroups >= 1 && ngroups <= 4, "conv_grouped: 1..4 groups");
   AOD_CHECK_ARG(!desc->out_f32, "conv_grouped: bf16 destinations only");
-  AOD_CHECK_ARG(!desc->x3, "conv_grouped: no X3 form");
+  AOD_CHECK_ARG(!desc->x3 || (desc->N % 256 == 0 && desc->R * desc->S * desc->C >= 2048), "conv_grouped (x3): N %% 256 == 0 and a deep K required");
   ConvKParams p;
   int rc = conv_params(desc, src[0], w_packed[0], dst[0], nullptr, pre_shift ? pre_shift[0] : nullptr, nullptr, mask ? mask[0] : nullptr, nullptr,
                        nullptr, colsum ? colsum[0] : nullptr, p);
@@ -1053,7 +1066,9 @@ extern "C" int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, cons
   };
   static const char* dbg_t256 = getenv("AOD_TILE_256");
   const bool ok256 = !(dbg_t256 && dbg_t256[0] == '0') && p.N % 256 == 0 && p.K >= 1024;
-  if (ok256 && fill(256, 256, 256) * 1.12 >= fill(128, 128, 512)) {        // (the big tile is ~15 % faster per FLOP when its rounds are full)
+  if (p.x3) {          // x3 groups take the big tile (the 4-wave forms have no grouped instances)
+    if (!any_mask) launch_conv<256, 256, 512, 0, true, 2, true>(p, st); else launch_conv<256, 256, 512, 1, true, 2, true>(p, st);
+  } else if (ok256 && fill(256, 256, 256) * 1.12 >= fill(128, 128, 512)) {        // (the big tile is ~15 % faster per FLOP when its rounds are full)
     if (!any_mask) launch_conv<256, 256, 512, 0, true>(p, st); else launch_conv<256, 256, 512, 1, true>(p, st);
   } else {
     AOD_CHECK_ARG(p.N >= 128, "conv_grouped: N >= 128 required");

@@ -791,7 +791,7 @@ class ConvPairFn(Function):
         dsegs, xd = dense_segs(y_segs), dense_segs(x_segs)
         dzs, gws, gbs = [], [], []
         for gi, (w, x_rows, a_rows) in enumerate(((wA, xA, yA), (wB, xB, yB))):
-            g_rows = _grad_rows(gouts[gi * nl:(gi + 1) * nl], y_segs, O, w.device)
+            g_rows = _grad_rows(gouts[gi * nl:(gi + 1) * nl], y_segs, ho.width(O), w.device)
             slot = meta['slot'][gi]
             if slot is not None and slot.masked and g_rows.dtype == torch.bfloat16:
                 dz, s1 = g_rows, slot.s1                      # the consumer's dgrad epilogue already did the activation backward
@@ -830,7 +830,9 @@ def conv_pair_act(xsA, xsB, convA, convB, sole_consumer=False, rider=None):
     whose forward (no autograd) is computed in the same launch; then returns (ya, yb, rider output rows or None)."""
     import os
     wA, wB = convA.weight, convB.weight
-    ok = (_PREC == 'bf16' and os.environ.get('AOD_GROUP_TOWERS', '1') != '0' and wA.shape == wB.shape and wA.shape[0] % 8 == 0
+    # (reference-precision mode: the grouped launch exists for the 256 x 256 tile only -- N % 256 == 0 and a deep filter)
+    x3_ok = not ho.X3 or (wA.shape[0] % 256 == 0 and wA.shape[1] % 32 == 0 and wA.shape[1] * wA.shape[2] * wA.shape[3] >= 1024)
+    ok = (x3_ok and os.environ.get('AOD_GROUP_TOWERS', '1') != '0' and wA.shape == wB.shape and wA.shape[0] % 8 == 0
           and wA.shape[0] >= 128 and convA.bias is not None and convB.bias is not None and convA.stride[0] == convB.stride[0] == 1
           and convA.padding == convB.padding and convA.dilation == convB.dilation and len(xsA) == len(xsB)
           and all(a.shape == b.shape and a.dtype == torch.bfloat16 for a, b in zip(xsA, xsB)))
@@ -867,7 +869,7 @@ def conv_towers_nograd(xss, convs, relu=True):
     """Inference-only: the same-depth convs of several head towers (list of parameter holders with .weight / .bias, identical shape)
     applied to their own level lists `xss[g]` in ONE grouped launch (hipops.conv2d_rows_grouped): cls / reg / evidence towers of the
     scoring pass.  Returns one level list per tower."""
-    assert not torch.is_grad_enabled() and _PREC == 'bf16'
+    assert not torch.is_grad_enabled()
     G = len(convs)
     rows, segs = zip(*[multi_rows(list(xs)) for xs in xss])
     assert all(sg == segs[0] for sg in segs), 'towers must see the same pyramid geometry'
@@ -875,7 +877,8 @@ def conv_towers_nograd(xss, convs, relu=True):
     O, I, R, S = w0.shape
     pis = [PREP.get(c.weight, None, rows[0].shape[1], 0.0) for c in convs]
     outs, dsegs = ho.conv2d_rows_grouped(list(rows), list(segs[0]), [pi.wf for pi in pis], O, R, S, convs[0].stride[0], convs[0].padding[0],
-                                         convs[0].dilation[0], pre_shifts=[c.bias.detach() if c.bias is not None else None for c in convs], relu=relu)
+                                         convs[0].dilation[0], pre_shifts=[c.bias.detach() if c.bias is not None else None for c in convs], relu=relu,
+                                         alg=(I, O))
     return [[as_nchw(o[s.row0:s.row0 + s.rows], s.B, s.H, s.W) for s in dsegs] for o in outs]
 
 

@@ -214,7 +214,7 @@ def conv2d_rows_grouped(xs, src_segs, ws, N, R, S, stride=1, pad=0, dil=1, *, pr
     dst_segs = out_segs(src_segs, R, S, stride, pad, dil)
     rows = sum(s.rows for s in dst_segs)
     if outs is None:
-        outs = [torch.empty(rows, N, dtype=torch.bfloat16, device=xs[0].device) for _ in range(G)]
+        outs = [torch.empty(rows, width(N), dtype=torch.bfloat16, device=xs[0].device) for _ in range(G)]
     d = make_desc(Cin, N, R, S, stride, pad, dil, src_segs, dst_segs, False, relu, False)
     arr = lambda ts: (C.c_void_p * G)(*[(t.data_ptr() if t is not None else None) for t in ts])
     for t in list(xs) + list(ws) + list(outs):
@@ -234,7 +234,7 @@ def conv2d_dgrad_rows_grouped(dzs, dz_segs, x_segs, wds, Cin, R, S, stride=1, pa
     G = len(dzs)
     Npad = dzs[0].shape[1]
     rows = sum(s.rows for s in x_segs)
-    outs = [torch.empty(rows, Cin, dtype=torch.bfloat16, device=dzs[0].device) for _ in range(G)]
+    outs = [torch.empty(rows, width(Cin), dtype=torch.bfloat16, device=dzs[0].device) for _ in range(G)]
     d = make_desc(Npad, Cin, R, S, stride, pad, dil, dz_segs, x_segs, True, False, False)
     arr = lambda ts: (C.c_void_p * G)(*[(t.data_ptr() if t is not None else None) for t in ts])
     for t in list(dzs) + list(wds) + outs:

@@ -148,7 +148,8 @@ class Lambda_L2Net(L_AnchorHead):
     def simple_test(self, feats, img_metas, rescale=False, **kwargs):
         """Lambda_L2.py:398-420."""
         import os
-        if (not torch.is_grad_enabled() and AF.get_precision() == 'bf16' and os.environ.get('AOD_GROUP_TOWERS', '1') != '0'
+        x3_ok = AF.get_precision() == 'bf16' or all(m.conv.weight.shape[0] % 256 == 0 and m.conv.weight.shape[1] % 32 == 0 for m in self.cls_convs)
+        if (not torch.is_grad_enabled() and x3_ok and os.environ.get('AOD_GROUP_TOWERS', '1') != '0'
                 and len(self.cls_convs) == len(self.reg_convs) == len(self.L_convs) > 0 and all(m.with_activation for m in self.cls_convs)):
             outs, L_scores = self.forward_all_towers(feats)
         else:

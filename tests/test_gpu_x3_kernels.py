@@ -189,3 +189,56 @@ def test_x3_stem_against_fp32():
     ref = F.max_pool2d(torch.relu(F.batch_norm(F.conv2d(img, conv.weight, None, 2, 3), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)), 3, 2, 1)
     got = AF.x3_to_f32(y, 64)
     assert got.shape == ref.shape and _err(got, ref) < 1e-4, _err(got, ref)
+
+
+def test_x3_grouped_tower_launches_equal_the_separate_ones():
+    """cls / reg tower convs of one depth as ONE grouped launch of the 256 x 256 tile (aod_conv2d_grouped, x3), forward and dgrad with the fused
+    activation backward, against two separate launches of the 4-wave tile: the same K order per output element -> identical bits"""
+    import os
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    g = torch.Generator(device='cuda').manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    B, C = 2, 256
+    shapes = [(24, 40), (12, 20), (6, 10)]
+    convs = []
+    for _ in range(4):
+        c = Conv2d(C, C, 3, padding=1).cuda()
+        with torch.no_grad():
+            c.weight.copy_(rnd(C, C, 3, 3) * 0.02); c.bias.copy_(rnd(C) * 0.1)
+        convs.append(c)
+    _, slots = AF.pyramid_buffer([(B, h, w) for h, w in shapes], C, 'cuda')
+    feats = []
+    for sl, (h, w) in zip(slots, shapes):
+        sl.copy_(AF.as_nchw(_x(rnd(B, C, h, w)), B, h, w))
+        feats.append(sl)
+
+    def run(grouped):
+        os.environ['AOD_GROUP_TOWERS'] = '1' if grouped else '0'
+        try:
+            xs = [f.detach().requires_grad_() for f in feats]
+            a, b = zip(*[AF.fork(x, 2) for x in xs])
+            ya, yb = AF.conv_pair_act(list(a), list(b), convs[0], convs[1], sole_consumer=False)
+            za, zb = AF.conv_pair_act(ya, yb, convs[2], convs[3], sole_consumer=True)
+            for c in convs:
+                c.weight.grad = c.bias.grad = None
+            gs = [AF.as_nchw(_x(torch.randn(B, C, h, w, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5 + i))), B, h, w)
+                  for i, (h, w) in enumerate(shapes)]
+            torch.autograd.backward(list(za) + list(zb), gs + gs)
+            torch.cuda.synchronize()
+            return ([t.detach().clone() for t in list(za) + list(zb)], [x.grad.clone() for x in xs],
+                    [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs])
+        finally:
+            os.environ.pop('AOD_GROUP_TOWERS', None)
+    o1, gx1, gw1 = run(True)
+    o0, gx0, gw0 = run(False)
+    assert all(torch.equal(u, v) for u, v in zip(o1, o0))
+    assert all(torch.equal(u, v) for u, v in zip(gx1, gx0))
+    # weight / bias gradients: same slabs or a different grouping of the wgrad launches -> fp32 summation order may differ
+    for u, v in zip(gw1, gw0):
+        assert _err(u, v) < 1e-5
+    # and against fp32
+    x32 = [_f(AF.as_rows(f), B, h, w, C) for f, (h, w) in zip(feats, shapes)]
+    ref = [torch.relu(F.conv2d(torch.relu(F.conv2d(x, convs[0].weight, convs[0].bias, 1, 1)), convs[2].weight, convs[2].bias, 1, 1)) for x in x32]
+    for r, o, (h, w) in zip(ref, o1[:3], shapes):
+        assert _err(_f(AF.as_rows(o), B, h, w, C), r) < 1e-4
