@@ -127,7 +127,8 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
         image_ids = all_ids[pos:pos + len(idxs)]
         pos += len(idxs)
         if device_side:
-            data = dataset.device_batch(idxs, dev, image_ids=image_ids)
+            out = gscore.static_image((len(idxs), 3) + tuple(dataset.size)) if gscore is not None and hasattr(dataset, 'size') else None
+            data = dataset.device_batch(idxs, dev, image_ids=image_ids, out=out)
         else:
             data = {k: _unwrap(v) for k, v in data.items() if k in ('img', 'img_metas')}
             if dev.type == 'cuda':

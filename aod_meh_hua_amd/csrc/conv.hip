@@ -1365,6 +1365,28 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
   float* const dwp = p.dw + (long long)split * p.slab_stride;
   const bool slab = p.slab_stride > 0;
   const int lr = lane & 15, lq = lane >> 4;
+  if constexpr (X3) {
+    // X3: the three bands of a logical entry sit in the SAME lane and register slot of three accumulators of this wave -- (zh, xh), (zh, xl)
+    // and (zl, xh) -- and are added here, (hh + hl) + lh: the slab is the LOGICAL [N / 2][R][S][C / 2] partial gradient (a quarter of the
+    // bytes of the band form) and the plain unpack kernel serves it
+    const int KL = p.K >> 1;
+#pragma unroll
+    for (int I = 0; I < NI / 2; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ / 2; ++J) {
+        const int ih = (I >> 1) * 4 + (I & 1), jh = (J >> 1) * 4 + (J & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wm * (16 * NI) + ih * 16 + lq * 4 + r;        // physical column of the head of the entry's dZ channel
+          const int k = k0 + wn * (16 * NJ) + jh * 16 + lr;                // ... and of its (tap, input channel)
+          if (n < p.N && k < p.K) {
+            const float v = (acc[ih][jh][r] + acc[ih][jh + 2][r]) + acc[ih + 2][jh][r];
+            dwp[(long long)(((n >> 6) << 5) + (n & 31)) * KL + ((k >> 6) << 5) + (k & 31)] = v;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1382,6 +1404,178 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
         }
 #endif
       }
+}
+
+// X3, WIDE form (the tower filters and every other layer whose X-layout dW is whole 512 x 512 tiles): a 256 x 256 LOGICAL tile per
+// workgroup with ONE accumulator per entry -- zh*xh + zh*xl + zl*xh are summed in it, like the forward form sums its three products.  The
+// band form above spends a 256 x 256 accumulator tile on 128 x 128 logical entries (a quarter of it on the tail x tail band it never
+// computes) and issues 1.5 MFMAs per accumulator and 64-pixel step for 64 KB of staged operands; this form stages the same 64 KB per
+// 32-pixel step -- eight 128-column sub-images: [zh32 | zl32] x 4 channel groups for each operand -- for 3 MFMAs per accumulator: twice the
+// matrix work per staged byte, four times per LDS fragment read.  8 waves as 2 x 4, 128 x 64 logical entries per wave (32 accumulators);
+// the head fragments of dZ are replaced by its tail fragments for the third product (the x fragments stay).
+__device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in) {
+  constexpr int NW = 8, TN = 4, TK = 4, BKM = 32;
+  constexpr int IMG = BKM * 256;              // one 128-column sub-image: 8 KB
+  constexpr int STAGE = (TN + TK) * IMG;      // 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = uw >> 2, wn = uw & 3;
+  int bid = bid_in;
+  const int ntile = p.tiles_n * p.tiles_k;
+  const int split = bid / ntile; bid -= split * ntile;
+  const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
+  const int n0 = tile_n * 512, k0 = tile_k * 512;       // physical columns
+  const int ms = split * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  if (ms >= me) return;
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
+  const auto rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.tab, 0, (int)p.tab_bytes, 0x00020000);
+  const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group (one pass covers the 32 rows of a step)
+  const int ch = (lane & 15) ^ ((prow << 2) | (uw & 3));       // source chunk of this lane (fixed; tr_off's key of row 4 * uw + prow)
+  constexpr unsigned OOB_BASE = 0xf0000000u;
+  unsigned zcol[TN];
+  bool zok[TN];
+#pragma unroll
+  for (int h = 0; h < TN; ++h) {
+    const int zn = n0 + 128 * h + ch * 8;
+    zok[h] = zn < p.N;
+    zcol[h] = (unsigned)(zn * 2);
+  }
+  unsigned cdx[TK];
+  int dy[TK];
+  unsigned long long tbit[TK];
+#pragma unroll
+  for (int h = 0; h < TK; ++h) {
+    const int kk = k0 + 128 * h + ch * 8;
+    const bool kok = kk < p.K;
+    const int tap = kok ? kk / p.C : 0, c0 = kok ? kk - tap * p.C : 0;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    dy[h] = tr * p.dil;
+    cdx[h] = (unsigned)((ts * p.dil * p.C + c0) * 2);
+    tbit[h] = kok ? (1ull << tap) : 0ull;
+  }
+  char* const stab = smem + 2 * STAGE;                        // [2][32] row records
+  auto tdma = [&](int mbase, int slot) {
+    if (uw == 0) {
+      const int m = mbase + (lane >> 1);
+      const unsigned off = (unsigned)min(m, p.M - 1) * 32u + (unsigned)(lane & 1) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (__attribute__((address_space(3))) void*)(stab + slot * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  RowRec rec;
+  auto rread = [&](int slot) { rec = *reinterpret_cast<const RowRec*>(stab + slot * 1024 + (4 * uw + prow) * 32); };
+  auto gload = [&](int mbase, int buf) {
+    char* sz = smem + buf * STAGE;
+    char* sx = sz + TN * IMG;
+    const int m = mbase + 4 * uw + prow;
+    const bool mok = m < me;
+    const RowRec r = rec;
+#pragma unroll
+    for (int h = 0; h < TN; ++h) {
+      const unsigned zoff = (mok && zok[h]) ? r.zoff + zcol[h] : OOB_BASE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + h * IMG + (4 * uw) * 256), 16, zoff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < TK; ++h) {
+      const unsigned xoff = (mok && (r.mask & tbit[h])) ? r.xrow + (unsigned)dy[h] * r.wc2 + cdx[h] : OOB_BASE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + h * IMG + (4 * uw) * 256), 16, xoff, 0, 0, 0);
+    }
+  };
+  constexpr int NI = 8, NJ = 4;               // 16-entry groups per wave: 128 logical dZ channels x 64 logical (tap, channel) columns
+  f32x4 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (me - ms + BKM - 1) / BKM;
+  tdma(ms, 0);
+  if (nsteps > 1) tdma(ms + BKM, 1);
+  __syncthreads();
+  rread(0);
+  gload(ms, 0);
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  auto tr_read = [&](u32x2_t& dst, const char* ptr) {
+    const unsigned a = (unsigned)(unsigned long long)ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+  };
+  // fragment of the 16 physical columns [col, col + 16) of an operand stage: pixel rows 8g + q (+4), 4 columns per lane
+  auto frag = [&](u32x2_t& lo, u32x2_t& hi, const char* base, int col) {
+    const char* im = base + (col >> 7) * IMG;
+    const int c = (col & 127) + pp * 4;
+    tr_read(lo, im + tr_off(8 * g + q, c >> 3) + (c & 7) * 2);
+    tr_read(hi, im + tr_off(8 * g + q + 4, c >> 3) + (c & 7) * 2);
+  };
+  u32x2_t alo[NI], ahi[NI], bhlo[NJ], bhhi[NJ], bllo[NJ], blhi[NJ];
+  bf16x8 af[NI], bh[NJ], bl[NJ];
+  for (int stp = 0; stp < nsteps; ++stp) {
+    const int cur = stp & 1;
+    if (stp + 1 < nsteps) {
+      rread((stp + 1) & 1);                                 // landed before the previous barrier
+      gload(ms + (stp + 1) * BKM, cur ^ 1);
+    }
+    if (stp + 2 < nsteps) tdma(ms + (stp + 2) * BKM, stp & 1);
+    const char* sz = smem + cur * STAGE;
+    const char* sx = sz + TN * IMG;
+    // heads of dZ, heads and tails of x
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int nl = wm * 128 + i * 16; frag(alo[i], ahi[i], sz, ((nl >> 5) << 6) + (nl & 31)); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int kl = wn * 64 + j * 16, col = ((kl >> 5) << 6) + (kl & 31);
+      frag(bhlo[j], bhhi[j], sx, col);
+      frag(bllo[j], blhi[j], sx, col + 32);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { asm volatile("" : "+v"(alo[i]), "+v"(ahi[i])); af[i] = __builtin_bit_cast(bf16x8, (u32x4_t){alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]}); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      asm volatile("" : "+v"(bhlo[j]), "+v"(bhhi[j]), "+v"(bllo[j]), "+v"(blhi[j]));
+      bh[j] = __builtin_bit_cast(bf16x8, (u32x4_t){bhlo[j][0], bhlo[j][1], bhhi[j][0], bhhi[j][1]});
+      bl[j] = __builtin_bit_cast(bf16x8, (u32x4_t){bllo[j][0], bllo[j][1], blhi[j][0], blhi[j][1]});
+    }
+    // tails of dZ requested now, consumed after the two head products
+    u32x2_t tlo[NI], thi[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int nl = wm * 128 + i * 16; frag(tlo[i], thi[i], sz, ((nl >> 5) << 6) + (nl & 31) + 32); }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bh[j], acc[i][j], 0, 0, 0);       // zh * xh
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);       // zh * xl
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { asm volatile("" : "+v"(tlo[i]), "+v"(thi[i])); af[i] = __builtin_bit_cast(bf16x8, (u32x4_t){tlo[i][0], tlo[i][1], thi[i][0], thi[i][1]}); }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bh[j], acc[i][j], 0, 0, 0);         // zl * xh
+    __syncthreads();
+  }
+  // logical slab [N / 2][K / 2] of this pixel split
+  float* const dwp = p.dw + (long long)split * p.slab_stride;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int NL = p.N >> 1, KL = p.K >> 1;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (n0 >> 1) + wm * 128 + i * 16 + lq * 4 + r;
+        const int k = (k0 >> 1) + wn * 64 + j * 16 + lr;
+        if (n < NL && k < KL) dwp[(long long)n * KL + k] = acc[i][j][r];
+      }
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_x3w_kernel(const WgradParams p) {
+  wgrad_tile_x3w(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
 }
 
 // split of the pixel axis over workgroups: all workgroups co-resident (<= 2 per CU, no ragged second round); cost model (measured on
@@ -1407,6 +1601,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK
   else wgrad_tile<NW, TN, TK, X3>(gp.g[3], b - gp.wg0[3]);
 }
 
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_grouped_x3w_kernel(const WgradGroups gp) {
+  const int b = gp.g[0].xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
+  if (b < gp.wg0[1]) wgrad_tile_x3w(gp.g[0], b);
+  else if (b < gp.wg0[2]) wgrad_tile_x3w(gp.g[1], b - gp.wg0[1]);
+  else if (b < gp.wg0[3]) wgrad_tile_x3w(gp.g[2], b - gp.wg0[2]);
+  else wgrad_tile_x3w(gp.g[3], b - gp.wg0[3]);
+}
+
+// `big`: tile form -- 0 = 128 x 128, 1 = 256 x 256, 2 = the WIDE x3 form (512 x 512 physical columns = 256 x 256 logical entries, wgrad_tile_x3w)
 static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big, int big_min_m = 49152, int x3 = 0) {
   // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
   static const char* dbg_big = getenv("AOD_WGRAD_256");
@@ -1414,7 +1617,9 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
   // runs per workgroup and take it from 16 384 pixels on: -0.11 ms per step, AOD_WGRAD_BIG_MINM overrides the group threshold)
   big = (N % 256 == 0 && K % 256 == 0 && M >= big_min_m) ? 1 : 0;
   if (dbg_big && dbg_big[0] == '0') big = 0;
-  const int T = big ? 256 : 128;
+  static const char* dbg_wide = getenv("AOD_WGRAD_X3_WIDE");       // (debug: 0 = never the wide x3 form)
+  if (x3 && N % 512 == 0 && K % 512 == 0 && M >= big_min_m && !(dbg_wide && dbg_wide[0] == '0') && !(dbg_big && dbg_big[0] == '0')) big = 2;
+  const int T = big == 2 ? 512 : (big ? 256 : 128);
   tiles_n = (N + T - 1) / T;
   tiles_k = (K + T - 1) / T;
   const int tiles = tiles_n * tiles_k;
@@ -1426,7 +1631,7 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
     const int rows = ((M + sp - 1) / sp + 63) / 64 * 64;
     const int nsp = (M + rows - 1) / rows;
     const int wgs = tiles * nsp;
-    double cost = (rows / 64) * (big ? 2.9 : (wgs > 256 ? 1.7 : 1.45));
+    double cost = (rows / 64) * (big == 2 ? 4.5 : (big ? 2.9 : (wgs > 256 ? 1.7 : 1.45)));
     cost += slabs ? wgs * 0.012 * (big ? 4 : 1) + nsp * ((double)N * K * 4.0) / 2.5e6 : wgs * 0.05 * (big ? 4 : 1);
     if (cost < best_cost) { best_cost = cost; best = sp; }
   }
@@ -1476,6 +1681,8 @@ static void wgrad_attrs() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
 }
 
 static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
@@ -1491,13 +1698,14 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   p.slab_stride = slab_stride;
   if (slab_stride > 0) {
     AOD_CHECK_ARG(splits <= max_slabs, "wgrad: %d slabs needed, %d provided (aod_conv2d_wgrad_splits)", splits, max_slabs);
-    AOD_CHECK_ARG(slab_stride >= (long long)p.N * p.K, "wgrad: slab stride smaller than N*K");
+    AOD_CHECK_ARG(slab_stride >= (long long)p.N * p.K / (p.x3 ? 4 : 1), "wgrad: slab stride smaller than N*K (x3: the logical N/2 * K/2)");
   }
   wgrad_attrs();
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
   if (p.x3) {
     AOD_CHECK_ARG(slab_stride > 0, "wgrad (x3): slab form only");
-    if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2, true>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+    if (big == 2) hipLaunchKernelGGL(conv_wgrad_x3w_kernel, dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+    else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2, true>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, true>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   } else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
   else if (!(dbg_w8 && dbg_w8[0] == '0')) hipLaunchKernelGGL((conv_wgrad_kernel<8, 1, 1>), dim3(tiles * splits), dim3(512), 65536 + 4096, (hipStream_t)stream, p);
@@ -1602,7 +1810,7 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
   for (int g = 0; g < n; ++g) {
     WgradParams& p = gp.g[g];
     AOD_CHECK_ARG(sp[g] <= nslabs[g], "wgrad_grouped: member %d needs %d slabs, %d provided", g, sp[g], nslabs[g]);
-    AOD_CHECK_ARG(slab_stride[g] >= (long long)p.N * p.K, "wgrad_grouped: slab stride smaller than N*K");
+    AOD_CHECK_ARG(slab_stride[g] >= (long long)p.N * p.K / (p.x3 ? 4 : 1), "wgrad_grouped: slab stride smaller than N*K (x3: N/2 * K/2)");
     p.tiles_n = tn[g]; p.tiles_k = tk[g]; p.splits = sp[g]; p.rows_per_split = rps[g]; p.slab_stride = slab_stride[g];
     gp.wg0[g] = wg;
     wg += tn[g] * tk[g] * sp[g];
@@ -1610,7 +1818,8 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
   for (int g = n; g <= WG_MAXG; ++g) gp.wg0[g] = g == n ? wg : 0x7fffffff;
   gp.n = n;
   wgrad_attrs();
-  if (x3 && big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2, true>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  if (x3 && big == 2) hipLaunchKernelGGL(conv_wgrad_grouped_x3w_kernel, dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  else if (x3 && big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2, true>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
   else if (x3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<4, 1, 1, true>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
   else if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
   else hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 1, 1>), dim3(wg), dim3(512), 65536 + 4096, (hipStream_t)stream, gp);
@@ -1697,7 +1906,7 @@ struct UnpackArgs {
   const float* dw; float* g; const float* scale; const float* w; float* wdot; const float* bn_s1; const float* bn_mean; const float* bn_invstd;
   long long slab_stride;
   int nslabs, O, I, RS, Ipad, accumulate;
-  int x3;      // slabs of an X3 wgrad launch: rows / columns in the X-layout; dW[o][c] = hh + hl + lh bands (the ll band was never computed)
+  int x3;      // (unused: x3 wgrad launches write LOGICAL slabs -- the three bands of an entry are added in the wgrad epilogue)
 };
 __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* tile, float* red) {
   const float* __restrict__ dw = a.dw;
@@ -1712,18 +1921,7 @@ __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* t
     for (int i = threadIdx.x; i < nc * RS; i += UNP_T) {
       const int rs = i / nc, c = i - rs * nc;                       // consecutive lanes on consecutive channels of one slab row
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                 // fixed association: ((s0+s4+..)+(s1+s5+..))+((s2+..)+(s3+..))
-      if (a.x3) {
-        // X-layout slabs: row of the heads of output channel oo, 32 rows further its tails; column of the heads of input channel cc, 32
-        // columns further its tails.  Per slab (zh.xh + zh.xl) + zl.xh, slabs in order: deterministic like the plain form.
-        const int cc = c0 + c;
-        const float* sh = dw + ((long long)(((oo >> 5) << 6) + (oo & 31)) * RS + rs) * Ipad + ((cc >> 5) << 6) + (cc & 31);
-        const float* sl_ = sh + (long long)32 * RS * Ipad;
-        for (int sl = 0; sl < nslabs; ++sl) {
-          const long long o = (long long)sl * slab_stride;
-          const float b = (sh[o] + sh[o + 32]) + sl_[o];
-          if ((sl & 3) == 0) v0 += b; else if ((sl & 3) == 1) v1 += b; else if ((sl & 3) == 2) v2 += b; else v3 += b;
-        }
-      } else {
+      {
       const float* src = dw + ((long long)oo * RS + rs) * Ipad + c0 + c;
       int sl = 0;
       for (; sl + 4 <= nslabs; sl += 4) {

@@ -82,16 +82,19 @@ class DevicePhiloxPool(Dataset):
         return dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3), scale_factor=np.ones(4, np.float32), flip=False,
                     flip_direction=None, filename=f'philox_{idx}', ori_filename=f'philox_{idx}', image_id=idx)
 
-    def device_batch(self, idxs, device, image_ids=None):
-        """-> dict(img=[tensor [B,3,H,W] on device], img_metas=[list of dicts]).  The image tensor is a per-batch-size static buffer (it is
-        copied into the scoring graph's input buffer by the caller), filled by one kernel launch."""
+    def device_batch(self, idxs, device, image_ids=None, out=None):
+        """-> dict(img=[tensor [B,3,H,W] on device], img_metas=[list of dicts]).  The image tensor is `out` when given (the scoring graph's
+        input buffer, graphs.GraphedScore.static_image: nothing is copied afterwards), else a per-batch-size static buffer; one kernel launch."""
         from . import _C
         H, W = self.size
         B = len(idxs)
-        key = (B, str(device))
-        if key not in self._buf:
-            self._buf[key] = torch.empty(B, 3, H, W, device=device)
-        img = self._buf[key]
+        if out is not None and tuple(out.shape) == (B, 3, H, W) and out.dtype == torch.float32 and out.is_contiguous():
+            img = out
+        else:
+            key = (B, str(device))
+            if key not in self._buf:
+                self._buf[key] = torch.empty(B, 3, H, W, device=device)
+            img = self._buf[key]
         ids = image_ids if image_ids is not None else torch.tensor(list(idxs), dtype=torch.int64).to(device, non_blocking=True)
         _C.call('aod_synth_normal_images', _C.ptr(img), B, 3 * H * W, self.seed, _C.ptr(ids), _C.stream())
         return dict(img=[img], img_metas=[[self._meta(int(i)) for i in idxs]])

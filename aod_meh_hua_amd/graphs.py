@@ -93,7 +93,8 @@ class GraphedTrainStep:
 
     def _load(self, d):
         st = self.cur['static']
-        st['img'].copy_(d['img'], non_blocking=True)
+        if d['img'].data_ptr() != st['img'].data_ptr():        # (a loader that filled static_image() directly has nothing to copy: 50 MB at 16 x 512^2)
+            st['img'].copy_(d['img'], non_blocking=True)
         B, G = st['gts'].shape[:2]
         # fresh pinned staging every call: the copies below are asynchronous, and torch's caching host allocator only recycles a pinned
         # block once the copy that read it has completed (re-using one fixed buffer races with the next call's host writes)
@@ -371,6 +372,12 @@ class GraphedScore:
         with torch.no_grad(), scoring.static_meta(ent['hw'], ent['sc']):
             ent['out'] = self.module(img=[ent['img']], img_metas=[ent['metas']], return_loss=False, image_ids=ent['ids'], **self.kw)
 
+    def static_image(self, shape):
+        """The captured graph's own input buffer for image batches of `shape` (None while no graph of that shape exists): a producer that
+        writes the batch there -- the on-device pool generator, a loader's H2D copy -- saves the device-to-device copy into it."""
+        ent = self.cache.get(tuple(shape))
+        return ent['img'] if ent is not None else None
+
     def maybe(self, img, img_metas, image_ids):
         """Replay if this batch shape is captured, capture if it repeats the previous batch's shape, else None (caller scores eagerly)."""
         shape = tuple(img.shape)
@@ -383,7 +390,8 @@ class GraphedScore:
         from . import scoring
         # (value-keyed device copies of the sizes / scale factors: a pool re-uses a handful of them; device-to-device into the static buffers)
         hw, sc = scoring._meta_tensors([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas], self.dev)
-        ent['img'].copy_(img, non_blocking=True)
+        if img.data_ptr() != ent['img'].data_ptr():            # (see static_image)
+            ent['img'].copy_(img, non_blocking=True)
         ent['ids'].copy_(image_ids, non_blocking=True)
         ent['hw'].copy_(hw, non_blocking=True), ent['sc'].copy_(sc, non_blocking=True)
 

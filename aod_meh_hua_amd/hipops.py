@@ -323,7 +323,9 @@ def wgrad_unpack_group(jobs):
         return
     n = len(jobs)
     dev = jobs[0].dz.device
-    strides = [j.dz.shape[1] * j.R * j.S * j.x_rows.shape[1] for j in jobs]
+    # (x3: the launch writes LOGICAL slabs [N / 2][R][S][C / 2] -- the three head / tail bands of an entry are added in its epilogue)
+    lg = 2 if X3 else 1
+    strides = [(j.dz.shape[1] // lg) * j.R * j.S * (j.x_rows.shape[1] // lg) for j in jobs]
     offs, tot = [], 0
     for sp, st in zip(splits, strides):
         offs.append(tot)
@@ -345,8 +347,8 @@ def wgrad_unpack_group(jobs):
     prof_flops('wgrad', (ms[0], sum(j.dz.shape[1] for j in jobs), sum(j.R * j.S * j.x_rows.shape[1] for j in jobs), 10 + n, 1), flops, launch)
     ws = [j.w.contiguous() if (j.wdot is not None and j.w is not None) else None for j in jobs]
     call('aod_unpack_wgrad_slabs_grouped', n, pv(slabs), I32A(*splits), I64A(*strides), pv([j.gw for j in jobs]), I32A(*[j.O for j in jobs]),
-         I32A(*[j.I for j in jobs]), I32A(*[j.R for j in jobs]), I32A(*[j.S for j in jobs]), I32A(*[j.x_rows.shape[1] for j in jobs]),
-         I32A(*[2 if X3 else 0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
+         I32A(*[j.I for j in jobs]), I32A(*[j.R for j in jobs]), I32A(*[j.S for j in jobs]), I32A(*[j.x_rows.shape[1] // lg for j in jobs]),
+         I32A(*[0] * n), pv([j.scale for j in jobs]), pv(ws), pv([j.wdot for j in jobs]), pv([j.bn[0] if j.bn else None for j in jobs]),
          pv([j.bn[1] if j.bn else None for j in jobs]), pv([j.bn[2] if j.bn else None for j in jobs]), stream())
     SCOPE = prev_scope
 
@@ -364,8 +366,9 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
         dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     tab = _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, x_rows.device)
     if nslabs:
-        stride_ = Npad * R * S * Cin
-        slabs = _slab_scratch(nslabs * stride_, x_rows.device).view(nslabs, Npad, R, S, Cin)
+        lg = 2 if X3 else 1                   # (x3: logical slabs, see wgrad_unpack_group)
+        stride_ = (Npad // lg) * R * S * (Cin // lg)
+        slabs = _slab_scratch(nslabs * stride_, x_rows.device).view(nslabs, Npad // lg, R, S, Cin // lg)
         _prof('wgrad', d, lambda: call('aod_conv2d_wgrad_slabs', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(slabs), nslabs, stride_, ptr(tab), stream()), alg)
         return slabs
     _prof('wgrad', d, lambda: call('aod_conv2d_wgrad', C.byref(d), ptr(x_rows), ptr(dz_rows), ptr(dw), ptr(tab), stream()), alg)
@@ -427,7 +430,7 @@ def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, sc
             grad_oihw = torch.empty(O, I, R, S, dtype=torch.float32, device=dw_orsi.device)
         if wdot is None:
             wdot = torch.empty(O, dtype=torch.float32, device=dw_orsi.device) if want_wdot else None
-        call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(bool(accumulate)) | (2 if X3 else 0), ptr(scale),
+        call('aod_unpack_wgrad_slabs', ptr(dw_orsi), nslabs, Opad * R * S * Ipad, ptr(grad_oihw), O, I, R, S, Ipad, int(bool(accumulate)), ptr(scale),
              ptr(w_oihw.contiguous()) if want_wdot else None, ptr(wdot), ptr(bn[0]) if bn else None, ptr(bn[1]) if bn else None,
              ptr(bn[2]) if bn else None, stream())
         return (grad_oihw, wdot) if want_wdot else grad_oihw

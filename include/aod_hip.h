@@ -192,8 +192,9 @@ int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int 
                      const float* bn_invstd, aod_stream_t stream);
 
 /* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 9 taps.
- * `accumulate`: bit 0 = add into grad_oihw; bit 1 = the slabs come from an x3 launch (aod_conv_desc_t.x3): rows and columns are in the
- * X-layout (Ipad = the physical width 2*ceil32(I)) and dW[o][c] = sum over slabs of the (head, head) + (head, tail) + (tail, head) bands. */
+ * The slabs of an x3 launch (aod_conv_desc_t.x3) are LOGICAL -- [N/2][R][S][C/2] for the physical widths N, C of the descriptor, slab_stride
+ * >= N*R*S*C/4: the (head, head) + (head, tail) + (tail, head) bands of an entry are added in the wgrad epilogue -- and unpack like any
+ * other: Opad = N/2, Ipad = C/2. */
 int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t slab_stride, float* grad_oihw, int O, int I, int R, int S, int Ipad,
                            int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
                            const float* bn_mean, const float* bn_invstd, aod_stream_t stream);

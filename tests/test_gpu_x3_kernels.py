@@ -57,6 +57,9 @@ def test_split_merge_round_trip_keeps_16_bits():
     dict(B=2, C=2048, O=256, H=8, W=8, R=3, stride=2, pad=1, relu=False, bn=False, res=False),    # P6 shape: split-K
     dict(B=2, C=256, O=180, H=16, W=16, R=3, stride=1, pad=1, relu=False, bn=False, res=False, out_f32=True),     # prediction conv
     dict(B=2, C=256, O=9, H=16, W=16, R=3, stride=1, pad=1, relu=True, bn=False, res=False, out_f32=True),
+    # tower shape, 51 842 pixels (not a multiple of the 32-pixel step): the 256 x 256 conv tile and the WIDE wgrad form (one accumulator per entry)
+    dict(B=2, C=256, O=256, H=161, W=161, R=3, stride=1, pad=1, relu=True, bn=False, res=False),
+    dict(B=1, C=512, O=256, H=224, W=224, R=1, stride=1, pad=0, relu=False, bn=True, res=False),     # wide wgrad of a 1x1 layer with BN
 ])
 def test_x3_conv_forward_dgrad_wgrad_against_fp32(case):
     from aod_meh_hua_amd import functional as AF

@@ -31,10 +31,26 @@ def step():
     outL = model.train_step_L(prev, head_out, feat_out, Labeled=True, Pseudo=False)
     opt_L.zero_grad(); outL['loss'].backward()
     opt.step(); opt_L.step()
-for _ in range(2): step()
+from aod_meh_hua_amd import functional as AF
+AF.set_precision(os.environ.get('PREC', 'bf16'))
+import copy
+pm = copy.deepcopy(model); B.calibrate_head(pm, data['img'])
+def score():
+    pm.eval()
+    with torch.no_grad():
+        pm(img=[data['img']], img_metas=[data['img_metas']], image_ids=torch.arange(16, device=dev), **B.SCORE_KW)
+for _ in range(2): step(); score()
 torch.cuda.synchronize()
 with Log():
     step()
 torch.cuda.synchronize()
+print('---- train step'); 
+for (name, site), n in sorted(counts.items(), key=lambda kv: -kv[1]):
+    print(f'{n:3d} {name:32s} {site}')
+counts.clear()
+with Log():
+    score()
+torch.cuda.synchronize()
+print('---- scoring pass')
 for (name, site), n in sorted(counts.items(), key=lambda kv: -kv[1]):
     print(f'{n:3d} {name:32s} {site}')

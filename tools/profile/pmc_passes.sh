@@ -10,32 +10,38 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 D=$R/gpurun_out/pmc_passes
 mkdir -p $D $R/gpurun_out/profiles
 SHA=$(cd $R && python3 -c "from aod_meh_hua_amd.build import source_digest; print(source_digest())")
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -d $D/traffic -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph > $D/bench_traffic.json 2>$D/err_traffic.txt
+# (one traffic pass per precision mode: pmc_traffic.json = the bench's default, reference-precision mode; pmc_traffic_bf16.json = the fast mode)
+for PREC in bf16x3 bf16; do
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -d $D/traffic_$PREC -o out --output-format csv -- python3 $R/bench.py --precision $PREC --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph --phase-iters 2 > $D/bench_traffic_$PREC.json 2>$D/err_traffic_$PREC.txt
+done
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace -d $D/hua$i -o out --output-format csv -- python3 $R/bench.py --mode score --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph > $D/bench_hua$i.json 2>$D/err_hua$i.txt
+  rocprofv3 --pmc $grp --kernel-trace -d $D/hua$i -o out --output-format csv -- python3 $R/bench.py --mode score --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph --phase-iters 2 > $D/bench_hua$i.json 2>$D/err_hua$i.txt
 done
 python3 - <<PY
 import csv, glob, collections, json
 sha = '$SHA'
 # ---- HBM-side traffic per launch
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for f in glob.glob('$D/traffic/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:60]
-        agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
-out = {}
-for k, d in agg.items():
-    n = cnt[(k, 'TCC_EA0_RDREQ_sum')]
-    if not n: continue
-    rd, rd32, wr, wr64 = d['TCC_EA0_RDREQ_sum'], d['TCC_EA0_RDREQ_32B_sum'], d['TCC_EA0_WRREQ_sum'], d['TCC_EA0_WRREQ_64B_sum']
-    # guide: FETCH_SIZE = RDREQ x 64 B under-reports wide coalesced reads by 2x on gfx950 -> 128 B per non-32B request; writes: 64-B requests exact
-    out[k] = dict(launches=n, read_MB_per_launch=((rd - rd32) * 128 + rd32 * 32) / n / 1e6, write_MB_per_launch=(wr64 * 64 + (wr - wr64) * 32) / n / 1e6)
-json.dump(dict(kernels_sha16=sha, command='rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph',
-               kernels=out), open('$R/gpurun_out/profiles/pmc_traffic.json', 'w'), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -(kv[1]['read_MB_per_launch'] + kv[1]['write_MB_per_launch']) * kv[1]['launches'])[:16]:
-    print('%-60s n=%5d  read %8.2f MB  write %8.2f MB per launch' % (k, v['launches'], v['read_MB_per_launch'], v['write_MB_per_launch']))
+for prec, fname in (('bf16x3', 'pmc_traffic.json'), ('bf16', 'pmc_traffic_bf16.json')):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for f in glob.glob('$D/traffic_%s/**/*counter_collection.csv' % prec, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:72]
+            agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
+    out = {}
+    for k, d in agg.items():
+        n = cnt[(k, 'TCC_EA0_RDREQ_sum')]
+        if not n: continue
+        rd, rd32, wr, wr64 = d['TCC_EA0_RDREQ_sum'], d['TCC_EA0_RDREQ_32B_sum'], d['TCC_EA0_WRREQ_sum'], d['TCC_EA0_WRREQ_64B_sum']
+        # guide: FETCH_SIZE = RDREQ x 64 B under-reports wide coalesced reads by 2x on gfx950 -> 128 B per non-32B request; writes: 64-B requests exact
+        out[k] = dict(launches=n, read_MB_per_launch=((rd - rd32) * 128 + rd32 * 32) / n / 1e6, write_MB_per_launch=(wr64 * 64 + (wr - wr64) * 32) / n / 1e6)
+    json.dump(dict(kernels_sha16=sha, precision=prec,
+                   command='rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace -- python3 bench.py --precision %s --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph' % prec,
+                   kernels=out), open('$R/gpurun_out/profiles/' + fname, 'w'), indent=1)
+    print('----', prec)
+    for k, v in sorted(out.items(), key=lambda kv: -(kv[1]['read_MB_per_launch'] + kv[1]['write_MB_per_launch']) * kv[1]['launches'])[:16]:
+        print('%-72s n=%5d  read %8.2f MB  write %8.2f MB per launch' % (k, v['launches'], v['read_MB_per_launch'], v['write_MB_per_launch']))
 # ---- HUA sampler VALU utilisation
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); dur = collections.defaultdict(list)
 for f in glob.glob('$D/hua*/**/*counter_collection.csv', recursive=True):

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Every measured artefact the docs / the bench line cite, from ONE build on ONE GPU box:
-#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r04'
 # then copy gpurun_out/profiles/* into profiles/ and commit.  (rocprofv3: kernel trace + stats in one pass; --pmc passes separately.)
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -20,6 +20,8 @@ tail -1 $D/bench.json > $O/${TAG}_bench_line_under_rocprof.json
 python3 $R/tools/dbg/prof_summary.py $D/out_kernel_stats.csv > $O/${TAG}_per_step_summary.txt
 # 3. secondary configurations: configs[3] (10k on-device pool), configs[4] (R101 / 80 classes / 800x1344), two ranks on this one GPU (gloo)
 python3 $R/bench.py --mode pool --pool 10000 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_pool10k.json 2>/dev/null
+python3 $R/bench.py --precision bf16 --mode pool --pool 10000 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_pool10k_bf16.json 2>/dev/null
+python3 $R/bench.py --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-check --shapes $O/${TAG}_conv_shapes_one_step_bf16.txt > $O/${TAG}_bench_bf16.json 2>/dev/null
 python3 $R/bench.py --config r101coco --steps 6 --warmup 2 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_r101coco.json 2>/dev/null
 AOD_BENCH_ONE_GPU=1 python3 $R/bench.py --gpus 2 --steps 6 --warmup 2 --batch 8 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_2ranks_one_gpu.json 2>/dev/null
 # 4. PMC passes (tagged with the build digest; bench.py merges them only for this build)
