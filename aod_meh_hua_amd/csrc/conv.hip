@@ -1413,27 +1413,34 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, int bid_in) {
 // 32-pixel step -- eight 128-column sub-images: [zh32 | zl32] x 4 channel groups for each operand -- for 3 MFMAs per accumulator: twice the
 // matrix work per staged byte, four times per LDS fragment read.  8 waves as 2 x 4, 128 x 64 logical entries per wave (32 accumulators);
 // the head fragments of dZ are replaced by its tail fragments for the third product (the x fragments stay).
+// NW = 8, T = 4: 512 x 512 physical columns = 256 x 256 logical entries, one workgroup per CU.  NW = 4, T = 2: 256 x 256 physical = 128 x 128
+// logical (2 x 2 waves, 64 x 64 logical per wave, 16 accumulators; two workgroups per CU): the backbone layers whose dW is not whole
+// 512-column tiles or whose pixel axis is too short to fill the chip with the big form.
+template <int NW, int T>
 __device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in) {
-  constexpr int NW = 8, TN = 4, TK = 4, BKM = 32;
+  static_assert((NW == 8 && T == 4) || (NW == 4 && T == 2), "wide x3 wgrad forms");
+  constexpr int TN = T, TK = T, BKM = 32;
+  constexpr int RPW = 4 * NW, PASSES = BKM / RPW;      // pixel rows per pass of all waves
   constexpr int IMG = BKM * 256;              // one 128-column sub-image: 8 KB
   constexpr int STAGE = (TN + TK) * IMG;      // 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = uw >> 2, wn = uw & 3;
+  constexpr int WNC = NW / 2;                           // waves along the (tap, channel) axis
+  const int wm = uw / WNC, wn = uw % WNC;
   int bid = bid_in;
   const int ntile = p.tiles_n * p.tiles_k;
   const int split = bid / ntile; bid -= split * ntile;
   const int tile_k = bid % p.tiles_k, tile_n = bid / p.tiles_k;
-  const int n0 = tile_n * 512, k0 = tile_k * 512;       // physical columns
+  const int n0 = tile_n * (128 * T), k0 = tile_k * (128 * T);       // physical columns
   const int ms = split * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   if (ms >= me) return;
   const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)p.z_bytes, 0x00020000);
   const auto rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.tab, 0, (int)p.tab_bytes, 0x00020000);
-  const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group (one pass covers the 32 rows of a step)
-  const int ch = (lane & 15) ^ ((prow << 2) | (uw & 3));       // source chunk of this lane (fixed; tr_off's key of row 4 * uw + prow)
+  const int prow = lane >> 4;                                  // pixel row inside the wave's 4-row group
+  const int ch = (lane & 15) ^ ((prow << 2) | (uw & 3));       // source chunk of this lane (fixed; tr_off's key of row RPW * i + 4 * uw + prow)
   constexpr unsigned OOB_BASE = 0xf0000000u;
   unsigned zcol[TN];
   bool zok[TN];
@@ -1464,26 +1471,34 @@ __device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (__attribute__((address_space(3))) void*)(stab + slot * 1024), 16, off, 0, 0, 0);
     }
   };
-  RowRec rec;
-  auto rread = [&](int slot) { rec = *reinterpret_cast<const RowRec*>(stab + slot * 1024 + (4 * uw + prow) * 32); };
+  RowRec rec[PASSES];
+  auto rread = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) rec[i] = *reinterpret_cast<const RowRec*>(stab + slot * 1024 + (RPW * i + 4 * uw + prow) * 32);
+  };
   auto gload = [&](int mbase, int buf) {
     char* sz = smem + buf * STAGE;
     char* sx = sz + TN * IMG;
-    const int m = mbase + 4 * uw + prow;
-    const bool mok = m < me;
-    const RowRec r = rec;
 #pragma unroll
-    for (int h = 0; h < TN; ++h) {
-      const unsigned zoff = (mok && zok[h]) ? r.zoff + zcol[h] : OOB_BASE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + h * IMG + (4 * uw) * 256), 16, zoff, 0, 0, 0);
-    }
+    for (int i = 0; i < PASSES; ++i) {
+      const int m = mbase + RPW * i + 4 * uw + prow;
+      const bool mok = m < me;
+      const RowRec r = rec[i];
 #pragma unroll
-    for (int h = 0; h < TK; ++h) {
-      const unsigned xoff = (mok && (r.mask & tbit[h])) ? r.xrow + (unsigned)dy[h] * r.wc2 + cdx[h] : OOB_BASE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + h * IMG + (4 * uw) * 256), 16, xoff, 0, 0, 0);
+      for (int h = 0; h < TN; ++h) {
+        const unsigned zoff = (mok && zok[h]) ? r.zoff + zcol[h] : OOB_BASE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (__attribute__((address_space(3))) void*)(sz + h * IMG + (RPW * i + 4 * uw) * 256), 16, zoff, 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < TK; ++h) {
+        const unsigned xoff = (mok && (r.mask & tbit[h])) ? r.xrow + (unsigned)dy[h] * r.wc2 + cdx[h] : OOB_BASE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sx + h * IMG + (RPW * i + 4 * uw) * 256), 16, xoff, 0, 0, 0);
+      }
     }
   };
-  constexpr int NI = 8, NJ = 4;               // 16-entry groups per wave: 128 logical dZ channels x 64 logical (tap, channel) columns
+  // 16-entry groups per wave: NW = 8: 128 logical dZ channels x 64 logical (tap, channel) columns; NW = 4: 64 x 64
+  constexpr int NI = 32 * T / 16, NJ = 4;
+  constexpr int WML = 16 * NI, WNL = 16 * NJ;
   f32x4 acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -1523,10 +1538,10 @@ __device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in)
     const char* sx = sz + TN * IMG;
     // heads of dZ, heads and tails of x
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { const int nl = wm * 128 + i * 16; frag(alo[i], ahi[i], sz, ((nl >> 5) << 6) + (nl & 31)); }
+    for (int i = 0; i < NI; ++i) { const int nl = wm * WML + i * 16; frag(alo[i], ahi[i], sz, ((nl >> 5) << 6) + (nl & 31)); }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int kl = wn * 64 + j * 16, col = ((kl >> 5) << 6) + (kl & 31);
+      const int kl = wn * WNL + j * 16, col = ((kl >> 5) << 6) + (kl & 31);
       frag(bhlo[j], bhhi[j], sx, col);
       frag(bllo[j], blhi[j], sx, col + 32);
     }
@@ -1542,7 +1557,7 @@ __device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in)
     // tails of dZ requested now, consumed after the two head products
     u32x2_t tlo[NI], thi[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { const int nl = wm * 128 + i * 16; frag(tlo[i], thi[i], sz, ((nl >> 5) << 6) + (nl & 31) + 32); }
+    for (int i = 0; i < NI; ++i) { const int nl = wm * WML + i * 16; frag(tlo[i], thi[i], sz, ((nl >> 5) << 6) + (nl & 31) + 32); }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1569,13 +1584,14 @@ __device__ __forceinline__ void wgrad_tile_x3w(const WgradParams& p, int bid_in)
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = (n0 >> 1) + wm * 128 + i * 16 + lq * 4 + r;
-        const int k = (k0 >> 1) + wn * 64 + j * 16 + lr;
+        const int n = (n0 >> 1) + wm * WML + i * 16 + lq * 4 + r;
+        const int k = (k0 >> 1) + wn * WNL + j * 16 + lr;
         if (n < NL && k < KL) dwp[(long long)n * KL + k] = acc[i][j][r];
       }
 }
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_x3w_kernel(const WgradParams p) {
-  wgrad_tile_x3w(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
+template <int NW, int T>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_x3w_kernel(const WgradParams p) {
+  wgrad_tile_x3w<NW, T>(p, p.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x);
 }
 
 // split of the pixel axis over workgroups: all workgroups co-resident (<= 2 per CU, no ragged second round); cost model (measured on
@@ -1601,15 +1617,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(TN * TK
   else wgrad_tile<NW, TN, TK, X3>(gp.g[3], b - gp.wg0[3]);
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_grouped_x3w_kernel(const WgradGroups gp) {
+template <int NW, int T>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_grouped_x3w_kernel(const WgradGroups gp) {
   const int b = gp.g[0].xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
-  if (b < gp.wg0[1]) wgrad_tile_x3w(gp.g[0], b);
-  else if (b < gp.wg0[2]) wgrad_tile_x3w(gp.g[1], b - gp.wg0[1]);
-  else if (b < gp.wg0[3]) wgrad_tile_x3w(gp.g[2], b - gp.wg0[2]);
-  else wgrad_tile_x3w(gp.g[3], b - gp.wg0[3]);
+  if (b < gp.wg0[1]) wgrad_tile_x3w<NW, T>(gp.g[0], b);
+  else if (b < gp.wg0[2]) wgrad_tile_x3w<NW, T>(gp.g[1], b - gp.wg0[1]);
+  else if (b < gp.wg0[3]) wgrad_tile_x3w<NW, T>(gp.g[2], b - gp.wg0[2]);
+  else wgrad_tile_x3w<NW, T>(gp.g[3], b - gp.wg0[3]);
 }
 
-// `big`: tile form -- 0 = 128 x 128, 1 = 256 x 256, 2 = the WIDE x3 form (512 x 512 physical columns = 256 x 256 logical entries, wgrad_tile_x3w)
+// `big`: tile form -- 0 = 128 x 128, 1 = 256 x 256, 2 = the WIDE x3 form of 8 waves (512 x 512 physical columns = 256 x 256 logical entries,
+// wgrad_tile_x3w<8, 4>), 3 = the wide x3 form of 4 waves (256 x 256 physical = 128 x 128 logical, wgrad_tile_x3w<4, 2>)
 static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles_k, int& splits, int& rps, int& big, int big_min_m = 49152, int x3 = 0) {
   // the 256 x 256 tile (one workgroup per CU): deep layers whose dW is whole tiles of it and whose pixel axis gives every CU a long run
   static const char* dbg_big = getenv("AOD_WGRAD_256");
@@ -1618,21 +1636,24 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
   big = (N % 256 == 0 && K % 256 == 0 && M >= big_min_m) ? 1 : 0;
   if (dbg_big && dbg_big[0] == '0') big = 0;
   static const char* dbg_wide = getenv("AOD_WGRAD_X3_WIDE");       // (debug: 0 = never the wide x3 form)
-  if (x3 && N % 512 == 0 && K % 512 == 0 && M >= big_min_m && !(dbg_wide && dbg_wide[0] == '0') && !(dbg_big && dbg_big[0] == '0')) big = 2;
+  if (x3 && !(dbg_wide && dbg_wide[0] == '0')) {
+    if (N % 512 == 0 && K % 512 == 0 && M >= big_min_m && !(dbg_big && dbg_big[0] == '0')) big = 2;
+    else if (N % 256 == 0 && K % 256 == 0) big = 3;
+  }
   const int T = big == 2 ? 512 : (big ? 256 : 128);
   tiles_n = (N + T - 1) / T;
   tiles_k = (K + T - 1) / T;
   const int tiles = tiles_n * tiles_k;
   int best = 1;
   double best_cost = 1e30;
-  const int slots = big ? 256 : 512;
+  const int slots = (big == 1 || big == 2) ? 256 : 512;
   const int max_s = slots / tiles > 0 ? slots / tiles : 1;
   for (int sp = 1; sp <= max_s; ++sp) {
     const int rows = ((M + sp - 1) / sp + 63) / 64 * 64;
     const int nsp = (M + rows - 1) / rows;
     const int wgs = tiles * nsp;
-    double cost = (rows / 64) * (big == 2 ? 4.5 : (big ? 2.9 : (wgs > 256 ? 1.7 : 1.45)));
-    cost += slabs ? wgs * 0.012 * (big ? 4 : 1) + nsp * ((double)N * K * 4.0) / 2.5e6 : wgs * 0.05 * (big ? 4 : 1);
+    double cost = (rows / 64) * (big == 2 ? 4.5 : (big == 3 ? (wgs > 256 ? 2.6 : 2.2) : (big ? 2.9 : (wgs > 256 ? 1.7 : 1.45))));
+    cost += slabs ? wgs * 0.012 * (big ? 4 : 1) + nsp * ((double)N * K * (x3 ? 1.0 : 4.0)) / 2.5e6 : wgs * 0.05 * (big ? 4 : 1);
     if (cost < best_cost) { best_cost = cost; best = sp; }
   }
   rps = ((M + best - 1) / best + 63) / 64 * 64;
@@ -1681,8 +1702,10 @@ static void wgrad_attrs() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<4, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_kernel<8, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3w_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_x3w_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x3w_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_grouped_x3w_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096);
 }
 
 static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz, float* dw, long long slab_stride, int max_slabs,
@@ -1704,7 +1727,8 @@ static int wgrad_launch(const aod_conv_desc_t* d, const void* x, const void* dz,
   static const char* dbg_w8 = getenv("AOD_WGRAD_W8");      // (debug: 0 = the 4-wave form)
   if (p.x3) {
     AOD_CHECK_ARG(slab_stride > 0, "wgrad (x3): slab form only");
-    if (big == 2) hipLaunchKernelGGL(conv_wgrad_x3w_kernel, dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+    if (big == 2) hipLaunchKernelGGL((conv_wgrad_x3w_kernel<8, 4>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
+    else if (big == 3) hipLaunchKernelGGL((conv_wgrad_x3w_kernel<4, 2>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
     else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2, true>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, true>), dim3(tiles * splits), dim3(256), 65536 + 4096, (hipStream_t)stream, p);
   } else if (big) hipLaunchKernelGGL((conv_wgrad_kernel<8, 2, 2>), dim3(tiles * splits), dim3(512), 131072 + 4096, (hipStream_t)stream, p);
@@ -1732,7 +1756,7 @@ static int wgrad_plan_group(int n, const int* M, const int* N, const int* K, int
     if (steps[g] > max_steps) max_steps = steps[g];
   }
   static const char* dbg_slots = getenv("AOD_WGRAD_SLOTS");      // (debug: grid size the group plan aims at, small-tile form)
-  const int slots = big ? 256 : (dbg_slots ? atoi(dbg_slots) : 512);
+  const int slots = (big == 1 || big == 2) ? 256 : (dbg_slots ? atoi(dbg_slots) : 512);
   int T = 1;
   bool fits = false;
   for (; T <= max_steps; ++T) {
@@ -1818,7 +1842,8 @@ extern "C" int aod_conv2d_wgrad_grouped(const aod_conv_desc_t* const* descs, int
   for (int g = n; g <= WG_MAXG; ++g) gp.wg0[g] = g == n ? wg : 0x7fffffff;
   gp.n = n;
   wgrad_attrs();
-  if (x3 && big == 2) hipLaunchKernelGGL(conv_wgrad_grouped_x3w_kernel, dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  if (x3 && big == 2) hipLaunchKernelGGL((conv_wgrad_grouped_x3w_kernel<8, 4>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
+  else if (x3 && big == 3) hipLaunchKernelGGL((conv_wgrad_grouped_x3w_kernel<4, 2>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
   else if (x3 && big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2, true>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
   else if (x3) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<4, 1, 1, true>), dim3(wg), dim3(256), 65536 + 4096, (hipStream_t)stream, gp);
   else if (big) hipLaunchKernelGGL((conv_wgrad_grouped_kernel<8, 2, 2>), dim3(wg), dim3(512), 131072 + 4096, (hipStream_t)stream, gp);
