@@ -135,7 +135,7 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
                 data['img'] = _pin(data['img'])
         out = None
         if gscore is not None and isinstance(data['img'], (list, tuple)) and len(data['img']) == 1:
-            out = gscore.maybe(data['img'][0], data['img_metas'][0], image_ids)
+            out = gscore.maybe(data['img'][0], data['img_metas'][0], image_ids, defer=True)       # (scores are read after gscore.sync() below)
         if out is not None:
             result, unc = out
         else:
@@ -146,6 +146,8 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
             conf_chunks.append(torch.as_tensor(others[0], dtype=torch.float32, device=dev).reshape(-1))
         prog_bar.update(len(idxs))
     dev = next(model.parameters()).device
+    if gscore is not None:
+        gscore.sync()                       # deferred selection halves (second stream) -> this stream
     local = torch.cat(chunks) if chunks else torch.zeros(0, device=dev)
     if timed:           # load balance of this pass: every rank learns every rank's loop time and takes the same decision for the next pass
         import torch.distributed as dist

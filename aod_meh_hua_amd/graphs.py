@@ -347,11 +347,20 @@ class GraphedTrainStep:
 
 class GraphedScore:
     """One HUA scoring batch: model(img=[img], img_metas=[metas], image_ids=ids, **kw) under no_grad -> unc [B] (a copy).  One captured
-    graph per batch tensor shape (LRU): the per-image sizes and scale factors the decode step needs are STATIC device buffers refreshed
-    per call (scoring.static_meta), so keep-ratio pool batches of one padded shape share a graph."""
+    graph set per batch tensor shape (LRU): the per-image sizes and scale factors the decode step needs are STATIC device buffers refreshed
+    per call (scoring.static_meta), so keep-ratio pool batches of one padded shape share a graph.
+
+    Two graphs, two streams (AOD_SCORE_PIPELINE=0: one graph).  A scoring batch is a conv half -- backbone, neck, towers, prediction convs:
+    thousands of workgroups per launch -- and a selection half -- softmax / top-k / decode / NMS / pairs / Dirichlet sampler / reduce: one
+    workgroup per image for most of its 0.5 ms, 240 of 256 CUs idle.  The halves are captured separately (detector.extract_feat +
+    head.test_heads | head.simple_test(_preds=...)) into TWO slots that alternate, so that the selection half of batch k runs on a second
+    stream beside the conv half of batch k + 1 (it reads slot k % 2's prediction tensors, batch k + 1 writes the other slot's).  The
+    overlap happens between calls with `defer=True` (the pool loop of apis/test.py, which collects the scores and calls sync() once at the
+    end); a plain call makes the caller's stream wait for its scores, which also orders the next call behind them."""
     MAX_GRAPHS = 16
 
-    def __init__(self, model, warmup=2, **score_kwargs):
+    def __init__(self, model, warmup=2, pipeline=None, **score_kwargs):
+        import os
         import weakref
         # the model is held WEAKLY: single_gpu_uncertainty caches this object on the model itself, and a strong reference back would be a
         # cycle that keeps a dead cycle's graph memory pool + static image buffers alive until the cyclic collector happens to run
@@ -359,6 +368,11 @@ class GraphedScore:
         self.kw, self.warmup = score_kwargs, warmup
         self.cache, self.pending = {}, None          # shape -> entry (insertion order = LRU); shape seen once
         self.dev = next(_unwrap(model).parameters()).device
+        m = _unwrap(model)
+        two_phase = (hasattr(m, 'extract_feat') and hasattr(getattr(m, 'bbox_head', None), 'test_heads') and not score_kwargs.get('isEval')
+                     and getattr(m.test_cfg, 'uncertainty_pool', None) in ('Entropy_NMS', 'Entropy_ALL'))
+        self.pipe = two_phase and (os.environ.get('AOD_SCORE_PIPELINE', '1') != '0' if pipeline is None else bool(pipeline))
+        self.s_conv = self.s_tail = None
 
     @property
     def module(self):
@@ -367,35 +381,88 @@ class GraphedScore:
             raise RuntimeError('GraphedScore outlived its model')
         return m
 
-    def _run(self, ent):
+    # ------------------------------------------------------------------ what the graphs contain
+    def _run(self, sl):
         from . import scoring
-        with torch.no_grad(), scoring.static_meta(ent['hw'], ent['sc']):
-            ent['out'] = self.module(img=[ent['img']], img_metas=[ent['metas']], return_loss=False, image_ids=ent['ids'], **self.kw)
+        with torch.no_grad(), scoring.static_meta(sl['hw'], sl['sc']):
+            sl['out'] = self.module(img=[sl['img']], img_metas=[sl['metas']], return_loss=False, image_ids=sl['ids'], **self.kw)
+
+    def _run_a(self, sl):
+        m = self.module
+        with torch.no_grad():
+            sl['preds'] = m.bbox_head.test_heads(m.extract_feat(sl['img']))
+
+    def _run_b(self, sl):
+        """the selection half as SSL_L_SingleStageDetector.simple_test / forward_test run it for isEval=False"""
+        from . import scoring
+        m = self.module
+        kw = dict(self.kw)
+        rescale = kw.pop('rescale', False)
+        for meta in sl['metas']:
+            meta['batch_input_shape'] = tuple(sl['img'].shape[-2:])
+        with torch.no_grad(), scoring.static_meta(sl['hw'], sl['sc']):
+            results_list, *unc = m.bbox_head.simple_test(None, sl['metas'], rescale=rescale, _preds=sl['preds'], image_ids=sl['ids'],
+                                                         _data=sl['img'], _meta=sl['metas'], **kw)
+        sl['out'] = (results_list, *unc)
 
     def static_image(self, shape):
-        """The captured graph's own input buffer for image batches of `shape` (None while no graph of that shape exists): a producer that
-        writes the batch there -- the on-device pool generator, a loader's H2D copy -- saves the device-to-device copy into it."""
+        """The input buffer the NEXT call with image batches of `shape` replays on (None while no graph of that shape exists): a producer that
+        writes the batch there -- the on-device pool generator, a loader's H2D copy -- saves the device-to-device copy into it.  The caller's
+        stream is made to wait until the slot's previous conv half has read it."""
         ent = self.cache.get(tuple(shape))
-        return ent['img'] if ent is not None else None
+        if ent is None:
+            return None
+        sl = ent['slots'][ent['n'] % len(ent['slots'])]
+        if sl.get('ev_a') is not None:
+            torch.cuda.current_stream().wait_event(sl['ev_a'])
+        return sl['img']
 
-    def maybe(self, img, img_metas, image_ids):
+    def maybe(self, img, img_metas, image_ids, defer=False):
         """Replay if this batch shape is captured, capture if it repeats the previous batch's shape, else None (caller scores eagerly)."""
         shape = tuple(img.shape)
         if shape not in self.cache and shape != self.pending:
             self.pending = shape
             return None
-        return self(img, img_metas, image_ids)
+        return self(img, img_metas, image_ids, defer=defer)
 
-    def _fill(self, ent, img, img_metas, image_ids):
+    def sync(self):
+        """the caller's stream waits for every deferred selection half (call before reading scores returned with defer=True)"""
+        if self.s_tail is not None:
+            torch.cuda.current_stream().wait_stream(self.s_tail)
+
+    def _fill_img(self, sl, img):
+        if img.data_ptr() != sl['img'].data_ptr():            # (see static_image)
+            sl['img'].copy_(img, non_blocking=True)
+
+    def _fill_meta(self, sl, img_metas, image_ids):
         from . import scoring
         # (value-keyed device copies of the sizes / scale factors: a pool re-uses a handful of them; device-to-device into the static buffers)
         hw, sc = scoring._meta_tensors([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas], self.dev)
-        if img.data_ptr() != ent['img'].data_ptr():            # (see static_image)
-            ent['img'].copy_(img, non_blocking=True)
-        ent['ids'].copy_(image_ids, non_blocking=True)
-        ent['hw'].copy_(hw, non_blocking=True), ent['sc'].copy_(sc, non_blocking=True)
+        sl['ids'].copy_(image_ids, non_blocking=True)
+        sl['hw'].copy_(hw, non_blocking=True), sl['sc'].copy_(sc, non_blocking=True)
 
-    def __call__(self, img, img_metas, image_ids):
+    def _capture(self, sl, fns):
+        """warm-up runs on a side stream, then one graph per function of `fns` (they share nothing but the slot's tensors)"""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                for f in fns:
+                    f(sl)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        for f in fns:
+            ho.reset_zero_arena()
+            AF.PREP.refresh_if_stale()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                f(sl)
+            graphs.append(g)
+        ho.reset_zero_arena()
+        return graphs
+
+    def __call__(self, img, img_metas, image_ids, defer=False):
         shape = tuple(img.shape)
         ent = self.cache.pop(shape, None)
         if ent is None:
@@ -404,28 +471,55 @@ class GraphedScore:
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
+            if self.s_tail is not None:                          # (a capture synchronises the device anyway)
+                torch.cuda.current_stream().wait_stream(self.s_tail)
             B = img.shape[0]
-            ent = dict(img=torch.empty(shape, dtype=torch.float32, device=self.dev), ids=torch.zeros(B, dtype=torch.int64, device=self.dev),
-                       hw=torch.zeros(B, 2, device=self.dev), sc=torch.ones(B, 4, device=self.dev), metas=[dict(m) for m in img_metas])
-            self._fill(ent, img, img_metas, image_ids)
             self.module.eval()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(self.warmup):
-                    self._run(ent)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            ho.reset_zero_arena()
-            AF.PREP.refresh_if_stale()
-            ent['graph'] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent['graph'], capture_error_mode='thread_local'):
-                self._run(ent)
-            ho.reset_zero_arena()
-            ent['keep'] = _pin_caches()
+            slots = []
+            for _ in range(2 if self.pipe else 1):
+                sl = dict(img=torch.empty(shape, dtype=torch.float32, device=self.dev), ids=torch.zeros(B, dtype=torch.int64, device=self.dev),
+                          hw=torch.zeros(B, 2, device=self.dev), sc=torch.ones(B, 4, device=self.dev), metas=[dict(m) for m in img_metas],
+                          ev_a=None, ev_b=None)
+                self._fill_img(sl, img)
+                self._fill_meta(sl, img_metas, image_ids)
+                if self.pipe:
+                    sl['ga'], sl['gb'] = self._capture(sl, [self._run_a, self._run_b])
+                else:
+                    sl['g'], = self._capture(sl, [self._run])
+                slots.append(sl)
+            ent = dict(slots=slots, n=0, keep=_pin_caches())
         self.cache[shape] = ent
-        self._fill(ent, img, img_metas, image_ids)
+        sl = ent['slots'][ent['n'] % len(ent['slots'])]
+        ent['n'] += 1
         AF.PREP.refresh_if_stale()        # e.g. a training replay or a checkpoint load since the last scoring batch
-        ent['graph'].replay()
-        unc = ent['out'][1]
-        return ent['out'][0], (unc.clone() if torch.is_tensor(unc) else unc)
+        if not self.pipe:
+            self._fill_img(sl, img)
+            self._fill_meta(sl, img_metas, image_ids)
+            sl['g'].replay()
+            unc = sl['out'][1]
+            return sl['out'][0], (unc.clone() if torch.is_tensor(unc) else unc)
+        if self.s_conv is None:
+            self.s_conv, self.s_tail = torch.cuda.Stream(), torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self.s_conv.wait_stream(cur)                 # the batch (and, for a non-deferred predecessor, its scores) are produced on the caller's stream
+        with torch.cuda.stream(self.s_conv):
+            if sl['ev_b'] is not None:
+                self.s_conv.wait_event(sl['ev_b'])   # this slot's previous selection half has read the prediction tensors
+            self._fill_img(sl, img)
+            sl['ga'].replay()
+            sl['ev_a'] = torch.cuda.Event()
+            sl['ev_a'].record(self.s_conv)
+        self.s_tail.wait_stream(cur)                 # (the image ids)
+        with torch.cuda.stream(self.s_tail):
+            self.s_tail.wait_event(sl['ev_a'])
+            self._fill_meta(sl, img_metas, image_ids)
+            sl['gb'].replay()
+            unc = sl['out'][1]
+            unc = unc.clone() if torch.is_tensor(unc) else unc
+            sl['ev_b'] = torch.cuda.Event()
+            sl['ev_b'].record(self.s_tail)
+        if torch.is_tensor(unc):
+            unc.record_stream(cur)
+        if not defer:
+            cur.wait_stream(self.s_tail)
+        return sl['out'][0], unc

@@ -145,16 +145,20 @@ class Lambda_L2Net(L_AnchorHead):
         outs = (self.retina_cls(c, out_f32=True), self.retina_reg(r, out_f32=True))
         return outs, self.retina_L(l, relu=True, out_f32=True)
 
-    def simple_test(self, feats, img_metas, rescale=False, **kwargs):
-        """Lambda_L2.py:398-420."""
+    def test_heads(self, feats):
+        """the conv half of simple_test (Lambda_L2.py:398-403): ((cls_scores, bbox_preds), L_scores) of a scoring batch"""
         import os
         x3_ok = AF.get_precision() == 'bf16' or all(m.conv.weight.shape[0] % 256 == 0 and m.conv.weight.shape[1] % 32 == 0 for m in self.cls_convs)
         if (not torch.is_grad_enabled() and x3_ok and os.environ.get('AOD_GROUP_TOWERS', '1') != '0'
                 and len(self.cls_convs) == len(self.reg_convs) == len(self.L_convs) > 0 and all(m.with_activation for m in self.cls_convs)):
-            outs, L_scores = self.forward_all_towers(feats)
-        else:
-            outs = self.forward(feats)
-            L_scores = self.forward_L(feats, head_out=None)
+            return self.forward_all_towers(feats)
+        outs = self.forward(feats)
+        return outs, self.forward_L(feats, head_out=None)
+
+    def simple_test(self, feats, img_metas, rescale=False, _preds=None, **kwargs):
+        """Lambda_L2.py:398-420.  `_preds` = the result of test_heads() computed earlier (graphs.GraphedScore runs the conv half and the
+        selection / HUA half as two graphs on two streams: the half below keeps at most 16 workgroups busy)."""
+        outs, L_scores = _preds if _preds is not None else self.test_heads(feats)
         if not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_NoNMS':
             results_list = self.get_bboxes(*outs, img_metas, rescale=rescale, with_nms=False, **kwargs)
         elif not kwargs['isEval'] and kwargs['uPool'] == 'Entropy_ALL':

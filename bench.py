@@ -315,15 +315,17 @@ def main():
         gscore = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'})
         state = dict(graph_ok=use_graph)
 
-        def step(it=0, do_train=do_train, do_score=do_score, graph=None):
-            """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python."""
+        def step(it=0, do_train=do_train, do_score=do_score, graph=None, defer=False):
+            """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python.
+            defer=True (score-only loops): like the pool loop of apis/test.py, the scores are not read before the loop's end, so the selection
+            half of batch k (second stream) runs beside the conv half of batch k + 1 (graphs.GraphedScore)."""
             graph = state['graph_ok'] if graph is None else graph
             if graph:
                 if do_train:
                     gstep(data)
                 if do_score:
                     ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                    _, unc = gscore(pool['img'], pool['img_metas'], ids)
+                    _, unc = gscore(pool['img'], pool['img_metas'], ids, defer=defer and world == 1)
                     if world > 1:
                         gather_scores(unc, B * world)
                 return
@@ -394,7 +396,8 @@ def main():
             barrier()
             t1 = time.perf_counter()
             for i in range(k):
-                step(warmup + steps + i, tr_, sc_)
+                step(warmup + steps + i, tr_, sc_, defer=sc_ and not tr_)
+            gscore.sync()
             barrier()
             d = time.perf_counter() - t1
             phase[name + '_img_per_s'] = round(B * world * k / d, 1)
