@@ -108,6 +108,11 @@ _SIGS = {
     'aod_x3_upsample2x_add_bwd_set': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),
     'aod_x3_act_bwd': (C.c_int, [P, P, P, P, I64, I32, I32, P]),
     'aod_x3_pad_cast_colsum': (C.c_int, [P, P, P, P, I64, I32, P]),
+    'aod_x3_nchw_f32_to_nhwc': (C.c_int, [P, P, I32, I32, I32, I32, P]),
+    'aod_x3_maxpool_fwd': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    'aod_x3_maxpool_bwd': (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P]),
+    'aod_x3_l2norm_fwd': (C.c_int, [P, P, P, I64, I32, F32, P]),
+    'aod_x3_l2norm_bwd': (C.c_int, [P, P, P, P, P, I64, I32, F32, P]),
     'aod_sgd_multi': (C.c_int, [P, P, P, P, I32, F32, P, F32, F32, I32, F32, P]),
 }
 for _n, (_r, _a) in _SIGS.items():

@@ -313,3 +313,171 @@ extern "C" int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32,
   AOD_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- SSD300-VGG16 in the reference-precision mode (BASELINE config 0)
+// NCHW fp32 image -> X rows: C <= 32 logical channels as ONE band [h(C) 0.. | l(C) 0..] of 64 columns (the 3x3 first conv of VGG reads it)
+__global__ void x3_nchw_to_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int C, int HW) {
+  const long long n = (long long)B * HW * 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3); const long long pix = i >> 2;
+    const long long b = pix / HW, px = pix - b * HW;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = q * 8 + j; v[j] = c < C ? src[(b * C + c) * HW + px] : 0.f; }
+    xstore(dst + pix * 64 + q * 8, v);
+  }
+}
+extern "C" int aod_x3_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(src && dst && C >= 1 && C <= 32, "x3_nchw_to_nhwc: at most 32 channels (got %d)", C);
+  hipLaunchKernelGGL(x3_nchw_to_nhwc_kernel, dim3(grid_for((long long)B * H * W * 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, C, H * W);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// generic max-pool (k x k, stride s, pad p; torch semantics incl. ceil_mode output sizes computed by the caller) on X rows
+__global__ void x3_maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int Q, int OH, int OW, int k, int s, int p) {
+  const long long n = (long long)B * OH * OW * Q;
+  const int CP = (Q >> 2) * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int q = i % Q; long long r = i / Q;
+    const int ox = r % OW; r /= OW;
+    const int oy = r % OH; const int b = r / OH;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int dy = 0; dy < k; ++dy) {
+      const int yy = oy * s - p + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int xx = ox * s - p + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        float v[8];
+        xload(x + (((long long)b * H + yy) * W + xx) * CP + xoct(q), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+      }
+    }
+    xstore(y + (i / Q) * CP + xoct(q), m);
+  }
+}
+// backward as a gather: input pixel (yy, xx) receives g[oy, ox] from every window whose FIRST maximum (scan order) it is
+__global__ void x3_maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g, bf16_t* __restrict__ gx, int B, int H, int W, int Q,
+                                      int OH, int OW, int k, int s, int p) {
+  const long long n = (long long)B * H * W * Q;
+  const int CP = (Q >> 2) * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int q = i % Q; long long r = i / Q;
+    const long long pix = r;
+    const int xx = r % W; r /= W;
+    const int yy = r % H; const int b = r / H;
+    float me[8], acc[8];
+    xload(x + pix * CP + xoct(q), me);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    int oy0 = yy + p - k + 1; oy0 = oy0 <= 0 ? 0 : (oy0 + s - 1) / s;
+    int ox0 = xx + p - k + 1; ox0 = ox0 <= 0 ? 0 : (ox0 + s - 1) / s;
+    const int oy1 = min((yy + p) / s, OH - 1), ox1 = min((xx + p) / s, OW - 1);
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        bool win[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) win[j] = true;
+        for (int dy = 0; dy < k; ++dy) {
+          const int y2 = oy * s - p + dy;
+          if ((unsigned)y2 >= (unsigned)H) continue;
+          for (int dx = 0; dx < k; ++dx) {
+            const int x2 = ox * s - p + dx;
+            if ((unsigned)x2 >= (unsigned)W || (y2 == yy && x2 == xx)) continue;
+            float v[8];
+            xload(x + (((long long)b * H + y2) * W + x2) * CP + xoct(q), v);
+            const bool before = (y2 < yy) || (y2 == yy && x2 < xx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (v[j] > me[j] || (before && v[j] == me[j])) win[j] = false;
+          }
+        }
+        float gv[8];
+        xload(g + (((long long)b * OH + oy) * OW + ox) * CP + xoct(q), gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (win[j]) acc[j] += gv[j];
+      }
+    xstore(gx + pix * CP + xoct(q), acc);
+  }
+}
+extern "C" int aod_x3_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int k, int s, int p, aod_stream_t stream) {
+  AOD_CHECK_ARG(x && y && C % 64 == 0 && k >= 1 && s >= 1, "x3_maxpool_fwd: bad args");
+  hipLaunchKernelGGL(x3_maxpool_fwd_kernel, dim3(grid_for((long long)B * OH * OW * (C / 16))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, B, H, W, C / 16, OH, OW, k, s, p);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_x3_maxpool_bwd(const void* x, const void* g, void* gx, int B, int H, int W, int C, int OH, int OW, int k, int s, int p,
+                                  aod_stream_t stream) {
+  AOD_CHECK_ARG(x && g && gx && C % 64 == 0, "x3_maxpool_bwd: bad args");
+  hipLaunchKernelGGL(x3_maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 16))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (const bf16_t*)g, (bf16_t*)gx, B, H, W, C / 16, OH, OW, k, s, p);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// L2Norm (ssd_neck.py:105-128): y = w * x / (||x||_2 + eps) per pixel on X rows; one wavefront per pixel, octets strided over lanes
+__global__ __launch_bounds__(256) void x3_l2norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y, long long rows,
+                                                            int Q, float eps) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63, CP = (Q >> 2) * 64;
+  float ss = 0.f;
+  for (int q = lane; q < Q; q += 64) {
+    float v[8];
+    xload(x + r * CP + xoct(q), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+  }
+  ss = wave_sum(ss);
+  const float n = sqrtf(ss) + eps;
+  for (int q = lane; q < Q; q += 64) {
+    float v[8];
+    xload(x + r * CP + xoct(q), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[q * 8 + j] * v[j] / n;
+    xstore(y + r * CP + xoct(q), v);
+  }
+}
+__global__ __launch_bounds__(256) void x3_l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ g,
+                                                            bf16_t* __restrict__ gx, float* __restrict__ gw, long long rows, int Q, float eps) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63, CP = (Q >> 2) * 64;
+  float ss = 0.f, dot = 0.f;
+  for (int q = lane; q < Q; q += 64) {
+    float v[8], gg[8];
+    xload(x + r * CP + xoct(q), v); xload(g + r * CP + xoct(q), gg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ss += v[j] * v[j]; dot += w[q * 8 + j] * gg[j] * v[j]; }
+  }
+  ss = wave_sum(ss); dot = wave_sum(dot);
+  const float nrm = sqrtf(ss), n = nrm + eps;
+  const float kk = nrm > 0.f ? dot / (n * n * nrm) : 0.f;
+  for (int q = lane; q < Q; q += 64) {
+    float v[8], gg[8], o[8];
+    xload(x + r * CP + xoct(q), v); xload(g + r * CP + xoct(q), gg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = w[q * 8 + j] * gg[j] / n - kk * v[j]; atomicAdd(gw + q * 8 + j, gg[j] * v[j] / n); }
+    xstore(gx + r * CP + xoct(q), o);
+  }
+}
+extern "C" int aod_x3_l2norm_fwd(const void* x, const float* w, void* y, int64_t rows, int C, float eps, aod_stream_t stream) {
+  if (rows == 0) return 0;
+  AOD_CHECK_ARG(x && w && y && C % 64 == 0, "x3_l2norm_fwd: bad args (C = X-layout width; w has C / 2 entries)");
+  hipLaunchKernelGGL(x3_l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)y, (long long)rows, C / 16, eps);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_x3_l2norm_bwd(const void* x, const float* w, const void* g, void* gx, float* gw, int64_t rows, int C, float eps, aod_stream_t stream) {
+  if (rows == 0) return 0;
+  AOD_CHECK_ARG(x && w && g && gx && gw && C % 64 == 0, "x3_l2norm_bwd: bad args");
+  hipLaunchKernelGGL(x3_l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (const bf16_t*)g, (bf16_t*)gx,
+                     gw, (long long)rows, C / 16, eps);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}

@@ -885,9 +885,11 @@ def conv_towers_nograd(xss, convs, relu=True):
 # --------------------------------------------------------------------------- stem helpers
 def image_to_nhwc(img, cpad=8):
     """fp32 NCHW image batch -> bf16 NHWC rows viewed as [B, cpad, H, W] (no grad: images are leaves)."""
-    if ho.X3:
-        raise NotImplementedError('reference-precision mode: the stem takes the space-to-depth image (fp32 NCHW input with even sides)')
     B, C, H, W = img.shape
+    if ho.X3:          # one 32-channel band of X rows (SSD's VGG reads the image with a 3x3 conv; the ResNet stem takes the space-to-depth form)
+        rows = torch.empty(B * H * W, 64, dtype=torch.bfloat16, device=img.device)
+        ho.call('aod_x3_nchw_f32_to_nhwc', ho.ptr(img.detach().float().contiguous()), ho.ptr(rows), B, C, H, W, ho.stream())
+        return as_nchw(rows, B, H, W)
     rows, _ = ho.nchw_to_rows(img.detach().float(), cpad)
     return as_nchw(rows, B, H, W)
 

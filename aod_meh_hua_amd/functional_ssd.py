@@ -4,6 +4,7 @@ import math
 import torch
 from torch.autograd import Function
 
+from . import hipops as ho
 from ._C import call, ptr, stream
 from .functional import as_nchw, as_rows
 
@@ -23,7 +24,7 @@ class MaxPoolFn(Function):
         OH, OW = pool_out(H, k, s, p, ceil_mode), pool_out(W, k, s, p, ceil_mode)
         xr = as_rows(x)
         y = torch.empty(B * OH * OW, C, device=x.device, dtype=torch.bfloat16)
-        call('aod_maxpool_fwd', ptr(xr), ptr(y), B, H, W, C, OH, OW, k, s, p, stream())
+        call('aod_x3_maxpool_fwd' if ho.X3 else 'aod_maxpool_fwd', ptr(xr), ptr(y), B, H, W, C, OH, OW, k, s, p, stream())
         ctx.save_for_backward(xr)
         ctx.cfg = (B, C, H, W, OH, OW, k, s, p)
         return as_nchw(y, B, OH, OW)
@@ -33,7 +34,7 @@ class MaxPoolFn(Function):
         (xr,) = ctx.saved_tensors
         B, C, H, W, OH, OW, k, s, p = ctx.cfg
         gx = torch.empty_like(xr)
-        call('aod_maxpool_bwd', ptr(xr), ptr(as_rows(g)), ptr(gx), B, H, W, C, OH, OW, k, s, p, stream())
+        call('aod_x3_maxpool_bwd' if ho.X3 else 'aod_maxpool_bwd', ptr(xr), ptr(as_rows(g)), ptr(gx), B, H, W, C, OH, OW, k, s, p, stream())
         return as_nchw(gx, B, H, W), None, None, None, None
 
 
@@ -47,7 +48,7 @@ class L2NormFn(Function):
         B, C, H, W = x.shape
         xr = as_rows(x)
         y = torch.empty_like(xr)
-        call('aod_l2norm_fwd', ptr(xr), ptr(weight.detach().float().contiguous()), ptr(y), xr.shape[0], C, float(eps), stream())
+        call('aod_x3_l2norm_fwd' if ho.X3 else 'aod_l2norm_fwd', ptr(xr), ptr(weight.detach().float().contiguous()), ptr(y), xr.shape[0], C, float(eps), stream())
         ctx.save_for_backward(xr, weight)
         ctx.cfg = (B, C, H, W, eps)
         return as_nchw(y, B, H, W)
@@ -57,8 +58,8 @@ class L2NormFn(Function):
         xr, weight = ctx.saved_tensors
         B, C, H, W, eps = ctx.cfg
         gx = torch.empty_like(xr)
-        gw = torch.zeros(C, device=xr.device, dtype=torch.float32)
-        call('aod_l2norm_bwd', ptr(xr), ptr(weight.detach().float().contiguous()), ptr(as_rows(g)), ptr(gx), ptr(gw), xr.shape[0], C, float(eps), stream())
+        gw = torch.zeros(C // 2 if ho.X3 else C, device=xr.device, dtype=torch.float32)      # (x3: C is the X-layout width)
+        call('aod_x3_l2norm_bwd' if ho.X3 else 'aod_l2norm_bwd', ptr(xr), ptr(weight.detach().float().contiguous()), ptr(as_rows(g)), ptr(gx), ptr(gw), xr.shape[0], C, float(eps), stream())
         return as_nchw(gx, B, H, W), gw.to(weight.dtype), None
 
 

@@ -52,6 +52,10 @@ class SSDVGG(BaseModule):
                 p = layer.padding if isinstance(layer.padding, int) else layer.padding[0]
                 x = max_pool(x, k, s, p, layer.ceil_mode)
             if i in self.out_feature_indices:
-                outs.append(x)
+                if i + 1 < n:
+                    x, tap = AF.fork(x, 2)          # (the tapped map also feeds the next layer: see functional.fork)
+                    outs.append(tap)
+                else:
+                    outs.append(x)
             i += 1
         return outs[0] if len(outs) == 1 else tuple(outs)

@@ -65,8 +65,10 @@ class MyLSSDHead(L_AnchorHead):
 
     def forward(self, feats, **kwargs):
         """:169-174."""
-        cls_scores = [c[0](f, out_f32=True) for f, c in zip(feats, self.cls_convs)]
-        bbox_preds = [r[0](f, out_f32=True) for f, r in zip(feats, self.reg_convs)]
+        from ... import functional as AF
+        fa, fb = zip(*[AF.fork(f, 2) for f in feats])          # (every level feeds the cls and the reg conv)
+        cls_scores = [c[0](f, out_f32=True) for f, c in zip(fa, self.cls_convs)]
+        bbox_preds = [r[0](f, out_f32=True) for f, r in zip(fb, self.reg_convs)]
         return cls_scores, bbox_preds
 
     def forward_L(self, feats, head_out=None, **kwargs):

@@ -46,8 +46,14 @@ class SSDNeck(BaseModule):
         outs = [feat for feat in inputs]
         if hasattr(self, 'l2_norm'):
             outs[0] = self.l2_norm(outs[0])
-        feat = outs[-1]
-        for layer in self.extra_layers:
+        from ... import functional as AF
+        # (every level is an output of the neck AND the input of the next extra layer: functional.fork)
+        outs[-1], feat = AF.fork(outs[-1], 2) if len(self.extra_layers) else (outs[-1], None)
+        for li, layer in enumerate(self.extra_layers):
             feat = layer[1](layer[0](feat))
-            outs.append(feat)
+            if li + 1 < len(self.extra_layers):
+                o, feat = AF.fork(feat, 2)
+                outs.append(o)
+            else:
+                outs.append(feat)
         return tuple(outs)

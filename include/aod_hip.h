@@ -425,6 +425,14 @@ int aod_x3_act_bwd(const void* g, const void* a, void* dz, float* colsum, int64_
 /* aod_pad_cast_colsum: fp32 head gradients [M][N] (* [relu_out > 0]) -> X rows of 2*ceil32(N) columns + column sums fp32 [ceil32(N)] */
 int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, aod_stream_t stream);
 
+/* SSD300-VGG16 (BASELINE config 0) in the reference-precision mode: the image as ONE 32-channel band of X rows (64 columns; the first VGG
+ * conv reads it), and aod_maxpool_fwd/bwd, aod_l2norm_fwd/bwd on X rows (C = the X-layout width; L2Norm's w has C/2 entries). */
+int aod_x3_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);
+int aod_x3_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, int k, int s, int p, aod_stream_t stream);
+int aod_x3_maxpool_bwd(const void* x, const void* g, void* gx, int B, int H, int W, int C, int OH, int OW, int k, int s, int p, aod_stream_t stream);
+int aod_x3_l2norm_fwd(const void* x, const float* w, void* y, int64_t rows, int C, float eps, aod_stream_t stream);
+int aod_x3_l2norm_bwd(const void* x, const float* w, const void* g, void* gx, float* gw, int64_t rows, int C, float eps, aod_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -390,3 +390,44 @@ def test_ssd512_scoring_vs_reference_golden(built512):
     mu, sd = g['unc_runs'].mean(0), g['unc_runs'].std(0)
     u = torch.as_tensor(unc).float().cpu().numpy()
     assert (np.abs(u - mu) <= 4 * sd + 0.02 * mu).all(), (u, mu, sd)
+
+
+def test_ssd_train_step_in_the_reference_precision_mode_vs_reference_golden(built):
+    """BASELINE config 0 in the bf16x3 mode (X-layout activations through VGG16, the ceil-mode pools, L2Norm, the extra layers and the three
+    per-level head convs; csrc/x3_ops.hip): the REFERENCE's golden train step at fp32-level tolerances -- 100x tighter than the bf16 test above"""
+    from aod_meh_hua_amd import functional as AF
+    model, sd = built
+    model.load_state_dict(sd, strict=True)
+    g = np.load(os.path.join(G, 'ssd_train_step.npz'))
+    img = synth.images(8, 300, 300, seed=41).cuda()
+    gtb, gtl = synth.random_gts(8, 300, 300, seed=42, gmin=1, gmax=3)
+    data = dict(img=img, img_metas=synth.metas(8, 300, 300), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    AF.set_precision('bf16x3')
+    try:
+        out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+        lab = torch.cat(head_out[4], 1).cpu()
+        assert [int(((l >= 0) & (l < 20)).sum()) for l in lab] == list(g['n_pos'])
+        chans = [f.shape[1] // 2 for f in feat_out]
+        f32 = [AF.x3_to_f32(f, c) for f, c in zip(feat_out, chans)]
+        fam = [float(f.abs().mean()) for f in f32]
+        assert np.allclose(fam, g['feat_absmean'], rtol=1e-4), (fam, g['feat_absmean'])
+        assert rel(f32[3][:2].cpu().numpy(), g['feat_l3']) < 2e-4 and rel(f32[5].cpu().numpy(), g['feat_l5']) < 2e-4
+        assert rel(head_out[1][2][:2].detach().float().cpu().numpy(), g['cls_l2']) < 2e-4
+        lv = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
+        assert np.allclose(lv, g['log_vars'], rtol=1e-4), (lv, g['log_vars'])
+        assert np.allclose(float(out['loss']), g['loss'], rtol=1e-4)
+        model.zero_grad()
+        out['loss'].backward()
+        pd = dict(model.named_parameters())
+        gn = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names']])
+        assert np.allclose(gn, g['grad_norms'], rtol=3e-3), (gn / g['grad_norms'])
+        lossL = model.train_step_L(prev, head_out, feat_out)
+        model.zero_grad()
+        lossL['loss'].backward()
+        torch.cuda.synchronize()
+        assert np.allclose(float(lossL['loss']), g['loss_L'], rtol=2e-4)
+        gnL = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names_L']])
+        assert np.allclose(gnL, g['grad_norms_L'], rtol=3e-3), (gnL / g['grad_norms_L'])
+    finally:
+        AF.set_precision('bf16')
+        model.zero_grad()

@@ -245,3 +245,34 @@ def test_x3_grouped_tower_launches_equal_the_separate_ones():
     ref = [torch.relu(F.conv2d(torch.relu(F.conv2d(x, convs[0].weight, convs[0].bias, 1, 1)), convs[2].weight, convs[2].bias, 1, 1)) for x in x32]
     for r, o, (h, w) in zip(ref, o1[:3], shapes):
         assert _err(_f(AF.as_rows(o), B, h, w, C), r) < 1e-4
+
+
+def test_x3_ssd_row_kernels_against_fp32():
+    """generic max-pool forward / backward (ceil-mode 2x2 s2 and 3x3 s1 p1, first-maximum routing like torch) and L2Norm forward / backward on X rows"""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import functional_ssd as FS
+    g = torch.Generator(device='cuda').manual_seed(21)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    B, C, H, W = 2, 64, 19, 23
+    x = rnd(B, C, H, W)
+    for k, s, p, ceil in ((2, 2, 0, True), (3, 1, 1, False)):
+        xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+        y = FS.max_pool(xx, k, s, p, ceil)
+        xr = x.clone().requires_grad_()
+        ref = F.max_pool2d(xr, k, s, p, ceil_mode=ceil)
+        oh, ow = ref.shape[2:]
+        assert tuple(y.shape[2:]) == (oh, ow) and _err(_f(AF.as_rows(y), B, oh, ow, C), ref) < 2e-5
+        gy = rnd(B, C, oh, ow)
+        y.backward(AF.as_nchw(_x(gy), B, oh, ow))
+        ref.backward(gy)
+        assert _err(_f(AF.as_rows(xx.grad), B, H, W, C), xr.grad) < 2e-5
+    w = (torch.rand(C, device='cuda', generator=g) * 20).requires_grad_()
+    xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+    y = FS.l2norm(xx, w, 1e-10)
+    xr, wr = x.clone().requires_grad_(), w.detach().clone().requires_grad_()
+    ref = wr[None, :, None, None] * xr / (xr.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    assert _err(_f(AF.as_rows(y), B, H, W, C), ref) < 2e-5
+    gy = rnd(B, C, H, W)
+    y.backward(AF.as_nchw(_x(gy), B, H, W))
+    ref.backward(gy)
+    assert _err(_f(AF.as_rows(xx.grad), B, H, W, C), xr.grad) < 5e-5 and _err(w.grad, wr.grad) < 5e-5
