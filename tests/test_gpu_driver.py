@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('script,extra', [('tools/train_RetinaNet.py', ['--synthetic-size', '128', '--samples-per-gpu', '4']),
-                                          ('tools/train_SSD.py', [])])
+                                          ('tools/train_SSD.py', []),
+                                          # the same cycles in the reference-precision mode (X-layout activations end to end)
+                                          ('tools/train_RetinaNet.py', ['--synthetic-size', '128', '--samples-per-gpu', '4', '--precision', 'bf16x3']),
+                                          ('tools/train_SSD.py', ['--precision', 'bf16x3'])])
 def test_al_driver_two_cycles(script, extra, tmp_path):
     wd = f'pytest_{os.path.basename(script)[:-3]}_{os.getpid()}'
     cmd = [sys.executable, os.path.join(ROOT, script), '--synthetic', '48', '--cycles', '2', '--work-dir', wd] + extra

@@ -13,7 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_voc_batches_through_train_score_eval(voc):  # noqa: F811
+@pytest.fixture(params=['bf16', 'bf16x3'])
+def precision(request):
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision(request.param)
+    yield request.param
+    AF.set_precision('bf16')
+
+
+def test_voc_batches_through_train_score_eval(voc, precision):  # noqa: F811
     from aod_meh_hua_amd.apis.test import single_gpu_test, single_gpu_uncertainty
     from aod_meh_hua_amd.datasets import build_dataloader, build_dataset
     from aod_meh_hua_amd.mmcv_lite import Config, MMDataParallel
