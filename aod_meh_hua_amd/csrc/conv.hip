@@ -36,6 +36,7 @@ struct ConvKParams {
   ConvGroup grp[4];
   int stagger;        // 8-wave forms: waves 4-7 run half a K-step behind waves 0-3 (see the K loop)
   int x3;             // reference-precision mode (aod_conv_desc_t.x3): operands in the X-layout, three MFMAs per 32 channels (see X3 below)
+  int tap_inner;      // X3: K-steps run (channel chunk, tap) with the TAP innermost (see the loaders)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
@@ -257,11 +258,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   }
   const bool skipping = tapmask != ~0ull;
   int kt_ld = kt_begin;                          // K-step the loaders fetch next
+  // X3, TAPS INNERMOST.  In (tap, channel chunk) order a tile re-reads its pixel rows -- shifted by a pixel or a line -- once per tap,
+  // C / 64 K-steps apart: 8 steps x 32 KB x 32 workgroups per XCD is twice the 4 MB L2, so every tap's re-read went out to the fabric (PMC:
+  // 2 193 MB per grouped tower launch for 268 MB of activations, 8.2x).  In (channel chunk, tap) order the nine taps of a chunk follow each
+  // other: the re-use distance is one K-step and the shifted rows are L2 / L1 hits.  Every K-step then changes the tap, so the incremental
+  // offsets of the plain order do not apply: a row keeps its offset at tap (0, 0) and a validity bit per tap, a K-step adds the tap's
+  // (workgroup-uniform per segment) displacement.  All x3 instances take this order (stride-1 forward / dgrad and strided forward; the
+  // class-major stride-2 dgrad keeps the plain order with its tap skipping), so grouped and separate launches still agree bit for bit.
+  const int ntaps = p.R * p.S;
+  // (deep layers only: with C < 256 columns a tap is at most 3 K-steps long -- the re-reads are L2 hits already -- and the per-step offset
+  // arithmetic shows: the 16-tap stem ran 13 % slower in this order)
+  const bool tapin = X3 && p.tap_inner && !p.perm && !(p.transposed && p.stride != 1) && ntaps > 1 && ntaps <= 32 && p.C >= 256;
+  int tp_tap = X3 ? kt_begin % ntaps : 0, tp_cc = X3 ? kt_begin / ntaps : 0;
+  unsigned tbase[X3 ? A_IT : 1], tvm[X3 ? A_IT : 1], wb0[X3 ? B_IT : 1];
   int ksteps_in_tap = fast_tap ? kt_begin % steps_per_tap : 0;     // (a split-K slice may start inside a tap)
   bool new_tap = true;
 
   auto load_a = [&](int buf) {
     char* sa = smem + buf * STAGE;
+    if constexpr (X3) {
+      if (tapin) {
+        const int trr = tp_tap / p.S, tss = tp_tap - trr * p.S;
+        const int dy = trr * p.dil, dx = tss * p.dil;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          const int d = (dy * rW[i] + dx) * p.C * 2;
+          const unsigned off = ((tvm[i] >> tp_tap) & 1u) ? tbase[i] + (unsigned)(p.transposed ? -d : d) + (unsigned)tp_cc * (BK * 2) : OOB_BASE;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + (RPP * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
+        }
+        return;
+      }
+    }
     if (new_tap) {
       const bool tapok = tr < p.R;
       const int dy = tr * p.dil, dx = ts * p.dil;
@@ -287,6 +314,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   };
   auto load_b = [&](int buf) {
     char* sb = smem + buf * STAGE + A_BYTES;
+    if constexpr (X3) {
+      if (tapin) {
+        const unsigned kofs = (unsigned)((tp_tap * p.C + tp_cc * BK) * 2);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+          const unsigned off = wb0[i] == OOB ? OOB_BASE : wb0[i] + kofs;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sb + (RPP * i + 8 * uw) * ROWB), 16, off, 0, 0, 0);
+        }
+        return;
+      }
+    }
     const bool kok = (kt_ld * BK + kc * 8) < p.K;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -303,6 +341,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     }
   };
   auto advance = [&]() {      // state of the next K-step
+    if constexpr (X3) {
+      if (tapin) {
+        ++kt_ld;
+        if (++tp_tap == ntaps) { tp_tap = 0; ++tp_cc; }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) woff[i] += BK * 2;
     c8 += CPR;
@@ -397,6 +442,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // first stage: the weight tile and the epilogue operands do not depend on the row decode -- they go out first and are in flight
   // while the rows are resolved
   bool have = __builtin_amdgcn_readfirstlane(kt_ld) < kt_end;     // (kt_ld is the same in every lane; say so, or the loop control goes through EXEC)                    // (a class without a reachable tap has no K-step at all: its dX is the epilogue of zero)
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int n = n0 + RPP * i + 8 * uw + prow;
+      wb0[i] = n < p.N ? (unsigned)(((long long)n * p.K + kc * 8) * 2) : OOB;
+    }
+  }
   if (have) load_b(0);
   if (linear && p.ksplit == 1 && PREFETCH) prefetch_epilogue(false);
   {
@@ -419,6 +471,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       const int hw = __shfl(d_hw, src);
       rbase[i] = (unsigned)__shfl(d_base, src); ry0[i] = __shfl(d_y, src); rx0[i] = __shfl(d_x, src);
       rH[i] = hw & 0xffff; rW[i] = (int)((unsigned)hw >> 16);
+    }
+    if constexpr (X3) {
+      if (tapin) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          tbase[i] = rbase[i] + (unsigned)(((ry0[i] * rW[i] + rx0[i]) * p.C + kc * 8) * 2);      // (modular: only used where the tap is valid)
+          unsigned vm = 0;
+          for (int tq = 0; tq < ntaps; ++tq) {
+            const int r_ = tq / p.S, s_ = tq - r_ * p.S;
+            const int y = p.transposed ? ry0[i] - r_ * p.dil : ry0[i] + r_ * p.dil, x = p.transposed ? rx0[i] - s_ * p.dil : rx0[i] + s_ * p.dil;
+            vm |= ((unsigned)y < (unsigned)rH[i] && (unsigned)x < (unsigned)rW[i]) ? (1u << tq) : 0u;
+          }
+          tvm[i] = vm;
+        }
+      }
     }
   }
   TSTAMP(9);
@@ -918,6 +985,7 @@ static int conv_params(const aod_conv_desc_t* desc, const void* src, const void*
   p.post_scale = post_scale; p.zraw = (bf16_t*)zraw; p.colsum = colsum;
   p.ksplit = 1;
   { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
+  { static const char* dbg_ti = getenv("AOD_X3_TAPS_INNER"); p.tap_inner = (dbg_ti && dbg_ti[0] == '0') ? 0 : 1; }     // (debug: 0 = the plain K order)
   p.perm = (desc->transposed && desc->stride == 2 && desc->R * desc->S > 1 && desc->R * desc->S <= 64) ? 1 : 0;     // (no gain measured for 1x1)
   static const char* dbg_perm = getenv("AOD_DGRAD_CLASSES");
   if (dbg_perm && dbg_perm[0] == '0') p.perm = 0;
