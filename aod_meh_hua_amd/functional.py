@@ -223,7 +223,8 @@ _FUSE_ACT = _os.environ.get('AOD_FUSE_ACT', '1') != '0'      # debug switch for 
 # gradient and packed filter travels as a bf16 head + tail pair (X-layout rows, hipops.xw) and every product is three MFMAs, in the same
 # kernels with the same fused epilogues (csrc/conv.hip "X3", csrc/x3_ops.hip): fp32-grade results at ~3x the matrix work.  In that mode a
 # tensor handed between modules has the logical shape [B, xw(C), H, W]; x3_to_f32() gives its fp32 [B, C, H, W] values.
-_PREC = _os.environ.get('AOD_CONV_PREC', 'bf16')
+_PREC = _os.environ.get('AOD_CONV_PREC', 'bf16x3')        # default: the reference's precision (the reference computes in fp32)
+assert _PREC in ('bf16', 'bf16x3'), f'AOD_CONV_PREC={_PREC!r}: bf16x3 (reference precision) or bf16 (fast mode)'
 ho.X3 = _PREC == 'bf16x3'
 
 

@@ -59,7 +59,7 @@ def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--Unc-type', type=str)
     p.add_argument('--precision', choices=['bf16x3', 'bf16'], default=None,
-                   help='arithmetic of the conv stack (default: AOD_CONV_PREC or bf16): bf16x3 = reference precision, bf16 = fast mode')
+                   help='arithmetic of the conv stack (default: AOD_CONV_PREC or bf16x3): bf16x3 = reference precision, bf16 = fast mode')
     p.add_argument('--synthetic', type=int, default=0, help='run on a synthetic VOC-shaped pool of this many images')
     p.add_argument('--synthetic-size', type=int, default=default_size)
     p.add_argument('--cycles', type=int, default=None, help='override the number of AL cycles')
