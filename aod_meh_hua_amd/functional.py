@@ -898,7 +898,9 @@ def image_to_nhwc(img, cpad=8):
 def bottleneck64_applies(blk, x):
     """a 64-channel, stride-1 bottleneck (resnet.py:262-301) whose forward keeps nothing for a backward pass: inference, or a frozen
     block (layer1 under frozen_stages = 1) on an input that needs no gradient"""
-    if _PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK', '1') == '0' or blk.planes != 64 or x.dtype != torch.bfloat16:
+    if _os.environ.get('AOD_FUSE_BOTTLENECK', '1') == '0' or blk.planes != 64 or x.dtype != torch.bfloat16:
+        return False
+    if ho.X3 and _os.environ.get('AOD_FUSE_BOTTLENECK_X3', '1') == '0':
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
     if (tuple(c2.stride) != (1, 1) or tuple(c2.dilation) != (1, 1) or tuple(c1.stride) != (1, 1) or c1.in_channels % 64 != 0
@@ -913,9 +915,9 @@ def bottleneck64_fwd(x, blk, identity):
     """the whole block in one launch (aod_bottleneck64_fwd); `identity` = x or the downsample branch's output"""
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
-    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
-    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), 64, blk.norm2.eps)
-    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), 64, blk.norm3.eps)
+    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)                 # (Cin = the row width of x: the X-layout width in the x3 mode)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), ho.width(64), blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), ho.width(64), blk.norm3.eps)
     out = ho.bottleneck64_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale, p3.shift,
                               as_rows(identity.detach()))
     return as_nchw(out, B, H, W)

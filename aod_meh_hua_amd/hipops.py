@@ -469,6 +469,15 @@ def nchw_to_s2d_rows(img_f32):
 def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_rows, out=None):
     """aod_bottleneck64_fwd: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + res) for a 64-channel bottleneck, one launch"""
     M, Cin = x_rows.shape
+    if X3:          # X rows: the x3 twin of the kernel (csrc/bottleneck_x3.hip); Cin = logical input channels
+        Cl = Cin // 2
+        assert M == B * H * W and res_rows.shape == (M, 512)
+        if out is None:
+            out = torch.empty(M, 512, dtype=torch.bfloat16, device=x_rows.device)
+        prof_flops('fwd', (M, 256, 2 * (Cl + 576 + 64), 11, 1), 2.0 * M * (Cl * 64 + 576 * 64 + 64 * 256),
+                   lambda: call('aod_bottleneck64x3_fwd', ptr(x_rows), Cl, B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
+                                ptr(b3), ptr(res_rows), ptr(out), stream()))
+        return out
     assert M == B * H * W and res_rows.shape == (M, 256)
     if out is None:
         out = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device)

@@ -425,6 +425,12 @@ int aod_x3_act_bwd(const void* g, const void* a, void* dz, float* colsum, int64_
 /* aod_pad_cast_colsum: fp32 head gradients [M][N] (* [relu_out > 0]) -> X rows of 2*ceil32(N) columns + column sums fp32 [ceil32(N)] */
 int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, aod_stream_t stream);
 
+/* aod_bottleneck64_fwd on X rows (reference-precision mode; csrc/bottleneck_x3.hip): x [B*H*W][2*Cin], w1 / w2 / w3 = the X filter images of
+ * aod_param_prep (flags bit 0), res / y [B*H*W][512]; Cin = LOGICAL input channels (64 or 256). */
+int aod_bottleneck64x3_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                           const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
+                           aod_stream_t stream);
+
 /* SSD300-VGG16 (BASELINE config 0) in the reference-precision mode: the image as ONE 32-channel band of X rows (64 columns; the first VGG
  * conv reads it), and aod_maxpool_fwd/bwd, aod_l2norm_fwd/bwd on X rows (C = the X-layout width; L2Norm's w has C/2 entries). */
 int aod_x3_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);

@@ -276,3 +276,52 @@ def test_x3_ssd_row_kernels_against_fp32():
     y.backward(AF.as_nchw(_x(gy), B, H, W))
     ref.backward(gy)
     assert _err(_f(AF.as_rows(xx.grad), B, H, W, C), xr.grad) < 5e-5 and _err(w.grad, wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 48), (1, 13, 37), (3, 8, 16)])
+def test_x3_fused_bottleneck64_equals_the_three_launch_block(shape):
+    """aod_bottleneck64x3_fwd (frozen layer-1 blocks in the reference-precision mode: conv1 on the halo, conv2 from LDS, conv3 + residual, one
+    launch) against the same block as three x3 conv launches -- same products in the same order per accumulator -> identical bits -- and
+    against fp32; whole and ragged tiles, the first block (64 input channels + downsample branch) and an identity block (256)"""
+    import os
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.models.backbones.resnet import Bottleneck
+    from aod_meh_hua_amd.mmcv_lite import BatchNorm2d, Conv2d
+    import torch.nn as nn
+    B, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(17)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    for cin in (64, 256):
+        ds = None
+        if cin != 256:
+            ds = nn.Sequential(Conv2d(cin, 256, 1, bias=False), BatchNorm2d(256))
+        blk = Bottleneck(cin, 64, downsample=ds).cuda().eval()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.weight.copy_(rnd(*m.weight.shape) / (m.weight[0].numel()) ** 0.5)
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.copy_(torch.rand(m.weight.shape, device='cuda', generator=g) + 0.5); m.bias.copy_(rnd(*m.bias.shape) * 0.1)
+                    m.running_mean.copy_(rnd(*m.bias.shape) * 0.1); m.running_var.copy_(torch.rand(m.bias.shape, device='cuda', generator=g) + 0.5)
+        for q in blk.parameters():
+            q.requires_grad_(False)
+        x = rnd(B, cin, H, W)
+        xx = AF.as_nchw(_x(x), B, H, W)
+        with torch.no_grad():
+            assert AF.bottleneck64_applies(blk, xx)
+            y1 = blk(xx)
+            os.environ['AOD_FUSE_BOTTLENECK_X3'] = '0'
+            try:
+                assert not AF.bottleneck64_applies(blk, xx)
+                y0 = blk(xx)
+            finally:
+                os.environ.pop('AOD_FUSE_BOTTLENECK_X3', None)
+            torch.cuda.synchronize()
+            bnf = lambda z, n: F.batch_norm(z, n.running_mean, n.running_var, n.weight, n.bias, False, 0.0, n.eps)
+            t = torch.relu(bnf(F.conv2d(x, blk.conv1.weight), blk.norm1))
+            t = torch.relu(bnf(F.conv2d(t, blk.conv2.weight, None, 1, 1), blk.norm2))
+            idn = x if ds is None else bnf(F.conv2d(x, ds[0].weight), ds[1])
+            ref = torch.relu(bnf(F.conv2d(t, blk.conv3.weight), blk.norm3) + idn)
+        f1 = _f(AF.as_rows(y1), B, H, W, 256)
+        assert _err(f1, ref) < 1e-4, (cin, _err(f1, ref))
+        assert torch.equal(y1, y0), (cin, float((AF.as_rows(y1).float() - AF.as_rows(y0).float()).abs().max()))
