@@ -25,7 +25,7 @@ ho.PROFILE = []
 step(False)
 torch.cuda.synchronize()
 agg = {}
-for kind, shape, flops, e0, e1 in ho.PROFILE:
+for kind, shape, flops, e0, e1, _scope in ho.PROFILE:
     a = agg.setdefault((kind, shape), [0, 0.0, flops])
     a[0] += 1; a[1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
