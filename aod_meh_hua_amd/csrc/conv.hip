@@ -380,6 +380,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   const int ec = t % NCH, er = t / NCH;
   float cs1[8], cb1[8], cs2[8];
   bf16x8 pres[PREFETCH ? E_IT : 1], pmask[PREFETCH ? E_IT : 1];
+  // LATE (the 4-wave X3 forms, which cannot spare the registers during the K loop): the same operands are fetched once the accumulators
+  // sit in LDS, all E_IT row segments at once, ahead of the barrier.  Fetched inside the store loop, every iteration's load waited behind the
+  // previous iteration's store (the two may alias as far as the compiler knows): one exposed memory latency per 16-B segment, 9.4 us of
+  // a 22 us tile on the residual convs of the X3 backbone.  (Not the 256 x 256 tile: its second-pass accumulators are still live, it spills.)
+  constexpr bool LATE = X3 && EP == 1;
+  bf16x8 lres[LATE ? E_IT : 1], lrl[(LATE && X3) ? E_IT : 1], lmask[LATE ? E_IT : 1];
   // interior tiles of the common configuration (bf16 destination, N % 8 == 0, no post-scale / raw copy) take an epilogue without per-thread
   // predicates; inside one segment the destination rows are also linear in m (drow = m + drow_lin)
   const bool fast = !p.out_f32 && !p.zraw && !p.post_scale && (p.N & 7) == 0 && n0 + BN <= p.N && m0 + BM <= p.M;
@@ -636,6 +642,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         for (int r = 0; r < 4; ++r)
           sc[(wm * WM - r0e + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
   }
+  if (LATE && fast && OPS > 0) {
+#pragma unroll
+    for (int it = 0; it < E_IT; ++it) {
+      const long long eoff = linear ? lin_off + (long long)r0e * NP + it * lin_step : s_drow[r0e + er + it * (NT / NCH)] * NP + xcol(n0 + ec * 8);
+      if (OPS > 1 && p.res) {
+        lres[it] = *reinterpret_cast<const bf16x8*>(p.res + eoff);
+        if constexpr (X3) lrl[it] = *reinterpret_cast<const bf16x8*>(p.res + eoff + 32);
+      }
+      if (g_mask) lmask[it] = *reinterpret_cast<const bf16x8*>(g_mask + eoff);
+    }
+  }
   __syncthreads();
   TSTAMP(4);
 
@@ -660,9 +677,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       for (int j = 0; j < 8; ++j) v[j] += cb1[j];
       const long long eoff = linear ? lin_off + (long long)r0e * NP + it * lin_step : s_drow[r0e + row] * NP + xcol(n0 + ec * 8);
       if (OPS > 1 && p.res) {
-        const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + eoff);
+        const bf16x8 rv = PREFETCH ? pres[it] : (LATE ? lres[it] : *reinterpret_cast<const bf16x8*>(p.res + eoff));
         if constexpr (X3) {
-          const bf16x8 rl = *reinterpret_cast<const bf16x8*>(p.res + eoff + 32);
+          const bf16x8 rl = LATE ? lrl[it] : *reinterpret_cast<const bf16x8*>(p.res + eoff + 32);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)rv[j] + (float)rl[j];
         } else {
@@ -671,7 +688,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         }
       }
       if (OPS > 0 && g_mask) {
-        const bf16x8 mv = PREFETCH ? pmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + eoff);
+        const bf16x8 mv = PREFETCH ? pmask[it] : (LATE ? lmask[it] : *reinterpret_cast<const bf16x8*>(g_mask + eoff));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ((float)mv[j] > 0.f) ? v[j] : 0.f;
       }

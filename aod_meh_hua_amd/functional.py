@@ -1076,10 +1076,21 @@ def stem_conv_s2d(img, conv, bn):
 def stem_pool_s2d(img, conv, bn):
     """max_pool_3x3_s2(relu(bn(conv7x7_s2(img)))) of the frozen stem in one launch after the layout kernel (aod_stem_pool_fwd): the
     64-channel conv output stays in LDS.  AOD_STEM_POOL_FUSE=0: conv and pool as separate launches."""
-    if ho.X3 or _os.environ.get('AOD_STEM_POOL_FUSE', '1') == '0':
-        return max_pool_3x3_s2(stem_conv_s2d(img, conv, bn))
     B, Cc, H, W = img.shape
     O = conv.weight.shape[0]
+    if _os.environ.get('AOD_STEM_POOL_FUSE', '1') == '0' or (ho.X3 and (Cc != 3 or O != 64)):
+        return max_pool_3x3_s2(stem_conv_s2d(img, conv, bn))
+    if ho.X3:
+        # reference-precision mode: image -> pooled X rows in one launch (csrc/stem_x3.hip); the X filter image is the one the s2d conv uses
+        pi = PREP.get(_stem_w4(conv), (bn.weight, bn.bias, bn.running_mean, bn.running_var), ho.xw(16), bn.eps)
+        H2, W2 = H // 2, W // 2
+        H4, W4 = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
+        out = torch.empty(B * H4 * W4, ho.xw(O), dtype=torch.bfloat16, device=img.device)
+        src = img.detach().contiguous()
+        ho.prof_flops('fwd', (B * H2 * W2, O, 2 * 49 * Cc, 49, 2), 2.0 * B * H2 * W2 * O * 49 * Cc,
+                      lambda: ho.call('aod_stem_pool_x3_fwd', ho.ptr(src), ho.ptr(pi.wf), ho.ptr(pi.scale), ho.ptr(pi.shift), ho.ptr(out), B, Cc, H, W,
+                                      ho.stream()))
+        return as_nchw(out, B, H4, W4)
     assert O == 64 and Cc <= 4
     rows, segs = ho.nchw_to_s2d_rows(img.detach())
     pi = PREP.get(_stem_w4(conv), (bn.weight, bn.bias, bn.running_mean, bn.running_var), 16, bn.eps)

@@ -431,6 +431,13 @@ int aod_bottleneck64x3_fwd(const void* x, int Cin, int B, int H, int W, const vo
                            const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
                            aod_stream_t stream);
 
+/* The frozen stem of the reference-precision mode in one launch (csrc/stem_x3.hip; resnet.py:630-637): fp32 NCHW image [B][3][H][W] (even
+ * H, W) -> y = max_pool_3x3_s2_p1(relu(bn1(conv1_7x7_s2(img)))) as X rows [B][H4][W4][128], H4 = (H/2 - 1) / 2 + 1.  w_x = the X filter
+ * image [64][4][4][64] of the space-to-depth form of conv1 (aod_param_prep, flags bit 0, of the [64][12][4][4] filter); replaces
+ * aod_x3_nchw_f32_to_s2d + aod_conv2d + aod_x3_maxpool3x3s2 and agrees with them to fp32 summation order. */
+int aod_stem_pool_x3_fwd(const float* img, const void* w_x, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
+                         aod_stream_t stream);
+
 /* SSD300-VGG16 (BASELINE config 0) in the reference-precision mode: the image as ONE 32-channel band of X rows (64 columns; the first VGG
  * conv reads it), and aod_maxpool_fwd/bwd, aod_l2norm_fwd/bwd on X rows (C = the X-layout width; L2Norm's w has C/2 entries). */
 int aod_x3_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, aod_stream_t stream);

@@ -173,8 +173,11 @@ def test_x3_row_kernels_against_fp32():
     assert _err(_f(AF.as_rows(xx.grad), B, H, W, C), g1 + g2) < 2e-5
 
 
-def test_x3_stem_against_fp32():
-    """frozen stem in the reference-precision mode: space-to-depth image (X rows of 64 columns) -> 4x4 conv + BN + ReLU -> max-pool"""
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 70, 102), (3, 128, 192), (1, 34, 30)])
+def test_x3_stem_against_fp32(shape, monkeypatch):
+    """frozen stem in the reference-precision mode, both forms: the ONE-launch kernel (csrc/stem_x3.hip: fp32 image -> pooled X rows) and
+    the three launches it replaces (space-to-depth X rows of 64 columns -> 4x4 conv + BN + ReLU -> max-pool), each against torch fp32 and
+    against each other (they group the fp32 sums differently: equal to summation order, not to the bit); ragged tiles included"""
     from aod_meh_hua_amd import functional as AF
     from aod_meh_hua_amd.mmcv_lite import BatchNorm2d, Conv2d
     g = torch.Generator(device='cuda').manual_seed(3)
@@ -186,12 +189,18 @@ def test_x3_stem_against_fp32():
         conv.weight.copy_(torch.randn(64, 3, 7, 7, device='cuda', generator=g) * 0.05)
         bn.running_mean.copy_(torch.randn(64, device='cuda', generator=g) * 0.1)
         bn.running_var.copy_(torch.rand(64, device='cuda', generator=g) + 0.5)
-    img = torch.randn(2, 3, 64, 96, device='cuda', generator=g)
+    B, H, W = shape
+    img = torch.randn(B, 3, H, W, device='cuda', generator=g)
     assert AF.stem_s2d_applies(img, conv, bn)
-    y = AF.stem_pool_s2d(img, conv, bn)
     ref = F.max_pool2d(torch.relu(F.batch_norm(F.conv2d(img, conv.weight, None, 2, 3), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)), 3, 2, 1)
-    got = AF.x3_to_f32(y, 64)
-    assert got.shape == ref.shape and _err(got, ref) < 1e-4, _err(got, ref)
+    got = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('AOD_STEM_POOL_FUSE', fuse)
+        y = AF.stem_pool_s2d(img, conv, bn)
+        got[fuse] = AF.x3_to_f32(y, 64)
+        assert got[fuse].shape == ref.shape and _err(got[fuse], ref) < 1e-4, (fuse, _err(got[fuse], ref))
+    # (a value's tail has 8 bits below its head's 8: one flipped tail rounding is 2^-17 = 7.6e-6 of the value)
+    assert _err(got['1'], got['0']) < 2e-5, _err(got['1'], got['0'])
 
 
 def test_x3_grouped_tower_launches_equal_the_separate_ones():
