@@ -38,6 +38,8 @@ struct ConvKParams {
   int x3;             // reference-precision mode (aod_conv_desc_t.x3): operands in the X-layout, three MFMAs per 32 channels (see X3 below)
   int tap_inner;      // X3: K-steps run (channel chunk, tap) with the TAP innermost (see the loaders)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
+  int up_w, up_hw;    // > 0: LATTICE launch (conv_params): the GEMM rows are the pixels (b, y, x) of the source map and row (b, y, x) is stored
+                      // at row b * up_hw + 2y * up_w + 2x of the destination -- the in-place 1x1 / stride-2 dgrad, whose other rows do not change
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
   long long seg_src0[8], seg_dst0[8];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       oy = 2 * yy + (unsigned)(cls >> 1); ox = 2 * (rem - yy * Wc) + (unsigned)(cls & 1);
     }
   };
-  const bool linear = one_seg && !p.perm;       // destination rows of the tile are consecutive: drow = m + const
+  const bool linear = one_seg && !p.perm && !p.up_w;       // destination rows of the tile are consecutive: drow = m + const
   // destination row of every tile row, parked in LDS behind the staging / epilogue area (read by the general epilogue, and by the
   // fast one on tiles that straddle a segment boundary)
   constexpr int EPI_BYTES = EBM * CP * 4;
@@ -205,6 +207,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   if (t < BM) {
     const int m = m0 + t;
     if (linear) s_drow[t] = p.seg_dst0[sg_first] + (long long)((unsigned)m - gu.mstart);
+    else if (p.up_w) {          // (one segment: conv_params)
+      unsigned b, oy, ox; int cls;
+      rowpos((unsigned)m, gu, b, oy, ox, cls);
+      s_drow[t] = p.seg_dst0[0] + (long long)b * p.up_hw + (long long)(2 * oy) * p.up_w + 2 * ox;
+    }
     else if (!p.perm) { const int sg = m < p.M ? seg_of(m) : 0; s_drow[t] = p.seg_dst0[sg] + (m - (sg ? p.seg_mend[sg - 1] : 0)); }
     else {
       const int sg = one_seg ? sg_first : (m < p.M ? seg_of(m) : 0);
@@ -1004,6 +1011,23 @@ static int conv_params(const aod_conv_desc_t* desc, const void* src, const void*
   { static const char* dbg_st = getenv("AOD_STAGGER"); p.stagger = (dbg_st && dbg_st[0] == '0') ? 0 : 1; }
   { static const char* dbg_ti = getenv("AOD_X3_TAPS_INNER"); p.tap_inner = (dbg_ti && dbg_ti[0] == '0') ? 0 : 1; }     // (debug: 0 = the plain K order)
   p.perm = (desc->transposed && desc->stride == 2 && desc->R * desc->S > 1 && desc->R * desc->S <= 64) ? 1 : 0;     // (no gain measured for 1x1)
+  // The dgrad of a 1x1 / stride-2 conv ACCUMULATED IN PLACE (res == dst, nothing else in the epilogue: the running sum of a gradient
+  // junction, functional.GradAcc) only changes the (even, even) pixels of the destination: dX[b, 2y, 2x] += dZ[b, y, x] . W.  As a general
+  // transposed launch it walks K for all four pixel classes and rewrites 4 x the rows (206 us for the layer-3 entry at 16 x 64 x 64 x 512
+  // in the reference-precision mode); as a LATTICE launch it is a plain GEMM over the dZ pixels whose rows are stored two apart.
+  if (desc->transposed && desc->stride == 2 && desc->R == 1 && desc->S == 1 && desc->pad == 0 && desc->nseg == 1 && res && res == dst &&
+      !mask && !colsum && !pre_scale && !pre_shift && !post_scale && !zraw && !desc->relu && !desc->out_f32 && p.M > 0) {
+    static const char* dbg_lat = getenv("AOD_DGRAD_LATTICE");
+    if (!(dbg_lat && dbg_lat[0] == '0')) {
+      p.up_w = p.segOW[0]; p.up_hw = p.segOH[0] * p.segOW[0];
+      p.segOH[0] = p.segH[0]; p.segOW[0] = p.segW[0];
+      p.stride = 1;
+      const long long m = (long long)p.segB[0] * p.segH[0] * p.segW[0];
+      p.M = (int)m;
+      for (int i = 0; i < 8; ++i) p.seg_mend[i] = (int)m;
+      p.bigrows = m >= (1ll << 22) ? 1 : 0;
+    }
+  }
   static const char* dbg_perm = getenv("AOD_DGRAD_CLASSES");
   if (dbg_perm && dbg_perm[0] == '0') p.perm = 0;
   long long xrows = 0;
@@ -1037,7 +1061,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   if (p.M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // 1x1, stride 1: a plain GEMM over consecutive rows -- the persistent streaming kernel (pointwise.hip) when its launch heuristic wants it
-  if (!p.x3 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && !p.out_f32 && !p.zraw && !p.post_scale) {
+  if (!p.x3 && !p.up_w && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.nseg == 1 && !p.out_f32 && !p.zraw && !p.post_scale) {
     PwArgs a;
     const long long s0 = p.seg_src0[0], d0 = p.seg_dst0[0];
     a.x = p.x + s0 * p.C; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y) + d0 * p.N;
@@ -1046,7 +1070,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     a.M = p.M; a.N = p.N; a.K = p.C; a.relu = p.relu;
     if (aod_pw_wants(a)) return aod_pw_gemm(a, st);
   }
-  const int ks = (workspace && !p.perm) ? choose_ksplit(p) : 1;
+  const int ks = (workspace && !p.perm && !p.up_w) ? choose_ksplit(p) : 1;
   if (ks > 1) {
     const size_t need = (size_t)ks * p.M * p.N * 4;
     AOD_CHECK_ARG(workspace_bytes >= need, "conv: split-K workspace of %zu bytes, need %zu (aod_conv2d_ws_bytes)", workspace_bytes, need);

@@ -676,8 +676,13 @@ class ConvFn(Function):
                     if role == 1:
                         ch.meta.clear(), ch.x_rows.clear(), ch.prep.clear()
             if dx is None:
+                # a 1x1 / stride-2 conv (a stage's downsample conv) that is not the junction's last consumer adds into the running sum IN
+                # PLACE: only the (even, even) pixels change, and the library then runs a plain GEMM over the dZ pixels (conv.hip, lattice launch)
+                inplace = (acc is not None and res_g is not None and jslot is None and not fuse and R == 1 and S == 1 and meta['stride'] == 2
+                           and meta['pad'] == 0 and res_g.dtype == torch.bfloat16 and _os.environ.get('AOD_DGRAD_INPLACE', '1') != '0')
                 dx = ho.conv2d_dgrad_rows(dz, dsegs, xd, wd, I, R, S, meta['stride'], meta['pad'], meta['dil'],
-                                          res=res_g, mask=x_rows if (fuse or jslot is not None) else None, colsum=s1_in, alg=(I, O))
+                                          res=res_g, mask=x_rows if (fuse or jslot is not None) else None, colsum=s1_in, alg=(I, O),
+                                          out=res_g if inplace else None)
             if fuse:
                 in_slot.masked, in_slot.s1, in_slot.res_grad = True, s1_in, None
             if jslot is not None:

@@ -281,6 +281,53 @@ def test_conv_dgrad_stride2_class_major_with_fused_activation_backward(ho, sizes
     assert close(cs, want.sum(0), 2e-2, 0.3 * scale)
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('shape', [(2, 33, 20, 128, 256), (3, 16, 16, 256, 512), (1, 7, 130, 64, 128)])
+def test_inplace_pointwise_stride2_dgrad_is_a_lattice_launch(ho, prec, shape):
+    """dX += conv_T(dZ, W) of a 1x1 / stride-2 conv with res == dst (the running sum of a gradient junction, functional.GradAcc): the library
+    runs a GEMM over the dZ pixels and stores its rows at the (even, even) pixels of dX (conv.hip, lattice launch) instead of a transposed
+    launch over all of dX.  Against the general launch into a separate destination: bf16 -- identical bits everywhere; reference-precision
+    mode -- identical on the lattice, and off it the untouched sum against its re-rounded copy (head + tail re-split)."""
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision(prec)
+    try:
+        B, H, W, I, O = shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        g = torch.Generator(device='cuda').manual_seed(7)
+        rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+        w = rnd(O, I, 1, 1) / np.sqrt(O)
+        dz_f, part_f = rnd(B * OH * OW, O), rnd(B * H * W, I)
+        if prec == 'bf16x3':
+            dz, part = ho.x3_split(dz_f), ho.x3_split(part_f)
+            wd = ho.x3_split(w.reshape(O, I).t().contiguous()).view(I, 1, 1, -1)
+        else:
+            dz, part = dz_f.bfloat16(), part_f.bfloat16()
+            wd = ho.pack_weight_dgrad(w, O)
+        zs, xs = [ho.Seg(B, OH, OW, 0)], [ho.Seg(B, H, W, 0)]
+        want = ho.conv2d_dgrad_rows(dz, zs, xs, wd, I, 1, 1, 2, 0, 1, res=part)
+        assert want.data_ptr() != part.data_ptr()
+        acc = part.clone()
+        got = ho.conv2d_dgrad_rows(dz, zs, xs, wd, I, 1, 1, 2, 0, 1, res=acc, out=acc)
+        torch.cuda.synchronize()
+        assert got.data_ptr() == acc.data_ptr()
+        lat = torch.zeros(B, H, W, dtype=torch.bool, device='cuda')
+        lat[:, ::2, ::2] = True
+        lat = lat.reshape(-1)
+        assert torch.equal(got[lat], want[lat])
+        assert torch.equal(got[~lat], part[~lat])
+        if prec == 'bf16':
+            assert torch.equal(got, want)
+        else:
+            assert float((ho.x3_merge(got) - ho.x3_merge(want)).abs().max()) <= 2e-5 * float(part_f.abs().max())
+        # and the values: fp32 reference on the same operands
+        ref = part_f.view(B, H, W, I).clone()
+        ref[:, ::2, ::2] += (dz_f @ w.reshape(O, I)).view(B, OH, OW, I)
+        out = ho.x3_merge(got) if prec == 'bf16x3' else got.float()
+        assert float((out - ref.reshape(-1, I)).abs().max()) < (1e-4 if prec == 'bf16x3' else 6e-2) * float(ref.abs().max())
+    finally:
+        AF.set_precision('bf16')
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_dgrad_and_wgrad(ho, case):
     B, C, H, W, N, R, stride, pad, dil = case
