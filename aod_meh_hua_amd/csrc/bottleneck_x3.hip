@@ -13,6 +13,10 @@
 //            8-slot ring in groups of four steps; t2 = relu(bn2(.)) -> LDS over t1;
 //   phase 3  conv3 from t2 against the X filter (64 KB, fetched into the ring's slots as they fall free), two halves of 128 output
 //            channels; epilogue in registers: + residual (head + tail), ReLU, head / tail stores.
+// DS form (the stage's FIRST block, Cin = 64): the residual is the block's downsample branch bn_d(conv_d_1x1(x)) (resnet.py:291-292), computed here
+// as well instead of being written (268 MB at 16 x 128 x 128) by a launch of its own and read back: per half of 128 output channels, the
+// wave's 16 pixels of x (fragments straight from global memory: L2 hits, the halo tile was just read) against half of the X filter [256][128]
+// staged in a 32 KB LDS region of its own; BN, rounding to head + tail as the separate launch would store it -> the residual registers.
 // Products are computed transposed (filter fragment = the MFMA's A operand) with the paired-block row permutation of bottleneck.hip, so a
 // lane holds 8 consecutive channels of one pixel and every intermediate / residual / output piece is 16 B.
 #include "common.h"
@@ -25,7 +29,8 @@ struct Bnx3Args {
   const bf16_t* w2;      // X filter [64][9][128]
   const bf16_t* w3;      // X filter [256][128]
   const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
-  const bf16_t* res;     // X rows [B*H*W][512] (may alias x when Cin == 256)
+  const bf16_t* res;     // X rows [B*H*W][512] (may alias x when Cin == 256); unused in the DS form
+  const bf16_t* wd; const float* sd; const float* bd;      // DS form: X filter [256][128] and folded BN of the downsample conv
   bf16_t* y;             // X rows [B*H*W][512]
   int B, H, W, CP, tiles_y, tiles_x;      // CP = 2 * Cin: physical width of x
 };
@@ -37,10 +42,12 @@ constexpr int OFF_W1 = 2 * XBUF;                       // 49152: [2][64 rows][12
 constexpr int OFF_T1 = 65536;                          // [2 sub-images][192][128 B] = 48 KB; later t2 [2][128][128 B]
 constexpr int T1SUB = M1 * 128, T2SUB = TH * TW * 128;
 constexpr int OFF_VEC = OFF_T1 + 2 * T1SUB;            // 114688
-constexpr int LDS_BYTES = OFF_VEC + 768 * 4;           // 117760
+constexpr int NVEC = 1280;                             // s1 b1 s2 b2 | s3 | b3 | sd | bd
+constexpr int OFF_WD = OFF_VEC + NVEC * 4;             // 119808: DS form, half of the downsample filter [2 channel groups][128 rows][128 B]
+constexpr int LDS_BYTES = OFF_WD, LDS_BYTES_DS = OFF_WD + 32768;      // 119808 / 152576
 constexpr int SLOT = 8192;                             // conv2 filter ring: 8 slots of [64 rows][128 B] over the phase-1 stages
 constexpr int W3SUB = 256 * 128;                       // conv3 filter: 2 sub-images [256][128 B] over the ring
-static_assert(OFF_W1 + 2 * 8192 <= OFF_T1 && 8 * SLOT <= OFF_T1 && 2 * W3SUB <= OFF_T1 && 2 * T2SUB <= 2 * T1SUB && LDS_BYTES <= 160 * 1024, "LDS map");
+static_assert(OFF_W1 + 2 * 8192 <= OFF_T1 && 8 * SLOT <= OFF_T1 && 2 * W3SUB <= OFF_T1 && 2 * T2SUB <= 2 * T1SUB && LDS_BYTES_DS <= 160 * 1024, "LDS map");
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -58,6 +65,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l
   for (int j = 0; j < 8; ++j) { h[j] = (bf16_t)v[j]; l[j] = (bf16_t)(v[j] - (float)h[j]); }
 }
 
+template <bool DS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck64x3_fwd_kernel(const Bnx3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -74,7 +82,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const auto rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 64 * p.CP * 2, 0x00020000);
   const auto rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 9 * 128 * 2, 0x00020000);
   const auto rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, 256 * 128 * 2, 0x00020000);
-  const auto rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)(npix * 1024), 0x00020000);
+  const auto rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.x : p.res), 0, DS ? (int)(npix * p.CP * 2) : (int)(npix * 1024), 0x00020000);
+  const auto rsrc_wd = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, DS ? 256 * 128 * 2 : 0, 0x00020000);
   const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)(npix * 1024), 0x00020000);
   constexpr unsigned OOB = 0xf0000000u;
   // LDS-DMA lane roles (bottleneck.hip): one wave-instruction fills 8 rows x 8 chunks; lane -> row (lane >> 3) of the group, slot lane & 7
@@ -97,8 +106,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else v = p.s3[t - 256];
     vec[t] = v;
     if (t < 256) vec[512 + t] = p.b3[t];
+    if constexpr (DS) {
+      if (t < 256) vec[768 + t] = p.sd[t]; else vec[768 + t] = p.bd[t - 256];
+    }
   }
   const float* const vs1 = vec, * const vb1 = vec + 64, * const vs2 = vec + 128, * const vb2 = vec + 192, * const vs3 = vec + 256, * const vb3 = vec + 512;
+  const float* const vsd = vec + 768, * const vbd = vec + 1024;
+  // DS: half h of the downsample filter, rows 128 h .. + 127 as two channel-group images [128][128 B] (4 instructions per wave).  Half 0 goes
+  // out FIRST: it is the oldest vector-memory operation of the wave, so every counted wait below (which names the YOUNGER operations that
+  // may stay in flight) covers it
+  const unsigned wdlane = (unsigned)((8 * uw + drow) * 256 + kcw * 16);
+  auto issueD = [&](int half) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wd, (__attribute__((address_space(3))) void*)(smem + OFF_WD + g * 16384 + (uw + 8 * i) * 1024), 16,
+                                                 wdlane + (unsigned)((half * 128 + i * 64) * 256) + (unsigned)g * 128u, 0, 0, 0);
+  };
+  if constexpr (DS) issueD(0);
 
   // ------------------------------------------------------------------ phase 1: t1 = relu(bn1(conv1(x))) on the halo
   unsigned xoff[3];
@@ -279,8 +305,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       rl[jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (int)(prow + col + 64u), 0, 0);
     }
   };
-  wait_vm<0>();                                   // the conv3 filter has landed (this wave's part)
-  load_res(0);
+  // DS: the wave's 16 pixels of x as MFMA fragments (lane = pixel lr, k-chunk lq): heads and tails of the two 32-channel groups
+  u32x4_t xf[4];
+  auto load_xf = [&]() {
+    const unsigned xrow = (oy < p.H && ox < p.W) ? (unsigned)((img0 + (long long)oy * p.W + ox) * 256) : OOB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xf[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, (int)(xrow + (unsigned)(q * 64 + lq * 16)), 0, 0);
+  };
+  // ... and the residual of one half from them: rh / rl = head / tail of bn_d(conv_d(x)), the bits the separate launch would have stored
+  auto compute_res = [&](int half) {
+    f32x4 accd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accd[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const char* ws = smem + OFF_WD + g * 16384;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, xf[2 * g]), al = __builtin_bit_cast(bf16x8, xf[2 * g + 1]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int fr = wrow(j, lr);
+        const bf16x8 fh = *reinterpret_cast<const bf16x8*>(ws + wswz(fr, lq)), fl = *reinterpret_cast<const bf16x8*>(ws + wswz(fr, 4 + lq));
+        accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, ah, accd[j], 0, 0, 0);
+        accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh, al, accd[j], 0, 0, 0);
+        accd[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl, ah, accd[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const int c = half * 128 + jp * 32 + lq * 8;
+      float v[8];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(vsd + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vbd + c + 4 * h2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * h2 + r] = accd[2 * jp + h2][r] * sc[r] + sh[r];
+      }
+      bf16x8 oh, ol;
+      split8(v, oh, ol);
+      rh[jp] = __builtin_bit_cast(u32x4_t, oh); rl[jp] = __builtin_bit_cast(u32x4_t, ol);
+    }
+  };
+  wait_vm<0>();                                   // the conv3 filter has landed (this wave's part; DS: and half 0 of the downsample filter)
+  if constexpr (DS) load_xf(); else load_res(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // t2 and the conv3 filter complete
   __builtin_amdgcn_sched_barrier(0);
@@ -288,6 +354,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ------------------------------------------------------------------ phase 3: y = relu(bn3(conv3(t2)) + res), 2 x 128 output channels
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if constexpr (DS) {
+      if (half == 1) {
+        // per wave, in issue order: issueD(1) x4 | half 0's stores x8 | load_xf x4 -- the filter half has landed when <= 12 younger ones are out
+        wait_vm<12>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      compute_res(half);
+      if (half == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave is done reading half 0 of the downsample filter
+        issueD(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     f32x4 acc3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc3[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -329,29 +411,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oh), rsrc_y, (int)(prow + col), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), rsrc_y, (int)(prow + col + 64u), 0, 0);
     }
-    if (half == 0) load_res(1);
+    if (half == 0) { if constexpr (DS) { __builtin_amdgcn_sched_barrier(0); load_xf(); } else load_res(1); }
   }
 }
 
 }  // namespace
 
-extern "C" int aod_bottleneck64x3_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
-                                      const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res,
-                                      void* y, aod_stream_t stream) {
-  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && res && y, "bottleneck64x3: null pointer");
+static int launch_bnx3(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                       const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, const void* wd,
+                       const float* sd, const float* bd, void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck64x3: null pointer");
   AOD_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && B >= 1 && H >= 1 && W >= 1, "bottleneck64x3: Cin %d must be a multiple of 32", Cin);
   AOD_CHECK_ARG((long long)B * H * W * (Cin > 256 ? Cin : 256) * 4 < 0xe0000000ll, "bottleneck64x3: operand larger than 3.5 GiB");
   Bnx3Args a;
   a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w3 = (const bf16_t*)w3;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.res = (const bf16_t*)res; a.y = (bf16_t*)y;
+  a.wd = (const bf16_t*)wd; a.sd = sd; a.bd = bd;
   a.B = B; a.H = H; a.W = W; a.CP = 2 * Cin;
   a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64x3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64x3_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64x3_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_DS);
   }
-  hipLaunchKernelGGL(bottleneck64x3_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  if (wd) hipLaunchKernelGGL(bottleneck64x3_fwd_kernel<true>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES_DS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bottleneck64x3_fwd_kernel<false>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   AOD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int aod_bottleneck64x3_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                                      const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res,
+                                      void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(res, "bottleneck64x3: null pointer");
+  return launch_bnx3(x, Cin, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res, nullptr, nullptr, nullptr, y, stream);
+}
+
+extern "C" int aod_bottleneck64x3_ds_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                                         const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd,
+                                         const float* sd, const float* bd, void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(wd && sd && bd, "bottleneck64x3_ds: null pointer");
+  return launch_bnx3(x, 64, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, nullptr, wd, sd, bd, y, stream);
 }

@@ -1084,7 +1084,8 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   }
   // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups
   auto ntiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  const long long want = 512;
+  static const char* dbg_want = getenv("AOD_TILE_WANT");           // (debug: the tile count that counts as 'fills the device')
+  const long long want = dbg_want ? atoll(dbg_want) : 512;
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;

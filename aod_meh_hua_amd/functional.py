@@ -916,15 +916,30 @@ def bottleneck64_applies(blk, x):
     return not x.requires_grad and not any(q.requires_grad for q in blk.parameters())
 
 
+def bottleneck64_ds_fused(blk, x):
+    """reference-precision mode: the downsample branch of the stage's first 64-plane block (1x1, stride 1, 64 -> 256 channels + eval BN) rides
+    in the block's launch (aod_bottleneck64x3_ds_fwd; AOD_FUSE_BOTTLENECK_DS=0: a launch of its own)"""
+    ds = blk.downsample
+    if not ho.X3 or ds is None or _os.environ.get('AOD_FUSE_BOTTLENECK_DS', '1') == '0' or x.shape[1] != ho.xw(64):
+        return False
+    c, n = ds[0], ds[1]
+    return (tuple(c.weight.shape) == (256, 64, 1, 1) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0) and c.bias is None
+            and not n.training and (not torch.is_grad_enabled() or not any(q.requires_grad for q in list(c.parameters()) + list(n.parameters()))))
+
+
 def bottleneck64_fwd(x, blk, identity):
-    """the whole block in one launch (aod_bottleneck64_fwd); `identity` = x or the downsample branch's output"""
+    """the whole block in one launch (aod_bottleneck64_fwd); `identity` = x or the downsample branch's output (None: bottleneck64_ds_fused)"""
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)                 # (Cin = the row width of x: the X-layout width in the x3 mode)
     p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), ho.width(64), blk.norm2.eps)
     p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), ho.width(64), blk.norm3.eps)
+    ds = None
+    if identity is None:
+        pd = PREP.get(blk.downsample[0].weight, bn(blk.downsample[1]), Cin, blk.downsample[1].eps)
+        ds = (pd.wf, pd.scale, pd.shift)
     out = ho.bottleneck64_fwd(as_rows(x.detach()), B, H, W, p1.wf, p1.scale, p1.shift, p2.wf, p2.scale, p2.shift, p3.wf, p3.scale, p3.shift,
-                              as_rows(identity.detach()))
+                              as_rows(identity.detach()) if identity is not None else None, ds=ds)
     return as_nchw(out, B, H, W)
 
 

@@ -466,9 +466,18 @@ def nchw_to_s2d_rows(img_f32):
     return out, [Seg(B, H // 2, W // 2, 0)]
 
 
-def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_rows, out=None):
-    """aod_bottleneck64_fwd: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + res) for a 64-channel bottleneck, one launch"""
+def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_rows, out=None, ds=None):
+    """aod_bottleneck64_fwd: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + res) for a 64-channel bottleneck, one launch.
+    ds = (wd, sd, bd) (reference-precision mode, 64 input channels): res = bn_d(conv_d(x)) computed inside the launch (aod_bottleneck64x3_ds_fwd)"""
     M, Cin = x_rows.shape
+    if X3 and ds is not None:
+        assert M == B * H * W and Cin == 128 and res_rows is None
+        if out is None:
+            out = torch.empty(M, 512, dtype=torch.bfloat16, device=x_rows.device)
+        prof_flops('fwd', (M, 256, 2 * (64 + 576 + 64 + 64), 12, 1), 2.0 * M * (64 * 64 + 576 * 64 + 64 * 256 + 64 * 256),
+                   lambda: call('aod_bottleneck64x3_ds_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
+                                ptr(b3), ptr(ds[0]), ptr(ds[1]), ptr(ds[2]), ptr(out), stream()))
+        return out
     if X3:          # X rows: the x3 twin of the kernel (csrc/bottleneck_x3.hip); Cin = logical input channels
         Cl = Cin // 2
         assert M == B * H * W and res_rows.shape == (M, 512)

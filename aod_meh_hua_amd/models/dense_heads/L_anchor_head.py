@@ -40,9 +40,15 @@ def pack_gts(gt_bboxes, gt_labels, device):
         bi = torch.tensor([b for b, c in enumerate(counts) for _ in range(c)], dtype=torch.long)
         gi = torch.tensor([i for c in counts for i in range(c)], dtype=torch.long)
         bi, gi = bi.to(device, non_blocking=True), gi.to(device, non_blocking=True)
-        gts[bi, gi] = torch.cat([g.to(device).float().reshape(-1, 4) for g in gt_bboxes])
+        # (lists that live on one device -- host tensors from a loader, as a rule -- are joined there and cross over in ONE copy each:
+        # a `.to(device)` per image was 2 B copies of a few boxes, a queue entry each)
+        def joined(ts, dt, shape):
+            if len({t.device for t in ts}) == 1:
+                return torch.cat([t.reshape(shape) for t in ts]).to(device=device, dtype=dt, non_blocking=True)
+            return torch.cat([t.to(device).to(dt).reshape(shape) for t in ts])
+        gts[bi, gi] = joined(gt_bboxes, torch.float32, (-1, 4))
         if gt_labels is not None:
-            labs[bi, gi] = torch.cat([l.to(device).long().reshape(-1) for l in gt_labels])
+            labs[bi, gi] = joined(gt_labels, torch.long, (-1,))
     return gts, torch.tensor(counts, dtype=torch.int32).to(device, non_blocking=True), labs
 
 

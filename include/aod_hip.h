@@ -431,6 +431,12 @@ int aod_bottleneck64x3_fwd(const void* x, int Cin, int B, int H, int W, const vo
                            const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
                            aod_stream_t stream);
 
+/* ... for the stage's FIRST block (Cin = 64; resnet.py:291-292): the residual is bn_d(conv_d_1x1(x)), computed inside the launch from wd = the X
+ * filter image [256][128] of the downsample conv and its folded BN -- the bits a separate aod_conv2d launch would have stored and this one read back. */
+int aod_bottleneck64x3_ds_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                              const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd,
+                              const float* sd, const float* bd, void* y, aod_stream_t stream);
+
 /* The frozen stem of the reference-precision mode in one launch (csrc/stem_x3.hip; resnet.py:630-637): fp32 NCHW image [B][3][H][W] (even
  * H, W) -> y = max_pool_3x3_s2_p1(relu(bn1(conv1_7x7_s2(img)))) as X rows [B][H4][W4][128], H4 = (H/2 - 1) / 2 + 1.  w_x = the X filter
  * image [64][4][4][64] of the space-to-depth form of conv1 (aod_param_prep, flags bit 0, of the [64][12][4][4] filter); replaces

@@ -334,3 +334,14 @@ def test_x3_fused_bottleneck64_equals_the_three_launch_block(shape):
         f1 = _f(AF.as_rows(y1), B, H, W, 256)
         assert _err(f1, ref) < 1e-4, (cin, _err(f1, ref))
         assert torch.equal(y1, y0), (cin, float((AF.as_rows(y1).float() - AF.as_rows(y0).float()).abs().max()))
+        if ds is not None:
+            # the first block's downsample branch rides in the launch (aod_bottleneck64x3_ds_fwd); as a launch of its own: the same bits again
+            assert AF.bottleneck64_ds_fused(blk, xx)
+            os.environ['AOD_FUSE_BOTTLENECK_DS'] = '0'
+            try:
+                with torch.no_grad():
+                    assert not AF.bottleneck64_ds_fused(blk, xx) and AF.bottleneck64_applies(blk, xx)
+                    y2 = blk(xx)
+            finally:
+                os.environ.pop('AOD_FUSE_BOTTLENECK_DS', None)
+            assert torch.equal(y1, y2)
