@@ -227,3 +227,24 @@ def test_wgrad_group_plan_is_host_logic_with_the_documented_properties(lib):
     # argument errors
     rc, _ = plan([tower] * 5) if False else (lib.aod_conv2d_wgrad_group_plan(None, 1, None), None)
     assert rc == -1
+
+
+def test_head_tail_rounding_is_monotone_and_idempotent():
+    """X-layout rounding v -> bf16(v) + bf16(v - bf16(v)) (csrc/x3_ops.hip xstore / xload): the fused reference-precision stem
+    (csrc/stem_x3.hip) takes the max-pool BEFORE this rounding where the three-launch path rounds first -- equal because the map is
+    non-decreasing -- and re-rounding a rounded value changes nothing.  Dense sweeps of consecutive fp32 values across bf16 boundaries."""
+    import numpy as np
+    import torch
+
+    def f(u):
+        h = u.bfloat16().float()
+        return h + (u - h).bfloat16().float()
+    for base in (1.0, 3.14159, 0.007, 1234.5, -2.5):
+        b = int(np.float32(base).view(np.uint32))
+        bits = np.arange(b - (1 << 17), b + (1 << 17), dtype=np.uint32)
+        u = torch.from_numpy(bits.view(np.float32).copy())
+        u, _ = u.sort()
+        v = f(u)
+        assert bool((v[1:] >= v[:-1]).all())
+        assert bool((f(v) == v).all())
+        assert float(((v - u).abs() / u.abs()).max()) < 2 ** -16
