@@ -986,9 +986,20 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
 static int choose_ksplit(const ConvKParams& p) {
   const int nk = (p.K + 63) / 64;
   if (nk < 64) return 1;
-  for (int i = 0; i < p.nseg; ++i)
-    if (p.segB[i] > 0 && (long long)p.segOH[i] * p.segOW[i] > 256) return 1;
-  return nk / 16;                       // slices of ~16 K-steps
+  long long rows16 = 0;                 // GEMM rows of a NOMINAL batch of 16 images (the batch size itself must not enter: see above)
+  for (int i = 0; i < p.nseg; ++i) {
+    if (p.segB[i] <= 0) continue;
+    if ((long long)p.segOH[i] * p.segOW[i] > 256) return 1;
+    rows16 += 16ll * p.segOH[i] * p.segOW[i];
+  }
+  static const char* dbg_ks = getenv("AOD_KSPLIT_STEPS");      // (debug: a fixed number of K-steps per slice, the rule of the earlier rounds at 16)
+  if (dbg_ks) { const int per = atoi(dbg_ks); return nk / per > 1 ? nk / per : 1; }
+  // as many slices as fill ONE round of two workgroups per CU with the split launch's 128-row tiles -- one slice more starts a second,
+  // nearly empty round (P6 at 16 x 8 x 8: 36 slices 66.7 us, 24 slices 54.4 us) -- but no slice shorter than 8 K-steps
+  const long long tiles = ((rows16 + 127) / 128) * ((p.N + 127) / 128);
+  long long ks = 512 / (tiles > 0 ? tiles : 1);
+  if (ks > nk / 8) ks = nk / 8;
+  return ks > 1 ? (int)ks : 1;
 }
 
 static int conv_params(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst, const float* pre_scale,
