@@ -986,10 +986,12 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
 static int choose_ksplit(const ConvKParams& p) {
   const int nk = (p.K + 63) / 64;
   if (nk < 64) return 1;
+  static const char* dbg_hw = getenv("AOD_KSPLIT_MAXHW");      // (debug: the largest per-image output that is still split)
+  const long long maxhw = dbg_hw ? atoll(dbg_hw) : 256;
   long long rows16 = 0;                 // GEMM rows of a NOMINAL batch of 16 images (the batch size itself must not enter: see above)
   for (int i = 0; i < p.nseg; ++i) {
     if (p.segB[i] <= 0) continue;
-    if ((long long)p.segOH[i] * p.segOW[i] > 256) return 1;
+    if ((long long)p.segOH[i] * p.segOW[i] > maxhw) return 1;
     rows16 += 16ll * p.segOH[i] * p.segOW[i];
   }
   static const char* dbg_ks = getenv("AOD_KSPLIT_STEPS");      // (debug: a fixed number of K-steps per slice, the rule of the earlier rounds at 16)
