@@ -313,7 +313,7 @@ def main():
         AF.set_precision(precision)
         gstep = GraphedTrainStep(model, opt, opt_L, grad_sync=gsync if world > 1 else None, Labeled=True, Pseudo=False)
         gscore = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'})
-        state = dict(graph_ok=use_graph)
+        state = dict(graph_ok=use_graph, filled=set())
 
         def step(it=0, do_train=do_train, do_score=do_score, graph=None, defer=False):
             """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python.
@@ -325,7 +325,17 @@ def main():
                     gstep(data)
                 if do_score:
                     ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                    _, unc = gscore(pool['img'], pool['img_metas'], ids, defer=defer and world == 1)
+                    # the synthetic pool batch is resident in HBM (contract): it sits in the static input buffer of EACH of the scoring graph's
+                    # alternating slots -- where the on-device pool generator / a loader's H2D copy writes a real batch (graphs.static_image) --
+                    # so no 50 MB device-to-device copy rides in the step
+                    img = pool['img']
+                    si = gscore.static_image(tuple(img.shape))
+                    if si is not None:
+                        if si.data_ptr() not in state['filled']:
+                            si.copy_(img)
+                            state['filled'].add(si.data_ptr())
+                        img = si
+                    _, unc = gscore(img, pool['img_metas'], ids, defer=defer and world == 1)
                     if world > 1:
                         gather_scores(unc, B * world)
                 return
@@ -370,9 +380,6 @@ def main():
             nonlocal data, pool
             if do_train and getattr(gstep, 'cur', None) and tuple(gstep.cur['static']['img'].shape) == tuple(data['img'].shape):
                 data = dict(data, img=gstep.cur['static']['img'])
-            si = gscore.static_image(tuple(pool['img'].shape)) if do_score else None
-            if si is not None:
-                pool = dict(pool, img=si)
         for i in range(warmup):
             step(i)
         barrier()
