@@ -1208,6 +1208,9 @@ class RetinaLossFn(Function):
     def forward(ctx, cls_score, bbox_pred, labels, label_w, bbox_t, bbox_w, gamma, alpha, num_classes, arena=None, level=0):
         B, AC, H, W = cls_score.shape
         ctx.arena, ctx.level = arena, level
+        # (an output nobody differentiates -- the loss_noR rows, which train_step detaches -- arrives as None in backward instead of a
+        # zero-filled tensor of its size that backward would then add the row-sum gradient to: two launches per level)
+        ctx.set_materialize_grads(False)
         A = AC // num_classes
         cls_rows = as_rows(cls_score).view(-1, num_classes)
         box_rows = as_rows(bbox_pred).view(-1, 4)

@@ -73,6 +73,7 @@ class SSDLossFn(Function):
     @staticmethod
     def forward(ctx, cls, bbox, labels, label_w, bbox_t, bbox_w, num_classes, neg_pos_ratio, beta):
         B, A, C1 = cls.shape
+        ctx.set_materialize_grads(False)          # (an undifferentiated output arrives as None in backward, not as a zero-filled tensor)
         cls, bbox = cls.contiguous(), bbox.contiguous()
         labels, label_w, bbox_t, bbox_w = labels.contiguous(), label_w.contiguous(), bbox_t.contiguous(), bbox_w.contiguous()
         ce = torch.empty(B, A, device=cls.device)
