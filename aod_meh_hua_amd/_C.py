@@ -70,6 +70,8 @@ _SIGS = {
     'aod_nchw_f32_to_nhwc_bf16': (C.c_int, [P, P, I32, I32, I32, I32, I32, P]),
     'aod_nchw_f32_to_s2d_bf16': (C.c_int, [P, P, I32, I32, I32, I32, P]),
     'aod_stem_pool_fwd': (C.c_int, [P, P, P, P, P, I32, I32, I32, P]),
+    'aod_set_deterministic': (C.c_int, [I32]),
+    'aod_get_deterministic': (C.c_int, []),
     'aod_stem_pool_x3_fwd': (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, P]),
     'aod_maxpool3x3s2': (C.c_int, [P, P, I32, I32, I32, I32, P]),
     'aod_upsample2x_add': (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P]),

@@ -40,6 +40,11 @@ static inline bool aod_first_on_device(unsigned long long* mask) {
   return true;
 }
 
+// deterministic mode (determinism.hip): per-device scratch for partial column sums (nullptr when the mode is off or the request is too large:
+// the caller keeps its atomic path) and the ordered row sum into the destination vector(s)
+float* aod_det_scratch(size_t floats);
+int aod_colsum_finalize(const float* ws, int nparts, int pitch, int N, float* dst, float* dst2, long long ws2_off, hipStream_t st);
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 

@@ -38,6 +38,8 @@ struct ConvKParams {
   int x3;             // reference-precision mode (aod_conv_desc_t.x3): operands in the X-layout, three MFMAs per 32 channels (see X3 below)
   int tap_inner;      // X3: K-steps run (channel chunk, tap) with the TAP innermost (see the loaders)
   int bigrows;        // some segment has >= 2^22 rows: the float-reciprocal row decode is not exact, use integer division
+  float* cs_ws;       // deterministic mode (determinism.hip): partial column sums go to row (group * tiles_m + tile_m) of this scratch [..][N]
+                      // (split-K finalize: row = its row block) instead of into fp32 atomics; the launcher adds the rows in order afterwards
   int up_w, up_hw;    // > 0: LATTICE launch (conv_params): the GEMM rows are the pixels (b, y, x) of the source map and row (b, y, x) is stored
                       // at row b * up_hw + 2y * up_w + 2x of the destination -- the in-place 1x1 / stride-2 dgrad, whose other rows do not change
   long long x_bytes, w_bytes;
@@ -823,7 +825,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     if (t < BN && n0 + t < p.N) {
       float s = 0.f;
       for (int r = 0; r < NT / NCH; ++r) s += sr[r * BN + t];
-      atomicAdd(g_colsum + n0 + t, s);
+      if (p.cs_ws) p.cs_ws[((long long)gi * p.tiles_m + tile_m) * p.N + n0 + t] = s;
+      else atomicAdd(g_colsum + n0 + t, s);
     }
   }
 }
@@ -846,7 +849,19 @@ static int launch_conv(const ConvKParams& p, hipStream_t st) {
   if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  // deterministic mode: partial column sums per (group, row tile) into the scratch, added in order below (a split-K launch has no epilogue
+  // of its own: conv_splitk_finalize_kernel takes the scratch)
+  bool any_cs = q.colsum != nullptr;
+  if (GROUPED) for (int g = 0; g < q.ngroups; ++g) any_cs = any_cs || q.grp[g].colsum;
+  const int ng = GROUPED ? q.ngroups : 1;
+  if (q.ksplit == 1) q.cs_ws = any_cs ? aod_det_scratch((size_t)ng * q.tiles_m * q.N) : nullptr;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NT, OPS, GROUPED, ST, X3>), dim3(q.tiles_m * q.tiles_n * (q.ngroups > 1 ? q.ngroups : q.ksplit)), dim3(NT), lds, st, q);
+  if (q.ksplit == 1 && q.cs_ws) {
+    for (int g = 0; g < ng; ++g) {
+      float* dst = GROUPED ? q.grp[g].colsum : q.colsum;
+      if (dst) { const int rc = aod_colsum_finalize(q.cs_ws + (size_t)g * q.tiles_m * q.N, q.tiles_m, q.N, q.N, dst, nullptr, 0, st); if (rc) return rc; }
+    }
+  }
   return 0;
 }
 
@@ -974,7 +989,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
       float s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) s2 += sr[r][t];
-      atomicAdd(p.colsum + c, s2);
+      if (p.cs_ws) p.cs_ws[(long long)blockIdx.x * p.N + c] = s2;
+      else atomicAdd(p.colsum + c, s2);
     }
   }
 }
@@ -1091,8 +1107,10 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     if (p.x3) { if (p.N > 64) launch_conv<128, 128, 256, 2, false, 2, true>(p, st); else launch_conv<128, 64, 256, 2, false, 2, true>(p, st); }
     else if (p.N > 64) launch_conv<128, 128>(p, st); else launch_conv<128, 64>(p, st);
     AOD_LAUNCH_CHECK();
+    p.cs_ws = p.colsum ? aod_det_scratch((size_t)((p.M + 7) / 8) * p.N) : nullptr;
     hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((p.M + 7) / 8, (p.N + 255) / 256), dim3(256), 0, st, p);
     AOD_LAUNCH_CHECK();
+    if (p.cs_ws) return aod_colsum_finalize(p.cs_ws, (p.M + 7) / 8, p.N, p.N, p.colsum, nullptr, 0, st);
     return 0;
   }
   // tile choice: the largest tile that still gives >= 2 workgroups per CU (2 x 256); else the most workgroups

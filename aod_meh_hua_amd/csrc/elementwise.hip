@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ g
                                                       const float* __restrict__ scale, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, bf16_t* __restrict__ dz,
                                                       bf16_t* __restrict__ gm_out, float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                      long long M, int N, int relu, int rows_per_block) {
+                                                      long long M, int N, int relu, int rows_per_block, float* __restrict__ cs_ws) {
   __shared__ float sb[8][256 + 8], sg[8][256 + 8];
   const int t = threadIdx.x;
   const int cc = t & 31, rl = t >> 5;
@@ -261,8 +261,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ g
       float b = 0.f, gsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) { b += sb[r][col]; gsum += sg[r][col]; }
-      if (dbeta) atomicAdd(dbeta + nn, b);
-      if (dgamma && z) atomicAdd(dgamma + nn, gsum);
+      if (cs_ws) {        // deterministic mode: this block's strip is row blockIdx.y of two partial images (dbeta | dgamma), added in order afterwards
+        cs_ws[(long long)blockIdx.y * N + nn] = b;
+        cs_ws[((long long)gridDim.y + blockIdx.y) * N + nn] = gsum;
+      } else {
+        if (dbeta) atomicAdd(dbeta + nn, b);
+        if (dgamma && z) atomicAdd(dgamma + nn, gsum);
+      }
     }
   }
 }
@@ -280,13 +285,18 @@ extern "C" int aod_act_bwd(const void* g, const void* a, const void* z, const fl
   if (rpb < 64) rpb = 64;
   rpb = (rpb + 7) / 8 * 8;
   const int gy = (int)((M + rpb - 1) / rpb);
+  float* const cs_ws = (dbeta || (dgamma && z)) ? aod_det_scratch((size_t)2 * gy * N) : nullptr;
   if (g_is_f32)
     hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(panels, gy), dim3(256), 0, (hipStream_t)stream, g, (const bf16_t*)a, (const bf16_t*)z, scale, mean,
-                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb);
+                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb, cs_ws);
   else
     hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(panels, gy), dim3(256), 0, (hipStream_t)stream, g, (const bf16_t*)a, (const bf16_t*)z, scale, mean,
-                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb);
+                       invstd, (bf16_t*)dz, (bf16_t*)gmask_out, dbeta, dgamma, (long long)M, N, relu, (int)rpb, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) {
+    if (dbeta) { const int rc = aod_colsum_finalize(cs_ws, gy, N, N, dbeta, (dgamma && z) ? dgamma : nullptr, (long long)gy * N, (hipStream_t)stream); if (rc) return rc; }
+    else if (dgamma && z) return aod_colsum_finalize(cs_ws + (size_t)gy * N, gy, N, N, dgamma, nullptr, 0, (hipStream_t)stream);
+  }
   return 0;
 }
 
@@ -377,7 +387,8 @@ extern "C" int aod_sgd_multi(void* const* params, void* const* grads, void* cons
 // every lane busy, and each thread has four independent rows in flight.
 template <bool G_F32>
 __global__ __launch_bounds__(256) void pad_cast_colsum_kernel(const void* __restrict__ g_, const float* __restrict__ a, bf16_t* __restrict__ dz,
-                                                              float* __restrict__ colsum, long long M, int N, int Npad, int rows_per_block, int TC) {
+                                                              float* __restrict__ colsum, long long M, int N, int Npad, int rows_per_block, int TC,
+                                                              float* __restrict__ cs_ws) {
   __shared__ float red[256];
   const int RP = 256 / TC;
   const int c0 = threadIdx.x % TC, rl = threadIdx.x / TC;
@@ -409,7 +420,8 @@ __global__ __launch_bounds__(256) void pad_cast_colsum_kernel(const void* __rest
     if (rl == 0 && c < N) {
       float tsum = 0.f;
       for (int r = 0; r < RP; ++r) tsum += red[r * TC + c0];
-      atomicAdd(colsum + c, tsum);
+      if (cs_ws) cs_ws[(long long)blockIdx.x * N + c] = tsum;
+      else atomicAdd(colsum + c, tsum);
     }
   }
 }
@@ -422,9 +434,11 @@ extern "C" int aod_pad_cast_colsum(const void* g, const float* relu_out_f32, voi
   const int nb = (int)((M + rpb - 1) / rpb);
   int tc = 8;
   while (tc < Npad && tc < 256) tc <<= 1;
-  if (g_is_f32) hipLaunchKernelGGL((pad_cast_colsum_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc);
-  else hipLaunchKernelGGL((pad_cast_colsum_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc);
+  float* const cs_ws = aod_det_scratch((size_t)nb * N);
+  if (g_is_f32) hipLaunchKernelGGL((pad_cast_colsum_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc, cs_ws);
+  else hipLaunchKernelGGL((pad_cast_colsum_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Npad, rpb, tc, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) return aod_colsum_finalize(cs_ws, nb, N, N, colsum, nullptr, 0, (hipStream_t)stream);
   return 0;
 }
 

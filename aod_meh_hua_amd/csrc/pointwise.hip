@@ -370,6 +370,7 @@ bool aod_pw_wants(const PwArgs& a) {
   static const char* dbg = getenv("AOD_PW_STREAM");
   const int mode = g_pw_mode >= 0 ? g_pw_mode : ((dbg && (dbg[0] == '0' || dbg[0] == '1')) ? dbg[0] - '0' : -1);
   if (mode == 0) return false;
+  if (a.colsum && aod_det_scratch(1)) return false;      // deterministic mode: column sums only through the general kernel's ordered partials
   if (a.K % 64 != 0 || a.N % 64 != 0 || a.N > PW_NMAX || a.M < 1) return false;
   if ((long long)a.M * a.K * 2 >= 0xe0000000ll || (long long)a.M * a.N * 2 >= 0xe0000000ll) return false;
   if (mode == 1) return true;

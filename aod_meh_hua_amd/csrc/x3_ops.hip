@@ -214,7 +214,7 @@ extern "C" int aod_x3_upsample2x_add_bwd_set(const void* g_dst, void* g_src, int
 // ---------------------------------------------------------------- activation backward + column sums: dz = g * [a > 0], colsum[c] += sum_m dz
 // Block = 32 octets (256 logical columns) x 8 row lanes over a strip of rows; column sums through LDS, one atomic per column and block.
 __global__ __launch_bounds__(256) void x3_act_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a, bf16_t* __restrict__ dz,
-                                                         float* __restrict__ colsum, long long M, int Q, int relu, int rows_per_block) {
+                                                         float* __restrict__ colsum, long long M, int Q, int relu, int rows_per_block, float* __restrict__ cs_ws) {
   __shared__ float sb[8][256 + 8];
   const int t = threadIdx.x, cc = t & 31, rl = t >> 5;
   const int q = blockIdx.x * 32 + cc;
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void x3_act_bwd_kernel(const bf16_t* __restric
     float b = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) b += sb[r][t];
-    atomicAdd(colsum + n, b);
+    if (cs_ws) cs_ws[(long long)blockIdx.y * (Q * 8) + n] = b;      // (deterministic mode: row = this block's strip, added in order by the launcher)
+    else atomicAdd(colsum + n, b);
   }
 }
 extern "C" int aod_x3_act_bwd(const void* g, const void* a, void* dz, float* colsum, int64_t M, int C, int relu, aod_stream_t stream) {
@@ -259,16 +260,20 @@ extern "C" int aod_x3_act_bwd(const void* g, const void* a, void* dz, float* col
   long long rpb = (M + want - 1) / want;
   if (rpb < 64) rpb = 64;
   rpb = (rpb + 7) / 8 * 8;
-  hipLaunchKernelGGL(x3_act_bwd_kernel, dim3(panels, (int)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)a,
-                     (bf16_t*)dz, colsum, (long long)M, Q, relu, (int)rpb);
+  const int gy = (int)((M + rpb - 1) / rpb);
+  float* const cs_ws = colsum ? aod_det_scratch((size_t)gy * Q * 8) : nullptr;
+  hipLaunchKernelGGL(x3_act_bwd_kernel, dim3(panels, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)a,
+                     (bf16_t*)dz, colsum, (long long)M, Q, relu, (int)rpb, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) return aod_colsum_finalize(cs_ws, gy, Q * 8, Q * 8, colsum, nullptr, 0, (hipStream_t)stream);
   return 0;
 }
 
 // ---------------------------------------------------------------- fp32 head gradients -> X rows (+ fused ReLU of retina_L) + column sums
 // g fp32 [M][N] (N = 180 / 36 / 9) -> dz X rows of 2 * ceil32(N) columns, zero in the pad channels; colsum fp32 [ceil32(N)]
 __global__ __launch_bounds__(256) void x3_pad_cast_colsum_kernel(const float* __restrict__ g, const float* __restrict__ a, bf16_t* __restrict__ dz,
-                                                                 float* __restrict__ colsum, long long M, int N, int Np, int rows_per_block, int TC) {
+                                                                 float* __restrict__ colsum, long long M, int N, int Np, int rows_per_block, int TC,
+                                                                 float* __restrict__ cs_ws) {
   __shared__ float red[256];
   const int RP = 256 / TC;
   const int c0 = threadIdx.x % TC, rl = threadIdx.x / TC;
@@ -296,7 +301,8 @@ __global__ __launch_bounds__(256) void x3_pad_cast_colsum_kernel(const float* __
     if (rl == 0 && c < N) {
       float tsum = 0.f;
       for (int r = 0; r < RP; ++r) tsum += red[r * TC + c0];
-      atomicAdd(colsum + c, tsum);
+      if (cs_ws) cs_ws[(long long)blockIdx.x * N + c] = tsum;
+      else atomicAdd(colsum + c, tsum);
     }
   }
 }
@@ -308,9 +314,12 @@ extern "C" int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32,
   if (rpb < 16) rpb = 16;
   int tc = 32;
   while (tc < Np && tc < 256) tc <<= 1;
-  hipLaunchKernelGGL(x3_pad_cast_colsum_kernel, dim3((int)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum,
-                     (long long)M, N, Np, rpb, tc);
+  const int nb = (int)((M + rpb - 1) / rpb);
+  float* const cs_ws = aod_det_scratch((size_t)nb * N);
+  hipLaunchKernelGGL(x3_pad_cast_colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum,
+                     (long long)M, N, Np, rpb, tc, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) return aod_colsum_finalize(cs_ws, nb, N, N, colsum, nullptr, 0, (hipStream_t)stream);
   return 0;
 }
 

@@ -302,8 +302,15 @@ class BwdChain:
 def bwd_chain_for(blk, x):
     """a BwdChain for a block whose training forward qualifies for the fused kernels (same conditions; AOD_FUSE_BOTTLENECK_BWD=0 switches
     the fused backward off), else None"""
-    on = _os.environ.get('AOD_FUSE_BOTTLENECK_BWD', '1') != '0'
+    on = _os.environ.get('AOD_FUSE_BOTTLENECK_BWD', '1') != '0' and not ho.DETERMINISTIC     # (the fused chain sums its columns with atomics of its own)
     return BwdChain() if on and _FUSE_ACT and bottleneck128_train_applies(blk, x) else None
+
+
+def set_deterministic(on=True):
+    """the reference's `--deterministic` (tools/train_RetinaNet.py:56-68 -> cudnn.deterministic): bias / BN-shift column sums as ordered sums
+    of per-workgroup partials instead of fp32 atomics (aod_set_deterministic; everything else on the training path is ordered by
+    construction).  Call on the training device, outside a graph capture; graphs captured before the switch keep their old kernels."""
+    ho.set_deterministic(on)
 
 
 class GradAcc:

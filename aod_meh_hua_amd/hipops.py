@@ -18,6 +18,15 @@ from ._C import ConvDesc, ConvSeg, call, lib, ptr, stream
 # tensor of c logical channels has xw(c) = 2 * ceil32(c) columns [h(0..31) | l(0..31) | h(32..63) | ...], value = head + tail -- and the
 # descriptors carry x3 = 1.  The wrappers below take and return such rows when X3 is set; channel COUNTS passed to them (N, Cin) stay logical.
 X3 = False
+DETERMINISTIC = False       # aod_set_deterministic (functional.set_deterministic): ordered column sums
+
+
+def set_deterministic(on=True):
+    global DETERMINISTIC
+    rc = lib.aod_set_deterministic(1 if on else 0)
+    if rc < 0:
+        raise RuntimeError(lib.aod_last_error().decode())
+    DETERMINISTIC = bool(on)
 
 
 def xw(c):

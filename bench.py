@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'],
                     help='arithmetic of the conv stack: bf16x3 = reference precision (fp32-grade products from bf16 head/tail pairs; the default, the '
                          'reference is fp32), bf16 = plain bf16 operands (faster, residuals ~1e-2)')
+    ap.add_argument('--deterministic', action='store_true', help='ordered bias / BN-shift column sums (functional.set_deterministic): bit-repeatable runs, ~1 %% slower')
     ap.add_argument('--phase-iters', type=int, default=50, help='iterations of each per-phase rate (SURVEY 8d: >= 50)')
     ap.add_argument('--no-precision-check', action='store_true', help='skip the short run in the OTHER precision mode after the timed region (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -264,6 +265,9 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (a line must not measure fewer ranks than it names)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if args.deterministic:
+        from aod_meh_hua_amd import functional as _AF
+        _AF.set_deterministic(True)
     if world > 1:
         import torch.distributed as dist
         if one_gpu:
@@ -552,7 +556,8 @@ def main():
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
                                 parallelism=f'dp{world}', collective_ranks=comm['ranks'], collective_backend=comm['backend'],
                                 phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
-                                arithmetic=PRECISIONS[args.precision][2]),
+                                arithmetic=PRECISIONS[args.precision][2],
+                                column_sums='ordered partial sums (--deterministic)' if args.deterministic else 'fp32 atomics (default)'),
                     phase_rates=main_m['phase'], hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

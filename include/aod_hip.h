@@ -95,6 +95,14 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
  * N <= 2048).  Process-wide; results of the two kernels are bit-identical (tests/test_gpu_kernels.py).  Returns the previous mode. */
 int aod_set_pointwise_mode(int mode);
 
+/* Deterministic mode (the reference's `--deterministic`, tools/train_RetinaNet.py:56-68 -> cudnn.deterministic): on = 1 makes the bias /
+ * BN-shift column sums of the dgrad epilogues and of the activation-backward / pad-cast passes -- the only order-dependent reduction of
+ * the training path (fp32 atomics otherwise) -- sums of per-workgroup partials in a fixed order (csrc/determinism.hip; one small extra
+ * launch per vector).  Two runs from the same state are then bit-identical.  Allocates a 32 MB scratch on the CURRENT device the first time
+ * it is switched on there (call it outside a graph capture, once per device).  Process-wide; returns the previous setting. */
+int aod_set_deterministic(int on);
+int aod_get_deterministic(void);
+
 /* A whole 64-channel ResNet bottleneck, forward only (mmdet/models/backbones/resnet.py:262-301 with eval-mode BN; layer1 is frozen,
  * resnet.py:612-628, so nothing of it is needed by the backward pass either):
  *   y = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(relu(bn1(conv1_1x1(x)))))))) + res)

@@ -54,7 +54,8 @@ def parse_args(default_config='configs/_base_/Config_RetinaNet.py', default_size
     group_gpus.add_argument('--gpu-ids', type=int, default=None, nargs='+', help='ids of gpus to use (only applicable to non-distributed training)')
     p.add_argument('--deterministic', action='store_true',
                    help='the reference sets cuDNN to deterministic here; the HIP kernels reduce in a fixed order already (slab-ordered weight '
-                        'gradients, ordered split-K) except the fp32-atomic column sums of bias / BN-shift gradients -- the flag is accepted and logged')
+                        'gradients, ordered split-K) except the fp32-atomic column sums of bias / BN-shift gradients -- the flag switches those '
+                        'to ordered partial sums as well (aod_set_deterministic: two runs from the same state are then bit-identical; ~1 %% slower)')
     p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none', help='job launcher')
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--Unc-type', type=str)
@@ -151,8 +152,10 @@ def main(default_config='configs/_base_/Config_RetinaNet.py', default_size=512):
     logger = get_root_logger(log_file=osp.join(cfg.work_dir, f'{timestamp}.log'), log_level=cfg.log_level)
     meta = dict(exp_name=osp.basename(args.config))
     if args.deterministic:
+        from aod_meh_hua_amd import functional as _AF
+        _AF.set_deterministic(True)
         logger.info('--deterministic: weight gradients and split-K sums are reduced in a fixed order by construction; bias / BN-shift column sums '
-                    'use fp32 atomics (last-bit run-to-run differences)')
+                    'now as ordered partial sums too (aod_set_deterministic)')
     # train_RetinaNet.py:139-141: 8 loader workers when started from a shell, else 0; here: 8 for real image data (AOD_WORKERS overrides), 0 for
     # the synthetic pool (its samples are generated in-process)
     cfg.data.workers_per_gpu = 0 if args.synthetic else int(os.environ.get('AOD_WORKERS', 8))
