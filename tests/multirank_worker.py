@@ -77,6 +77,9 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(0)
     dist.init_process_group('gloo')
+    if os.environ.get('MULTIRANK_DETERMINISTIC', '0') == '1':       # ordered column sums (functional.set_deterministic)
+        from aod_meh_hua_amd import functional as AF
+        AF.set_deterministic(True)
     from aod_meh_hua_amd.graphs import GraphedTrainStep
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model
     res = {}
