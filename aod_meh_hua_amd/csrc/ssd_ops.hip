@@ -109,11 +109,38 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const bf16_t* __restric
   const float n = sqrtf(ss) + eps;
   for (int c = lane; c < C; c += 64) y[r * C + c] = (bf16_t)(w[c] * (float)x[r * C + c] / n);
 }
+// (cs_ws: deterministic mode -- the four rows of a block are added in wave order through LDS and stored as ONE partial row per block, which
+// aod_colsum_finalize adds in block order; C <= 1024 there)
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ g,
-                                                         bf16_t* __restrict__ gx, float* __restrict__ gw, long long rows, int C, float eps) {
+                                                         bf16_t* __restrict__ gx, float* __restrict__ gw, long long rows, int C, float eps,
+                                                         float* __restrict__ cs_ws) {
+  __shared__ float sm[4][1024];
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
   const int lane = threadIdx.x & 63;
+  if (cs_ws) {
+    const int wv = threadIdx.x >> 6;
+    float n = 1.f, k = 0.f;
+    if (r < rows) {
+      float ss = 0.f, dot = 0.f;
+      for (int c = lane; c < C; c += 64) { const float v = (float)x[r * C + c]; ss += v * v; dot += w[c] * (float)g[r * C + c] * v; }
+      ss = wave_sum(ss); dot = wave_sum(dot);
+      const float nrm = sqrtf(ss);
+      n = nrm + eps; k = nrm > 0.f ? dot / (n * n * nrm) : 0.f;
+    }
+    for (int c = lane; c < C; c += 64) {
+      float contrib = 0.f;
+      if (r < rows) {
+        const float v = (float)x[r * C + c], gg = (float)g[r * C + c];
+        gx[r * C + c] = (bf16_t)(w[c] * gg / n - k * v);
+        contrib = gg * v / n;
+      }
+      sm[wv][c] = contrib;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) cs_ws[(long long)blockIdx.x * C + c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
+    return;
+  }
+  if (r >= rows) return;
   float ss = 0.f, dot = 0.f;
   for (int c = lane; c < C; c += 64) {
     const float v = (float)x[r * C + c];
@@ -139,9 +166,12 @@ extern "C" int aod_l2norm_fwd(const void* x, const float* w, void* y, int64_t ro
 extern "C" int aod_l2norm_bwd(const void* x, const float* w, const void* g, void* gx, float* gw, int64_t rows, int C, float eps, aod_stream_t stream) {
   if (rows == 0) return 0;
   AOD_CHECK_ARG(x && w && g && gx && gw, "l2norm_bwd: null");
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (const bf16_t*)g, (bf16_t*)gx,
-                     gw, (long long)rows, C, eps);
+  const int nb = (int)((rows + 3) / 4);
+  float* const cs_ws = C <= 1024 ? aod_det_scratch((size_t)nb * C) : nullptr;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (const bf16_t*)g, (bf16_t*)gx,
+                     gw, (long long)rows, C, eps, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) return aod_colsum_finalize(cs_ws, nb, C, C, gw, nullptr, 0, (hipStream_t)stream);
   return 0;
 }
 

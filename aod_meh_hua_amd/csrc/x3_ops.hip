@@ -452,11 +452,47 @@ __global__ __launch_bounds__(256) void x3_l2norm_fwd_kernel(const bf16_t* __rest
     xstore(y + r * CP + xoct(q), v);
   }
 }
+// (cs_ws: deterministic mode, see l2norm_bwd_kernel in ssd_ops.hip; Q * 8 <= 1024 logical channels there)
 __global__ __launch_bounds__(256) void x3_l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const bf16_t* __restrict__ g,
-                                                            bf16_t* __restrict__ gx, float* __restrict__ gw, long long rows, int Q, float eps) {
+                                                            bf16_t* __restrict__ gx, float* __restrict__ gw, long long rows, int Q, float eps,
+                                                            float* __restrict__ cs_ws) {
+  __shared__ float sm[4][1024];
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
   const int lane = threadIdx.x & 63, CP = (Q >> 2) * 64;
+  if (cs_ws) {
+    const int wv = threadIdx.x >> 6;
+    float n = 1.f, kk = 0.f;
+    if (r < rows) {
+      float ss = 0.f, dot = 0.f;
+      for (int q = lane; q < Q; q += 64) {
+        float v[8], gg[8];
+        xload(x + r * CP + xoct(q), v); xload(g + r * CP + xoct(q), gg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ss += v[j] * v[j]; dot += w[q * 8 + j] * gg[j] * v[j]; }
+      }
+      ss = wave_sum(ss); dot = wave_sum(dot);
+      const float nrm = sqrtf(ss);
+      n = nrm + eps; kk = nrm > 0.f ? dot / (n * n * nrm) : 0.f;
+    }
+    for (int q = lane; q < Q; q += 64) {
+      float c8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c8[j] = 0.f;
+      if (r < rows) {
+        float v[8], gg[8], o[8];
+        xload(x + r * CP + xoct(q), v); xload(g + r * CP + xoct(q), gg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = w[q * 8 + j] * gg[j] / n - kk * v[j]; c8[j] = gg[j] * v[j] / n; }
+        xstore(gx + r * CP + xoct(q), o);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm[wv][q * 8 + j] = c8[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Q * 8; c += 256) cs_ws[(long long)blockIdx.x * (Q * 8) + c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
+    return;
+  }
+  if (r >= rows) return;
   float ss = 0.f, dot = 0.f;
   for (int q = lane; q < Q; q += 64) {
     float v[8], gg[8];
@@ -485,8 +521,11 @@ extern "C" int aod_x3_l2norm_fwd(const void* x, const float* w, void* y, int64_t
 extern "C" int aod_x3_l2norm_bwd(const void* x, const float* w, const void* g, void* gx, float* gw, int64_t rows, int C, float eps, aod_stream_t stream) {
   if (rows == 0) return 0;
   AOD_CHECK_ARG(x && w && g && gx && gw && C % 64 == 0, "x3_l2norm_bwd: bad args");
-  hipLaunchKernelGGL(x3_l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (const bf16_t*)g, (bf16_t*)gx,
-                     gw, (long long)rows, C / 16, eps);
+  const int nb = (int)((rows + 3) / 4), CL = C / 2;
+  float* const cs_ws = CL <= 1024 ? aod_det_scratch((size_t)nb * CL) : nullptr;
+  hipLaunchKernelGGL(x3_l2norm_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (const bf16_t*)g, (bf16_t*)gx,
+                     gw, (long long)rows, C / 16, eps, cs_ws);
   AOD_LAUNCH_CHECK();
+  if (cs_ws) return aod_colsum_finalize(cs_ws, nb, CL, CL, gw, nullptr, 0, (hipStream_t)stream);
   return 0;
 }

@@ -70,3 +70,39 @@ def test_deterministic_mode_repeats_bit_for_bit(prec):
         AF.set_deterministic(False)
         AF.set_precision('bf16')
     assert lib.aod_get_deterministic() == 0
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+def test_l2norm_scale_gradient_is_ordered_in_the_deterministic_mode(prec):
+    """SSD's L2Norm (config 0): its scale gradient is a column sum over every pixel -- per-element fp32 atomics by default, ordered per-block
+    partials in the deterministic mode (csrc/ssd_ops.hip, csrc/x3_ops.hip)"""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd.functional_ssd import l2norm
+    AF.set_precision(prec)
+    try:
+        g = torch.Generator(device='cuda').manual_seed(6)
+        B, C, H, W = 3, 512, 38, 37
+        x = torch.randn(B, C, H, W, device='cuda', generator=g) * 3
+        go = torch.randn(B, C, H, W, device='cuda', generator=g)
+        rows = lambda t: (ho.x3_split(t.permute(0, 2, 3, 1).reshape(-1, C).contiguous()) if prec == 'bf16x3'
+                          else t.permute(0, 2, 3, 1).reshape(-1, C).contiguous().bfloat16())
+        w = (torch.rand(C, device='cuda', generator=g) * 10 + 15)
+
+        def grad_w():
+            xd = AF.as_nchw(rows(x), B, H, W).requires_grad_(True)
+            wd = w.clone().requires_grad_(True)
+            y = l2norm(xd, wd, 1e-10)
+            y.backward(AF.as_nchw(rows(go), B, H, W))
+            torch.cuda.synchronize()
+            return wd.grad.clone(), xd.grad.clone()
+        free_w, free_x = grad_w()
+        AF.set_deterministic(True)
+        a_w, a_x = grad_w()
+        b_w, b_x = grad_w()
+        assert torch.equal(a_w, b_w) and torch.equal(a_x, b_x)
+        assert torch.equal(a_x, free_x)
+        assert float((a_w - free_w).abs().max() / free_w.abs().max()) < 1e-5
+    finally:
+        AF.set_deterministic(False)
+        AF.set_precision('bf16')
