@@ -275,6 +275,12 @@ def get_precision():
     return _PREC
 
 
+def mode_key():
+    """what a captured HIP graph's kernels depend on besides shapes: the arithmetic mode and the deterministic switch (graphs.py keys its
+    caches with it -- a graph captured in one mode must not be replayed for a call made in the other)"""
+    return (_PREC, bool(ho.DETERMINISTIC))
+
+
 class ActSlot:
     """Side channel between a conv and the ONE conv that consumes its ReLU output.  The consumer's dgrad epilogue applies the producer's
     ReLU mask and sums the columns (aod_conv2d res / mask / colsum), so the producer's backward receives the finished masked gradient and

@@ -78,18 +78,18 @@ class GraphedTrainStep:
         """(batch tensor shape, per-image pad shapes).  Heads that read their valid-anchor flags from the static buffer
         (L_AnchorHead.get_targets_batch) make the second part irrelevant: __call__ then matches on the tensor shape alone, so the
         aspect-ratio-grouped keep-ratio VOC batches -- a dozen padded shapes, thousands of per-image shape combinations -- replay."""
-        return (tuple(d['img'].shape), tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in d['img_metas']))
+        return (tuple(d['img'].shape), tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in d['img_metas']), AF.mode_key())
 
     def _lookup(self, sig):
         ent = self.cache.pop(sig, None)
         if ent is None:
             for k in list(self.cache):
-                if k[0] == sig[0] and self.cache[k]['static'].get('valid_fn') is not None:
+                if k[0] == sig[0] and k[2] == sig[2] and self.cache[k]['static'].get('valid_fn') is not None:
                     return self.cache.pop(k)
         return ent
 
     def _known(self, sig):
-        return sig in self.cache or any(k[0] == sig[0] and e['static'].get('valid_fn') is not None for k, e in self.cache.items())
+        return sig in self.cache or any(k[0] == sig[0] and k[2] == sig[2] and e['static'].get('valid_fn') is not None for k, e in self.cache.items())
 
     def _load(self, d):
         st = self.cur['static']
@@ -409,7 +409,7 @@ class GraphedScore:
         """The input buffer the NEXT call with image batches of `shape` replays on (None while no graph of that shape exists): a producer that
         writes the batch there -- the on-device pool generator, a loader's H2D copy -- saves the device-to-device copy into it.  The caller's
         stream is made to wait until the slot's previous conv half has read it."""
-        ent = self.cache.get(tuple(shape))
+        ent = self.cache.get((tuple(shape), AF.mode_key()))
         if ent is None:
             return None
         sl = ent['slots'][ent['n'] % len(ent['slots'])]
@@ -419,7 +419,7 @@ class GraphedScore:
 
     def maybe(self, img, img_metas, image_ids, defer=False):
         """Replay if this batch shape is captured, capture if it repeats the previous batch's shape, else None (caller scores eagerly)."""
-        shape = tuple(img.shape)
+        shape = (tuple(img.shape), AF.mode_key())
         if shape not in self.cache and shape != self.pending:
             self.pending = shape
             return None
@@ -463,7 +463,7 @@ class GraphedScore:
         return graphs
 
     def __call__(self, img, img_metas, image_ids, defer=False):
-        shape = tuple(img.shape)
+        shape = (tuple(img.shape), AF.mode_key())          # (the key: a graph serves one batch shape in one arithmetic / determinism mode)
         ent = self.cache.pop(shape, None)
         if ent is None:
             while self.cache and (len(self.cache) >= self.MAX_GRAPHS or _low_memory(self.dev)):
@@ -477,7 +477,7 @@ class GraphedScore:
             self.module.eval()
             slots = []
             for _ in range(2 if self.pipe else 1):
-                sl = dict(img=torch.empty(shape, dtype=torch.float32, device=self.dev), ids=torch.zeros(B, dtype=torch.int64, device=self.dev),
+                sl = dict(img=torch.empty(tuple(img.shape), dtype=torch.float32, device=self.dev), ids=torch.zeros(B, dtype=torch.int64, device=self.dev),
                           hw=torch.zeros(B, 2, device=self.dev), sc=torch.ones(B, 4, device=self.dev), metas=[dict(m) for m in img_metas],
                           ev_a=None, ev_b=None)
                 self._fill_img(sl, img)

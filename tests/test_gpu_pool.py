@@ -61,7 +61,17 @@ def test_pool_images_equal_the_numpy_philox_restatement():
     assert abs(full.mean()) < 0.02 and abs(full.std() - 1.0) < 0.02
 
 
-def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch):
+@pytest.fixture(params=['bf16', 'bf16x3'])
+def precision(request):
+    """both arithmetic modes: in the reference-precision mode the batch-size independence also rests on the split-K rule (slices chosen from
+    the per-image geometry, conv.hip choose_ksplit) and on the lattice / fused layer-1 launches"""
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision(request.param)
+    yield request.param
+    AF.set_precision('bf16')
+
+
+def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch, precision):
     from aod_meh_hua_amd.apis import test as apis_test
     from aod_meh_hua_amd.apis.test import single_gpu_uncertainty
     from aod_meh_hua_amd.datasets import DevicePhiloxPool
