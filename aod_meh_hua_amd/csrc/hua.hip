@@ -227,11 +227,14 @@ __device__ __forceinline__ float slot_sum(float v) {     // over the 64 / LPP la
 // count up to 96; the sums over a sample's classes cross LPP lanes by shuffle, the sums over samples cross the wave once per pair.
 // EXACT: every lane owns exactly CPL classes (nd == CPL * LPP): no predication in the class loops.
 template <int CPL, int LPP, bool EXACT>
-__global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LPP == 1 && CPL <= 21 ? 4 : 2, LPP == 1 && CPL <= 21 ? 4 : 2))) void hua_sample_kernel(const HuaArgs p) {
   constexpr int SPR = 64 / LPP;                      // samples per wave round
   constexpr bool ALIGNED = LPP == 1 || (EXACT && (CPL % 4) == 0);      // a lane's first class is a multiple of four
   __shared__ float s_red[4][HMAXC + 2];
   __shared__ float s_tot[2];
+  // a sample's gamma variates wait in LDS for the sample's total (one column per thread: conflict-free) instead of in CPL registers -- with
+  // them the 20-class instance needs 147 VGPRs (three waves per SIMD), without 4 waves fit
+  __shared__ float s_g[CPL][256];
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int part = lane % LPP, slot = lane / LPP;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
     const float* sc = p.scores + ((long long)b * p.n + cand) * (p.C + 1);
     const unsigned c2 = (unsigned)p.cand_anchor[(long long)b * p.n + cand];
     const unsigned c3 = (unsigned)p.image_ids[b];
-    float dd[CPL], cc[CPL], binv[CPL], sum_p[CPL];
+    float dd[CPL], binv[CPL], sum_p[CPL];       // (cc = rsq(9 d) is recomputed per variate: one quarter-rate instruction against 20 registers)
     float best = -1.f;
     int am = 0;
 #pragma unroll
@@ -260,7 +263,6 @@ __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
       const bool boost = alpha < 1.f;
       const float a = boost ? alpha + 1.f : alpha;
       dd[c] = a - (1.0f / 3.0f);
-      cc[c] = __builtin_amdgcn_rsqf(9.f * dd[c]);
       binv[c] = boost ? fast_rcp(alpha) : 0.f;                     // u^(1/alpha) = exp2(log2(u) * binv); 0 -> factor 1 (no boost)
       sum_p[c] = 0.f;
     }
@@ -277,7 +279,6 @@ __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
     for (int r = wave; r * SPR < p.num_samples; r += 4) {
       const int s = r * SPR + slot;
       if (s < p.num_samples) {                                     // uniform over the LPP lanes of a sample
-        float g[CPL];
         float tot = 0.f;
         const unsigned cs = ((unsigned)obj << 20) | ((unsigned)s << 7);
         unsigned rb[4] = {0u, 0u, 0u, 0u};
@@ -287,10 +288,13 @@ __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
             const unsigned gc = (unsigned)(c0 + c);
             // boost uniforms: one Philox block per group of four classes, counter word 0 = 1 (the candidates use even words)
             if (ALIGNED ? (c & 3) == 0 : (c == 0 || (gc & 3u) == 0u)) philox4x32_10(1u, cs | (gc >> 2), c2, c3, p.seed_lo, p.seed_hi, rb);
-            float gv = gamma_mt(dd[c], cc[c], cs | gc, c2, c3, p.seed_lo, p.seed_hi);
+            float d_ = dd[c];
+            asm volatile("" : "+v"(d_));          // (opaque: keeps the recomputation of cc inside the sample loop instead of 20 hoisted registers)
+            float gv = gamma_mt(d_, __builtin_amdgcn_rsqf(9.f * d_), cs | gc, c2, c3, p.seed_lo, p.seed_hi);
             gv *= fast_exp2(fast_log2(u01(rb[gc & 3u])) * binv[c]);
-            g[c] = fmaxf(gv, FLT_MIN_F);
-            tot += g[c];
+            gv = fmaxf(gv, FLT_MIN_F);
+            s_g[c][threadIdx.x] = gv;
+            tot += gv;
           }
         }
         tot = part_sum<LPP>(tot);
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void hua_sample_kernel(const HuaArgs p) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           if (EXACT || c < n) {
-            const float pr = fminf(fmaxf(g[c] * inv, FLT_MIN_F), ONE_MINUS_EPS);
+            const float pr = fminf(fmaxf(s_g[c][threadIdx.x] * inv, FLT_MIN_F), ONE_MINUS_EPS);
             ent -= pr * fast_log2(pr);
             sum_p[c] += pr;
           }
