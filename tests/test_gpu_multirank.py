@@ -27,8 +27,10 @@ def test_two_rank_bench_on_one_gpu():
 
 def test_two_rank_replicas_stay_equal_and_match_a_mean_gradient_run():
     """after 3 data-parallel iterations rank 0 and rank 1 hold bit-equal parameters (graph mode and eager mode), .grad
-    is the slice of GradSync's flat buffer (all-reduce in place), and the result equals a 1-process run fed the mean gradient."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    is the slice of GradSync's flat buffer (all-reduce in place), and the result equals a 1-process run fed the mean gradient.  (The fast mode,
+    whatever the suite's default: its 8-bit operands round the column sums' arrival-order noise away; the reference-precision mode has the
+    test below.)"""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', AOD_CONV_PREC='bf16')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29547', os.path.join(ROOT, 'tests', 'multirank_worker.py')]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
