@@ -13,6 +13,10 @@
 //            epilogue in registers: + residual (8-B loads), ReLU, 8-B stores.
 // All three products are computed TRANSPOSED (filter fragment as the MFMA's A operand), so a lane holds 4 consecutive channels of one
 // pixel: the intermediates go to LDS with one ds_write_b64 per 16 x 16 block and the output leaves in 8-B pieces (see pointwise.hip).
+// DS form (the stage's FIRST block, Cin = 64): the residual is the block's downsample branch bn_d(conv_d_1x1(x)) (resnet.py:291-292), computed in the
+// same launch -- the wave's 2 x 16 pixels of x as fragments straight from global memory (L2 hits) against the [256][64] filter, fetched into the
+// dead t1 region once conv2 is done; rounded to bf16 as the separate launch would store it -> the residual registers: identical bits, one launch
+// and 134 MB of residual traffic less (the twin of bottleneck_x3.hip's DS form).
 // LDS images use the 128-B-row XOR swizzle of conv.hip (slot s of row r holds 16-B chunk s ^ ((r >> 1) & 7)).
 #include "common.h"
 
@@ -24,7 +28,8 @@ struct BnkArgs {
   const bf16_t* w2;      // [64][9][64]  (packed forward form [O][R][S][C])
   const bf16_t* w3;      // [256][64]
   const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3;
-  const bf16_t* res;     // [B*H*W][256] (may alias x when Cin == 256)
+  const bf16_t* res;     // [B*H*W][256] (may alias x when Cin == 256); unused in the DS form
+  const bf16_t* wd; const float* sd; const float* bd;      // DS form: packed [256][64] filter and folded BN of the downsample conv
   bf16_t* y;             // [B*H*W][256]
   int B, H, W, Cin, tiles_y, tiles_x;
 };
@@ -34,12 +39,13 @@ constexpr int M1 = 336;                               // halo pixels 324, padded
 constexpr int XBUF = M1 * 128;                        // one 64-channel K-step of the halo tile
 constexpr int OFF_W1 = 2 * XBUF;                      // [2][64 rows][128 B]  (86016 .. 102400)
 constexpr int OFF_T1 = 106496;                        // [336][128 B]
-constexpr int OFF_VEC = OFF_T1 + XBUF;                // fp32 s1 b1 s2 b2 [64] s3 b3 [256]: 768 floats
-constexpr int LDS_BYTES = OFF_VEC + 768 * 4;          // 152576
+constexpr int OFF_VEC = OFF_T1 + XBUF;                // fp32 s1 b1 s2 b2 [64] s3 b3 [256] (sd bd [256] in the DS form): 1280 floats
+constexpr int LDS_BYTES = OFF_VEC + 1280 * 4;         // 154624
+constexpr int OFF_WD = OFF_T1;                        // DS form: [256][128 B] downsample filter over t1 once conv2 has consumed it
 constexpr int OFF_W2 = 0;                             // phases 2 / 3 reuse the x / w1 buffers: [9 taps][64][128 B] conv2 filter,
 constexpr int OFF_W3 = 9 * 8192;                      // [256][128 B] conv3 filter (73728 .. 106496),
 constexpr int OFF_T2 = 0;                             // [256][128 B] t2 over the conv2 filter once its last tap has been consumed
-static_assert(OFF_W1 + 2 * 8192 <= OFF_T1 && OFF_W3 + 32768 <= OFF_T1 && LDS_BYTES <= 160 * 1024, "LDS map");
+static_assert(OFF_W1 + 2 * 8192 <= OFF_T1 && OFF_W3 + 32768 <= OFF_T1 && OFF_WD + 32768 <= OFF_VEC && LDS_BYTES <= 160 * 1024, "LDS map");
 
 #ifdef AOD_TILE_TIMING
 // debug build only (tools/dbg/bn_timing.py): per-workgroup wall-clock stamps (100 MHz) at the phase boundaries
@@ -66,6 +72,7 @@ __device__ __forceinline__ int wswz(int row, int chunk) { return row * 128 + ((c
 // CONSECUTIVE channels 32p + 8q .. + 7 across the pair: intermediates, residual and output move in 16-B pieces.
 __device__ __forceinline__ int wrow(int j, int lr) { return (j >> 1) * 32 + (lr >> 2) * 8 + (j & 1) * 4 + (lr & 3); }
 
+template <bool DS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck64_fwd_kernel(const BnkArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -107,8 +114,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else v = p.s3[t - 256];
     vec[t] = v;
     if (t < 256) vec[512 + t] = p.b3[t];
+    if constexpr (DS) {
+      if (t < 256) vec[768 + t] = p.sd[t]; else vec[768 + t] = p.bd[t - 256];
+    }
   }
   const float* const vs1 = vec, * const vb1 = vec + 64, * const vs2 = vec + 128, * const vb2 = vec + 192, * const vs3 = vec + 256, * const vb3 = vec + 512;
+  const float* const vsd = vec + 768, * const vbd = vec + 1024;
+  const auto rsrc_wd = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, DS ? 256 * 64 * 2 : 0, 0x00020000);
 
   // ------------------------------------------------------------------ phase 1: t1 = relu(bn1(conv1(x))) on the halo
   unsigned xoff[6];
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int r = tap / 3, s = tap - r * 3;
-    if (tap < 4) {
+    if (!DS && tap < 4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {       // piece 4 * tap + k -> (half, i, jp)
         const int half = tap >> 1, i = tap & 1, jp = k;
@@ -262,6 +274,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();      // t2 overwrites the conv2 filter
   BSTAMP(4);
+  // DS: t1 is dead as well -- the downsample filter takes its place (it lands under the t2 epilogue; the barrier behind it drains the queue),
+  // and the wave's 2 x 16 pixels of x are requested as fragments (lane = pixel lr, k-chunk lq)
+  u32x4_t xfr[2][2];
+  if constexpr (DS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned off = (unsigned)(((8 * (uw + 8 * i) + drow) * 64 + kcw * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wd, (__attribute__((address_space(3))) void*)(smem + OFF_WD + (uw + 8 * i) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = ty0 + 2 * uw + i, x = tx0 + lr;
+      const unsigned xrow = (y < p.H && x < p.W) ? (unsigned)((img0 + (long long)y * p.W + x) * 128) : OOB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xfr[i][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(xrow + (unsigned)((ks * 4 + lq) * 16)), 0, 0);
+    }
+  }
   {
     char* t2 = smem + OFF_T2;
 #pragma unroll
@@ -287,6 +316,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ------------------------------------------------------------------ phase 3: y = relu(bn3(conv3(t2)) + res), 2 x 128 output channels
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if constexpr (DS) {
+      // the residual of this half: bn_d(conv_d(x)) rounded to bf16 -- the bits the separate launch would have stored
+      f32x4 accd[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accd[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(smem + OFF_WD + wswz(half * 128 + wrow(j, lr), ks * 4 + lq));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) accd[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xfr[i][ks]), accd[i][j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          const int c = half * 128 + jp * 32 + lq * 8;
+          bf16x8 o;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(vsd + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vbd + c + 4 * h2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[4 * h2 + r] = (bf16_t)(accd[i][2 * jp + h2][r] * sc[r] + sh[r]);
+          }
+          rv[half][i][jp] = __builtin_bit_cast(u32x4_t, o);
+        }
+    }
     f32x4 acc3[2][8];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -340,23 +400,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 extern "C" int aod_dbg_set_bn_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bn_stamps), &buf, sizeof(buf)); }
 #endif
 
-extern "C" int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
-                                    const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res,
-                                    void* y, aod_stream_t stream) {
-  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && res && y, "bottleneck64: null pointer");
+static int launch_bnk(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                      const float* b2, const void* w3, const float* s3, const float* b3, const void* res, const void* wd, const float* sd,
+                      const float* bd, void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck64: null pointer");
   AOD_CHECK_ARG(Cin >= 64 && Cin % 64 == 0 && B >= 1 && H >= 1 && W >= 1, "bottleneck64: Cin %d must be a multiple of 64", Cin);
   AOD_CHECK_ARG((long long)B * H * W * (Cin > 256 ? Cin : 256) * 2 < 0xe0000000ll, "bottleneck64: operand larger than 3.5 GiB");
   BnkArgs a;
   a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w3 = (const bf16_t*)w3;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.res = (const bf16_t*)res; a.y = (bf16_t*)y;
+  a.wd = (const bf16_t*)wd; a.sd = sd; a.bd = bd;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
-  hipLaunchKernelGGL(bottleneck64_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  if (wd) hipLaunchKernelGGL(bottleneck64_fwd_kernel<true>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bottleneck64_fwd_kernel<false>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   AOD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                                    const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res,
+                                    void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(res, "bottleneck64: null pointer");
+  return launch_bnk(x, Cin, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res, nullptr, nullptr, nullptr, y, stream);
+}
+
+extern "C" int aod_bottleneck64_ds_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                                       const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd,
+                                       const float* sd, const float* bd, void* y, aod_stream_t stream) {
+  AOD_CHECK_ARG(wd && sd && bd, "bottleneck64_ds: null pointer");
+  return launch_bnk(x, 64, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, nullptr, wd, sd, bd, y, stream);
 }

@@ -930,10 +930,10 @@ def bottleneck64_applies(blk, x):
 
 
 def bottleneck64_ds_fused(blk, x):
-    """reference-precision mode: the downsample branch of the stage's first 64-plane block (1x1, stride 1, 64 -> 256 channels + eval BN) rides
-    in the block's launch (aod_bottleneck64x3_ds_fwd; AOD_FUSE_BOTTLENECK_DS=0: a launch of its own)"""
+    """the downsample branch of the stage's first 64-plane block (1x1, stride 1, 64 -> 256 channels + eval BN) rides in the block's launch
+    (aod_bottleneck64x3_ds_fwd / aod_bottleneck64_ds_fwd; AOD_FUSE_BOTTLENECK_DS=0: a launch of its own)"""
     ds = blk.downsample
-    if not ho.X3 or ds is None or _os.environ.get('AOD_FUSE_BOTTLENECK_DS', '1') == '0' or x.shape[1] != ho.xw(64):
+    if ds is None or _os.environ.get('AOD_FUSE_BOTTLENECK_DS', '1') == '0' or x.shape[1] != ho.width(64):
         return False
     c, n = ds[0], ds[1]
     return (tuple(c.weight.shape) == (256, 64, 1, 1) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0) and c.bias is None

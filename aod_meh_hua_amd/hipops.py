@@ -496,6 +496,14 @@ def bottleneck64_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, res_ro
                    lambda: call('aod_bottleneck64x3_fwd', ptr(x_rows), Cl, B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
                                 ptr(b3), ptr(res_rows), ptr(out), stream()))
         return out
+    if ds is not None:          # (fast mode: the same, aod_bottleneck64_ds_fwd)
+        assert M == B * H * W and Cin == 64 and res_rows is None
+        if out is None:
+            out = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device)
+        prof_flops('fwd', (M, 256, 64 + 576 + 64 + 64, 12, 1), 2.0 * M * (64 * 64 + 576 * 64 + 64 * 256 + 64 * 256),
+                   lambda: call('aod_bottleneck64_ds_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
+                                ptr(b3), ptr(ds[0]), ptr(ds[1]), ptr(ds[2]), ptr(out), stream()))
+        return out
     assert M == B * H * W and res_rows.shape == (M, 256)
     if out is None:
         out = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device)

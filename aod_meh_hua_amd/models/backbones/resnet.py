@@ -43,7 +43,7 @@ class Bottleneck(BaseModule):
         # identity block: the block input feeds conv1 and, as the residual, conv3 -- nothing else (stage outputs, which also go to
         # the neck, always enter a block WITH a downsample branch), so conv1's dgrad epilogue can finish the previous block's backward
         if AF.bottleneck64_applies(self, x):       # frozen / inference 64-channel block: one launch, intermediates stay in LDS
-            if AF.bottleneck64_ds_fused(self, x):      # (reference-precision mode: the downsample branch rides in the same launch)
+            if AF.bottleneck64_ds_fused(self, x):      # (the first block's downsample branch rides in the same launch)
                 return AF.bottleneck64_fwd(x, self, None)
             identity = x if self.downsample is None else self.downsample[0](x, bn=self.downsample[1])
             return AF.bottleneck64_fwd(x, self, identity)

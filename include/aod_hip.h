@@ -112,6 +112,11 @@ int aod_get_deterministic(void);
 int aod_bottleneck64_fwd(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                          const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, void* y,
                          aod_stream_t stream);
+/* ... for the stage's FIRST block (Cin = 64; resnet.py:291-292): the residual is bn_d(conv_d_1x1(x)), computed inside the launch from the packed
+ * [256][64] filter of the downsample conv and its folded BN -- the bits a separate aod_conv2d launch would have stored and this one read back. */
+int aod_bottleneck64_ds_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                            const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd,
+                            const float* sd, const float* bd, void* y, aod_stream_t stream);
 /* The same for an IDENTITY bottleneck of the 128-plane stage (layer2: 512 -> 128 -> 128 -> 512, residual = x): the conv2 / conv3 filters are
  * streamed through LDS rings (csrc/bottleneck_wide.hip).  t1 / t2 (optional, [B*H*W][128] bf16): the block's two intermediates for the
  * pixels of the image -- with them the launch is also the forward of a TRAINING step (the backward pass reads them); NULL: inference. */
