@@ -42,7 +42,7 @@ import weakref as _weakref
 _GSCORE = _weakref.WeakKeyDictionary()
 
 
-_SHARD_STATE = dict(interleaved=False, imbalance=None)       # pool partition across ranks (single_gpu_uncertainty)
+_SHARD_STATE = dict(interleaved=False, imbalance=None, over=0)       # pool partition across ranks (single_gpu_uncertainty)
 
 
 def calculate_uncertainty(cfg, *args, **kwargs):
@@ -158,9 +158,13 @@ def single_gpu_uncertainty(model, data_loader, **kwargs):
         dist.all_gather(ts, t)
         ts = torch.cat(ts)
         _SHARD_STATE['imbalance'] = float((ts.max() - ts.min()) / ts.max().clamp_min(1e-9))
-        if _SHARD_STATE['imbalance'] > 0.05:
+        # (two CONSECUTIVE passes over the threshold: a pass that captured its scoring graph or started its loader workers measures that, not
+        # the pool -- ADVICE r4)
+        _SHARD_STATE['over'] = _SHARD_STATE['over'] + 1 if _SHARD_STATE['imbalance'] > 0.05 else 0
+        if _SHARD_STATE['over'] >= 2:
             _SHARD_STATE['interleaved'] = True
-    gather = (lambda v: gather_scores_indexed(v, my_idx, N)) if interleaved else (lambda v: gather_scores(v, N))
+    per = -(-(-(-N // bs)) // world) * bs       # slots per rank of the interleaved partition: ceil(ceil(N / bs) / world) batches of bs
+    gather = (lambda v: gather_scores_indexed(v, my_idx, N, per=per)) if interleaved else (lambda v: gather_scores(v, N))
     if kwargs.get('saveMaxConf'):
         conf = torch.cat(conf_chunks) if conf_chunks else torch.zeros(0, device=dev)
         return gather(local), gather(conf)

@@ -869,6 +869,7 @@ static int fill_params(const aod_conv_desc_t* d, ConvKParams& p) {
   AOD_CHECK_ARG(d->nseg >= 1 && d->nseg <= 8, "conv: nseg %d out of range", d->nseg);
   AOD_CHECK_ARG(d->C % 8 == 0, "conv: source channels %d must be a multiple of 8", d->C);
   AOD_CHECK_ARG(d->stride >= 1 && d->dil >= 1 && d->R >= 1 && d->S >= 1, "conv: bad geometry");
+  AOD_CHECK_ARG(d->x3 == 0 || d->x3 == 1, "conv: aod_conv_desc_t.x3 = %d (0 or 1; descriptors must be zero-initialised -- the field took the place of padding in aod_version() 2)", d->x3);
   p.C = d->C; p.N = d->N; p.R = d->R; p.S = d->S; p.K = d->R * d->S * d->C;
   p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.transposed = d->transposed;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.nseg = d->nseg; p.x3 = d->x3 ? 1 : 0;

@@ -64,11 +64,24 @@ extern "C" int aod_set_deterministic(int on) {
 
 extern "C" int aod_get_deterministic(void) { return g_det; }
 
-// scratch of the current device for `floats` partial values, or nullptr when the mode is off (callers then take their atomic path)
+// scratch of the current device for `floats` partial values, or nullptr when the mode is off (callers then take their atomic path).
+// With the mode ON the scratch is allocated lazily per device (the switch is process-wide, a second device may never have seen the call) and
+// a request that does not fit is REPORTED once: the caller's atomic fallback is still correct, but the run is no longer bit-repeatable
+// (ADVICE r4).  One scratch per device, shared by every launch: deterministic training runs on ONE stream per device (include/aod_hip.h).
 float* aod_det_scratch(size_t floats) {
   if (!g_det) return nullptr;
   int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63 || !g_scratch[d] || floats > SCRATCH_FLOATS) return nullptr;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return nullptr;
+  if (!g_scratch[d] && hipMalloc((void**)&g_scratch[d], SCRATCH_FLOATS * sizeof(float)) != hipSuccess) g_scratch[d] = nullptr;
+  if (!g_scratch[d] || floats > SCRATCH_FLOATS) {
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "[libaodhip] deterministic mode: %zu partial sums do not fit the %zu-float scratch of device %d (or it could not be allocated): "
+                      "this launch falls back to fp32 atomics and the run is NOT bit-repeatable\n", floats, (size_t)SCRATCH_FLOATS, d);
+    }
+    return nullptr;
+  }
   return g_scratch[d];
 }
 

@@ -10,4 +10,5 @@ int aod_set_err(int code, const char* fmt, ...) {
   return code;
 }
 extern "C" const char* aod_last_error(void) { return g_aod_err; }
-extern "C" int aod_version(void) { return 1; }
+// 2: aod_conv_desc_t.x3 (round 4) -- the field fills what was padding in front of seg[]; descriptors must be zero-initialised
+extern "C" int aod_version(void) { return 2; }

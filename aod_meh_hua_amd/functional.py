@@ -153,7 +153,9 @@ class ParamPrep:
             conv = r()
             if conv is not None and not torch.cuda.is_current_stream_capturing():
                 _stem_w4(conv)
-        if any(it.ver != self._versions(it) for it in self.items.values()):
+        # (only the ACTIVE arithmetic mode's images: after a mode switch in one process the other mode's items stay stale until get() meets
+        # them again in their own mode -- ADVICE r4: every optimizer step re-packed both sets)
+        if any(it.x3 == ho.X3 and it.ver != self._versions(it) for it in self.items.values()):
             self.refresh()
 
     def refresh(self):
@@ -170,7 +172,7 @@ class ParamPrep:
             self.dirty = False
         # only the STALE layers are re-derived.  Which layers are stale together repeats (all trainable layers of one model after its
         # optimizer step; never the frozen stem / layer1; never a second, frozen model): one device table per staleness pattern.
-        stale = tuple(i for i, it in enumerate(self.order) if it.ver != self._versions(it))
+        stale = tuple(i for i, it in enumerate(self.order) if it.x3 == ho.X3 and it.ver != self._versions(it))
         if not stale:
             return
         ent = self.tables.get(stale)

@@ -463,6 +463,8 @@ class GraphedScore:
         return graphs
 
     def __call__(self, img, img_metas, image_ids, defer=False):
+        """defer=True: the scores are complete only after sync().  The caller may drop or re-allocate `img` / `image_ids` at once (both are
+        recorded on the stream that copies them) and may overwrite them in place on its own stream (which is made to wait for those copies)."""
         shape = (tuple(img.shape), AF.mode_key())          # (the key: a graph serves one batch shape in one arithmetic / determinism mode)
         ent = self.cache.pop(shape, None)
         if ent is None:
@@ -501,18 +503,28 @@ class GraphedScore:
         if self.s_conv is None:
             self.s_conv, self.s_tail = torch.cuda.Stream(), torch.cuda.Stream()
         cur = torch.cuda.current_stream()
-        self.s_conv.wait_stream(cur)                 # the batch (and, for a non-deferred predecessor, its scores) are produced on the caller's stream
+        self.s_conv.wait_stream(cur)                 # the batch, its ids (and, for a non-deferred predecessor, its scores) are produced on the caller's stream
         with torch.cuda.stream(self.s_conv):
             if sl['ev_b'] is not None:
-                self.s_conv.wait_event(sl['ev_b'])   # this slot's previous selection half has read the prediction tensors
+                self.s_conv.wait_event(sl['ev_b'])   # this slot's previous selection half has read the prediction tensors, the ids and the sizes
+            copied = img.data_ptr() != sl['img'].data_ptr() or (torch.is_tensor(image_ids) and image_ids.is_cuda)
             self._fill_img(sl, img)
+            self._fill_meta(sl, img_metas, image_ids)            # (on THIS stream: the selection half starts behind ev_a, an id copy queued there would
+            ev_fill = None                                       #  read the caller's tensor a whole conv half later -- ADVICE r4)
+            if copied:
+                ev_fill = torch.cuda.Event()
+                ev_fill.record(self.s_conv)
+                if img.is_cuda:
+                    img.record_stream(self.s_conv)
+                if torch.is_tensor(image_ids) and image_ids.is_cuda:
+                    image_ids.record_stream(self.s_conv)
             sl['ga'].replay()
             sl['ev_a'] = torch.cuda.Event()
             sl['ev_a'].record(self.s_conv)
-        self.s_tail.wait_stream(cur)                 # (the image ids)
+        if ev_fill is not None:
+            cur.wait_event(ev_fill)                  # the caller's inputs have been read: it may overwrite them in place from here on
         with torch.cuda.stream(self.s_tail):
             self.s_tail.wait_event(sl['ev_a'])
-            self._fill_meta(sl, img_metas, image_ids)
             sl['gb'].replay()
             unc = sl['out'][1]
             unc = unc.clone() if torch.is_tensor(unc) else unc

@@ -204,9 +204,11 @@ def shard_batches(n_total, bs, rank=None, world=None, interleaved=False):
     return [list(range(k * bs, min((k + 1) * bs, n_total))) for k in range(rank, nb, world)]
 
 
-def gather_scores_indexed(local_scores, local_idx, n_total):
-    """Scores of an arbitrary index set per rank -> the full [N] vector on every rank: ONE all-gather of the padded (index, score) pairs
-    (indices travel as fp32-exact int32 bit patterns in a second tensor; pad slots carry index -1)."""
+def gather_scores_indexed(local_scores, local_idx, n_total, per=None):
+    """Scores of an arbitrary index set per rank -> the full [N] vector on every rank with ONE all-gather: each rank sends a [per, 2] fp32
+    block whose column 0 holds its scores and whose column 1 holds the global indices as int32 bit patterns (pad slots: -1).
+    per: slots per rank, the same number on every rank (the interleaved partition's bound ceil(ceil(N / bs) / world) * bs is known to the
+    caller without communication); None -> agreed on by one extra all-reduce(MAX) and a host read of the result."""
     rank, world = get_dist_info()
     dev = local_scores.device
     idx = torch.as_tensor(local_idx, dtype=torch.int64, device=dev)
@@ -214,18 +216,23 @@ def gather_scores_indexed(local_scores, local_idx, n_total):
     if world == 1:
         full[idx] = local_scores
         return full
-    cnt = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
-    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-    per = int(cnt)
-    sbuf = local_scores.new_zeros(per)
-    ibuf = torch.full((per,), -1, dtype=torch.int64, device=dev)
-    sbuf[:idx.numel()], ibuf[:idx.numel()] = local_scores, idx
-    so, io = [torch.empty_like(sbuf) for _ in range(world)], [torch.empty_like(ibuf) for _ in range(world)]
-    dist.all_gather(so, sbuf)
-    dist.all_gather(io, ibuf)
-    sc, ix = torch.cat(so), torch.cat(io)
+    assert n_total < (1 << 31)
+    if per is None:
+        cnt = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        per = int(cnt)
+    assert idx.numel() <= per, (idx.numel(), per)
+    buf = torch.zeros(per, 2, dtype=torch.float32, device=dev)
+    ib = buf.view(torch.int32)
+    ib[:, 1] = -1
+    buf[:idx.numel(), 0] = local_scores.float()
+    ib[:idx.numel(), 1] = idx.to(torch.int32)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    allb = torch.cat(out)
+    ix = allb.view(torch.int32)[:, 1].long()
     ok = ix >= 0
-    full[ix[ok]] = sc[ok]
+    full[ix[ok]] = allb[ok, 0].to(full.dtype)
     return full
 
 

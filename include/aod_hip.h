@@ -54,7 +54,8 @@ typedef struct {
                              l = bf16(v - h)); three MFMAs per 32 channels (xh*wh + xl*wh + xh*wl) give fp32-grade products.  C is then
                              the PHYSICAL source width (multiple of 64), N the LOGICAL output channel count; a bf16 destination,
                              res and mask are X-layout rows of 2*ceil32(N) columns, an fp32 destination has N columns.  (Fills the
-                             padding the struct had in front of seg[]: the layout of the other fields is unchanged.) */
+                             padding the struct had in front of seg[]: the layout of the other fields is unchanged.  aod_version() >= 2.
+                             Descriptors MUST be zero-initialised (memset / = {0}); any value other than 0 or 1 is rejected.) */
   aod_conv_seg_t seg[8];
 } aod_conv_desc_t;
 

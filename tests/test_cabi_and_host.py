@@ -189,7 +189,7 @@ def test_ssd512_config_builds_the_seven_level_model():
     assert len(m.bbox_head.cls_convs) == 7
 
 
-def test_wgrad_group_plan_is_host_logic_with_the_documented_properties(lib):
+def test_wgrad_group_plan_is_host_logic_with_the_documented_properties(lib, bf16_mode):
     """aod_conv2d_wgrad_group_plan (host code of the C ABI, no launch): members of a group get FEWER pixel splits than alone, every member of a
     group runs the same number of 64-pixel steps per workgroup, the grid fits the chip's slots, mixed tile forms are refused (return 1), and a
     single member fills the slots too."""

@@ -298,7 +298,7 @@ def test_r101_p7_gradient_noise_is_operand_rounding(built):
         out['loss'].backward()
         torch.cuda.synchronize()
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
     assert np.allclose(float(out['loss']), float(o['loss']), rtol=1e-4), (float(out['loss']), float(o['loss']))
     pd = dict(model.named_parameters())
     for k in ('neck.fpn_convs.4.conv.weight', 'neck.fpn_convs.3.conv.weight', 'backbone.layer3.22.bn3.weight', 'bbox_head.retina_cls.weight'):

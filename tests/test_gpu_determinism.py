@@ -68,7 +68,7 @@ def test_deterministic_mode_repeats_bit_for_bit(prec):
         assert worst < 2e-6, worst
     finally:
         AF.set_deterministic(False)
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
     assert lib.aod_get_deterministic() == 0
 
 
@@ -105,4 +105,4 @@ def test_l2norm_scale_gradient_is_ordered_in_the_deterministic_mode(prec):
         assert float((a_w - free_w).abs().max() / free_w.abs().max()) < 1e-5
     finally:
         AF.set_deterministic(False)
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))

@@ -63,3 +63,79 @@ def test_full_size_scores_do_not_depend_on_batching(model):
     cut = torch.cat([torch.as_tensor(ua).float().cpu(), torch.as_tensor(ub).float().cpu()])
     assert torch.equal(u16, u16b) and torch.isfinite(u16).all()
     assert torch.equal(u16, cut), (u16, cut)
+
+
+FULL_NAMES = ['backbone.layer2.0.conv1.weight', 'backbone.layer2.0.downsample.0.weight', 'backbone.layer2.3.bn3.weight', 'backbone.layer3.0.conv2.weight',
+              'backbone.layer3.5.conv3.weight', 'backbone.layer3.5.bn2.bias', 'backbone.layer4.0.downsample.0.weight', 'backbone.layer4.2.conv2.weight',
+              'backbone.layer4.2.bn3.weight', 'neck.lateral_convs.0.conv.weight', 'neck.lateral_convs.2.conv.bias', 'neck.fpn_convs.0.conv.weight',
+              'neck.fpn_convs.3.conv.weight', 'neck.fpn_convs.4.conv.weight', 'bbox_head.cls_convs.0.conv.weight', 'bbox_head.cls_convs.3.conv.bias',
+              'bbox_head.reg_convs.2.conv.weight', 'bbox_head.retina_cls.weight', 'bbox_head.retina_cls.bias', 'bbox_head.retina_reg.weight']
+FULL_NAMES_L = ['bbox_head.L_convs.0.conv.weight', 'bbox_head.L_convs.3.conv.bias', 'bbox_head.retina_L.weight', 'bbox_head.retina_L.bias']
+
+
+def test_full_size_train_step_vs_oracle_in_the_reference_precision_mode(model):
+    """BASELINE configs[1] at its FULL size (16 x 512 x 512, 49 104 anchors per image) in the headline arithmetic (bf16x3) against the fp32 CPU
+    oracle of the reference's train_step + train_step_L (mmdet/utils/Epoch_Based_Runner_Lambda.py:20-38, dense_heads/L_anchor_head.py:290-327):
+    total loss and the three log_vars to 1e-4, per-anchor loss rows of every level to 5e-4 of the level's scale, assignment integer-exact,
+    twenty named gradients of the main step and four of the MEH step by norm and direction."""
+    from aod_meh_hua_amd import functional as AF
+    B, H = 16, 512
+    sd0 = omodel.seeded_state_dict(cls_bias=-1.0)
+    model.load_state_dict(sd0, strict=True)
+    gtb, gtl = synth.random_gts(B, H, H, seed=5, gmin=1, gmax=5)
+    img = synth.images(B, H, H, seed=6)
+    data = dict(img=img.cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    model.train()
+    prec0 = AF.get_precision()
+    AF.set_precision('bf16x3')
+    try:
+        out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+        model.zero_grad()
+        out['loss'].backward()
+        pd = dict(model.named_parameters())
+        grads = {k: pd[k].grad.detach().float().cpu().clone() for k in FULL_NAMES}
+        lossL = model.train_step_L(prev, head_out, feat_out)
+        model.zero_grad()
+        lossL['loss'].backward()
+        gradsL = {k: pd[k].grad.detach().float().cpu().clone() for k in FULL_NAMES_L}
+        torch.cuda.synchronize()
+    finally:
+        AF.set_precision(prec0)
+    # the oracle: same weights, same images, fp32 on the host cores
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k in FULL_NAMES + FULL_NAMES_L:
+        sd[k].requires_grad_(True)
+    o = omodel.train_step(sd, img, gtb, gtl)
+    o['loss'].backward()
+    g1 = {k: sd[k].grad.clone() for k in FULL_NAMES}
+    for v in sd.values():
+        v.grad = None
+    oL = omodel.train_step_L(sd, o['feats'], o['loss_noR'], o['targets'])
+    oL['loss'].backward()
+    gL = {k: sd[k].grad.clone() for k in FULL_NAMES_L}
+    # assignment: integer-exact
+    assert int(head_out[8]) == o['targets']['num_total_pos']
+    lab = torch.cat([l.reshape(B, -1) for l in head_out[4]], 1).cpu()
+    assert torch.equal(lab, torch.cat(o['targets']['labels'], 1))
+    # losses
+    got = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
+    exp = [float(sum(o['loss_cls'])), float(sum(o['loss_bbox'])), float(sum(x.mean() for x in o['loss_noR']))]
+    print('full size log_vars', got, exp, 'loss', float(out['loss']), float(o['loss']))
+    assert np.allclose(got, exp, rtol=1e-4), (got, exp)
+    assert abs(float(out['loss']) - float(o['loss'])) <= 1e-4 * abs(float(o['loss']))
+    assert abs(float(lossL['loss']) - float(oL['loss'])) <= 2e-4 * abs(float(oL['loss'])), (float(lossL['loss']), float(oL['loss']))
+    for l in range(5):                                                                        # per-anchor loss rows, every level
+        a, b = prev[l].cpu().numpy().reshape(-1), o['loss_noR'][l].detach().numpy().reshape(-1)
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max(), (l, np.abs(a - b).max(), np.abs(b).max())
+    worst = 0.0
+    for tag, gh, go in (('main', grads, g1), ('meh', gradsL, gL)):
+        for k in gh:
+            a, b = gh[k].flatten().double(), go[k].flatten().double()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+            nd = abs(float(a.norm() / b.norm()) - 1)
+            err = float((a - b).norm() / b.norm())
+            worst = max(worst, err)
+            print(f'{tag}:{k:48s} rel err {err:.2e}  norm dev {nd:.2e}  1-cos {1 - cos:.2e}')
+            assert cos > 1 - 1e-5 and nd < 1e-3 and err < 3e-3, (k, cos, nd, err)
+    print('worst relative gradient error at full size:', worst)

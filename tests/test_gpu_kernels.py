@@ -325,7 +325,7 @@ def test_inplace_pointwise_stride2_dgrad_is_a_lattice_launch(ho, prec, shape):
         out = ho.x3_merge(got) if prec == 'bf16x3' else got.float()
         assert float((out - ref.reshape(-1, I)).abs().max()) < (1e-4 if prec == 'bf16x3' else 6e-2) * float(ref.abs().max())
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
 
 
 @pytest.mark.parametrize('case', CONV_CASES)

@@ -68,7 +68,7 @@ def precision(request):
     from aod_meh_hua_amd import functional as AF
     AF.set_precision(request.param)
     yield request.param
-    AF.set_precision('bf16')
+    AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
 
 
 def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch, precision):
@@ -116,3 +116,42 @@ def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch
     with torch.no_grad():
         u2 = single_gpu_uncertainty(m2, Loader(ds, 16), **KW).cpu().numpy()
     assert np.array_equal(u2, u16)
+
+
+def test_deferred_scoring_survives_the_caller_recycling_its_inputs(pool_model, precision):
+    """ADVICE r4 (graphs.py): with defer=True the selection half of batch k runs on a second stream a whole conv half later.  The caller's
+    `image_ids` / `img` may be local tensors that are freed, re-allocated or overwritten in place right after the call -- the slot's copies
+    must have been taken by then.  Every deferred score must equal the score of the same (image, id) from a plain, non-deferred call."""
+    from aod_meh_hua_amd.datasets import DevicePhiloxPool
+    from aod_meh_hua_amd.graphs import GraphedScore
+    dev = torch.device('cuda', 0)
+    ds = DevicePhiloxPool(64, (256, 256), seed=33)
+    B, NB = 4, 6
+    metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3), ori_shape=(256, 256, 3), scale_factor=np.ones(4, np.float32), flip=False)
+             for _ in range(B)]
+    kw = dict(rescale=True, isEval=False, batchIdx=0, **KW)
+    batches = [ds.device_batch(list(range(k * B, k * B + B)), dev)['img'][0].clone() for k in range(NB)]
+    with torch.no_grad():
+        gs = GraphedScore(pool_model, **kw)
+        ref = []
+        for k in range(NB):
+            _, u = gs(batches[k], metas, torch.arange(k * B, k * B + B, device=dev))
+            ref.append(u.clone())
+        torch.cuda.synchronize()
+        got = []
+        buf = torch.empty_like(batches[0])
+        for k in range(NB):
+            ids = torch.arange(k * B, k * B + B, device=dev)
+            buf.copy_(batches[k])
+            _, u = gs(buf, metas, ids, defer=True)
+            got.append(u)
+            ids.fill_(10 ** 6 + k)                   # overwritten in place ...
+            del ids
+            junk = torch.full((B,), 7 + k, dtype=torch.int64, device=dev)      # ... and its block handed out again
+            buf.normal_()                            # the image buffer refilled at once
+            del junk
+        gs.sync()
+        torch.cuda.synchronize()
+    for k in range(NB):
+        assert torch.equal(got[k], ref[k]), (k, got[k], ref[k])
+    assert float(torch.stack(ref).abs().sum()) > 0

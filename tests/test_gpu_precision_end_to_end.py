@@ -57,7 +57,7 @@ def _hip_scores(model, img, ids, prec):
             dets, unc = model(img=[img.cuda()], img_metas=[synth.metas(B, H, W)], return_loss=False, image_ids=ids.cuda(), **KW)
         torch.cuda.synchronize()
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
     return torch.as_tensor(unc).float().cpu().numpy().astype(np.float64), dets
 
 

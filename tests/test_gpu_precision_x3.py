@@ -47,7 +47,7 @@ def _run(model, prec):
         feat4 = AF.x3_to_f32(feat_out[4], 256).cpu().numpy()          # (an X-layout tensor in the bf16x3 mode)
         torch.cuda.synchronize()
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
     rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
     dev = dict(
         loss=abs(float(out['loss']) - float(g['loss'])) / abs(float(g['loss'])),
@@ -141,7 +141,7 @@ def test_bf16x3_scoring_pass_matches_the_fp32_oracle_and_replays_as_a_graph():
                 _, unc_g2 = gs(img.cuda(), mt, ids)          # replay
             torch.cuda.synchronize()
         finally:
-            AF.set_precision('bf16')
+            AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
         u = torch.as_tensor(unc).float().cpu().numpy()
         assert np.array_equal(u, torch.as_tensor(unc_g1).float().cpu().numpy()) and np.array_equal(u, torch.as_tensor(unc_g2).float().cpu().numpy())
         res[prec] = (u, dets)

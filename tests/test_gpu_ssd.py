@@ -429,5 +429,5 @@ def test_ssd_train_step_in_the_reference_precision_mode_vs_reference_golden(buil
         gnL = np.array([float(pd[k].grad.float().norm()) for k in g['grad_names_L']])
         assert np.allclose(gnL, g['grad_norms_L'], rtol=3e-3), (gnL / g['grad_norms_L'])
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
         model.zero_grad()

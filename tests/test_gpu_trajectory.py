@@ -85,7 +85,7 @@ def _hip_run(batches, prec):
             losses_L.append(float(lossL['loss'].detach()))
         torch.cuda.synchronize()
     finally:
-        AF.set_precision('bf16')
+        AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
     return np.array(losses), np.array(losses_L), {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
 
 

@@ -18,7 +18,7 @@ def precision(request):
     from aod_meh_hua_amd import functional as AF
     AF.set_precision(request.param)
     yield request.param
-    AF.set_precision('bf16')
+    AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
 
 
 def test_voc_batches_through_train_score_eval(voc, precision):  # noqa: F811
