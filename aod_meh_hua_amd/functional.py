@@ -311,7 +311,8 @@ def bwd_chain_for(blk, x):
     """a BwdChain for a block whose training forward qualifies for the fused kernels (same conditions; AOD_FUSE_BOTTLENECK_BWD=0 switches
     the fused backward off), else None"""
     on = _os.environ.get('AOD_FUSE_BOTTLENECK_BWD', '1') != '0' and not ho.DETERMINISTIC     # (the fused chain sums its columns with atomics of its own)
-    return BwdChain() if on and _FUSE_ACT and bottleneck128_train_applies(blk, x) else None
+    # (reference-precision mode: the forward is fused -- aod_bottleneck128x3_fwd --, the dgrads stay three launches)
+    return BwdChain() if on and _FUSE_ACT and not ho.X3 and bottleneck128_train_applies(blk, x) else None
 
 
 def set_deterministic(on=True):
@@ -959,7 +960,11 @@ def bottleneck64_fwd(x, blk, identity):
 
 
 def _wide_stage(blk):
-    """128 planes (layer2, aod_bottleneck128_fwd) or 256 planes (layer3, aod_bottleneck256_fwd; AOD_FUSE_BOTTLENECK256=0 switches it off)"""
+    """128 planes (layer2, aod_bottleneck128_fwd) or 256 planes (layer3, aod_bottleneck256_fwd; AOD_FUSE_BOTTLENECK256=0 switches it off).
+    Reference-precision mode: the 128-plane stage only (aod_bottleneck128x3_fwd, csrc/bottleneck128_x3.hip; AOD_FUSE_BOTTLENECK128_X3=0 switches it
+    off) -- on X rows a 256-plane tile's intermediates and filter stream do not fit the CU's LDS / L2 path."""
+    if ho.X3:
+        return blk.planes == 128 and _os.environ.get('AOD_FUSE_BOTTLENECK128_X3', '1') != '0'
     return blk.planes == 128 or (blk.planes == 256 and _os.environ.get('AOD_FUSE_BOTTLENECK256', '1') != '0')
 
 
@@ -1014,7 +1019,7 @@ def _frag_form(blk):
 def bottleneck128_applies(blk, x):
     """an identity bottleneck of the 128-plane stage (resnet.py:262-301: 512 -> 128 -> 128 -> 512, stride 1, no downsample branch) whose
     forward keeps nothing for a backward pass (inference / frozen): one launch (aod_bottleneck128_fwd)"""
-    if _PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None:
+    if _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None:
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
     if (x.dtype != torch.bfloat16 or c1.in_channels != 4 * blk.planes or c3.out_channels != 4 * blk.planes or tuple(c1.stride) != (1, 1) or tuple(c2.stride) != (1, 1)
@@ -1030,7 +1035,7 @@ def bottleneck128_train_applies(blk, x):
     three convs are recorded as autograd nodes around its outputs (conv_bn_act(pre=...)): forward = one launch, backward unchanged"""
     if not torch.is_grad_enabled() or _os.environ.get('AOD_FUSE_BOTTLENECK128_TRAIN', '1') == '0':
         return False
-    if (_PREC != 'bf16' or _os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None
+    if (_os.environ.get('AOD_FUSE_BOTTLENECK128', '1') == '0' or not _wide_stage(blk) or blk.downsample is not None
             or x.dtype != torch.bfloat16):
         return False
     c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
@@ -1042,9 +1047,9 @@ def bottleneck128_train_fwd(x, blk):
     """(t1, t2, y) row tensors of the fused launch for a block under autograd"""
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
-    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
-    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
-    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
+    p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)                  # (Cin = the row width of x: the X-layout width in the x3 mode)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), ho.width(blk.planes), blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), ho.width(blk.planes), blk.norm3.eps)
     fr = _frag_form(blk)
     w1, w2, w3 = ((PREP.frag(q, 'f') for q in (p1, p2, p3)) if fr else (p1.wf, p2.wf, p3.wf))
     with torch.no_grad():
@@ -1057,8 +1062,8 @@ def bottleneck128_fwd(x, blk):
     B, Cin, H, W = x.shape
     bn = lambda n: (n.weight, n.bias, n.running_mean, n.running_var)
     p1 = PREP.get(blk.conv1.weight, bn(blk.norm1), Cin, blk.norm1.eps)
-    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), blk.planes, blk.norm2.eps)
-    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), blk.planes, blk.norm3.eps)
+    p2 = PREP.get(blk.conv2.weight, bn(blk.norm2), ho.width(blk.planes), blk.norm2.eps)
+    p3 = PREP.get(blk.conv3.weight, bn(blk.norm3), ho.width(blk.planes), blk.norm3.eps)
     fr = _frag_form(blk)
     w1, w2, w3 = ((PREP.frag(q, 'f') for q in (p1, p2, p3)) if fr else (p1.wf, p2.wf, p3.wf))
     out = ho.bottleneck128_fwd(as_rows(x.detach()), B, H, W, w1, p1.scale, p1.shift, w2, p2.scale, p2.shift, w3, p3.scale, p3.shift, frag=fr)

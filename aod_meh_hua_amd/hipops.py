@@ -518,6 +518,15 @@ def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=
     """aod_bottleneck128_fwd / aod_bottleneck256_fwd (by the channel count of x: 512 / 1024): identity bottleneck of the 128- / 256-plane
     stage in one launch; keep=True also returns the intermediates t1, t2"""
     M, Cin = x_rows.shape
+    if X3:          # X rows: the x3 twin of the 128-plane kernel (csrc/bottleneck128_x3.hip)
+        assert M == B * H * W and Cin == 1024 and not frag
+        out = torch.empty(M, 1024, dtype=torch.bfloat16, device=x_rows.device)
+        t1 = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+        t2 = torch.empty(M, 256, dtype=torch.bfloat16, device=x_rows.device) if keep else None
+        prof_flops('fwd', (M, 512, 2 * (512 + 9 * 128 + 128), 11, 1), 2.0 * M * (512 * 128 + 9 * 128 * 128 + 128 * 512),
+                   lambda: call('aod_bottleneck128x3_fwd', ptr(x_rows), B, H, W, ptr(w1), ptr(s1), ptr(b1), ptr(w2), ptr(s2), ptr(b2), ptr(w3), ptr(s3),
+                                ptr(b3), ptr(out), ptr(t1), ptr(t2), stream()))
+        return (out, t1, t2) if keep else out
     assert M == B * H * W and Cin in (512, 1024)
     Pl = Cin // 4
     out = torch.empty(M, Cin, dtype=torch.bfloat16, device=x_rows.device)

@@ -47,7 +47,7 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='voc512', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=None)
@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--no-precision-check', action='store_true', help='skip the short run in the OTHER precision mode after the timed region (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--shapes', default=None, help='write the per-shape conv breakdown of the instrumented step to this file')
+    ap.add_argument('--serial-scores', action='store_true', help='timed loop: read (and, for N > 1, all-gather) the scores after every step instead of once after the loop')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
     return ap.parse_args()
 
@@ -339,10 +340,11 @@ def main():
                             si.copy_(img)
                             state['filled'].add(si.data_ptr())
                         img = si
-                    _, unc = gscore(img, pool['img_metas'], ids, defer=defer and world == 1)
-                    if world > 1:
+                    _, unc = gscore(img, pool['img_metas'], ids, defer=defer)
+                    if world > 1 and not defer:
                         gather_scores(unc, B * world)
-                return
+                    return unc
+                return None
             if do_train:
                 model.train()
                 out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
@@ -384,14 +386,32 @@ def main():
             nonlocal data, pool
             if do_train and getattr(gstep, 'cur', None) and tuple(gstep.cur['static']['img'].shape) == tuple(data['img'].shape):
                 data = dict(data, img=gstep.cur['static']['img'])
+        # The timed loop calls the scoring graph the way the product's pool loop does (apis/test.py single_gpu_uncertainty): scores are
+        # deferred -- the selection half of batch k (<= 16 workgroups) runs on its own stream beside whatever follows --, read after the
+        # loop (gscore.sync()) and all-gathered ONCE, all inside the timed region.  --serial-scores restores one read + one gather per step.
+        deferred = state['graph_ok'] and do_score and not args.serial_scores
+
+        def timed(n, first):
+            uncs = []
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n):
+                uncs.append(step(first + i, defer=deferred))
+            if deferred:
+                gscore.sync()
+                if world > 1:
+                    gather_scores(torch.cat(uncs), B * world * n)
+            barrier()
+            return time.perf_counter() - t0
+
         for i in range(warmup):
             step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        barrier()
-        dt = time.perf_counter() - t0
+        dt = timed(steps, warmup)
+        serial_ms = None
+        if deferred and world == 1:                   # the same steps with the scores read after every step, beside the line (not `value`)
+            deferred = False
+            serial_ms = round(timed(min(steps, 20), warmup + steps) / min(steps, 20) * 1e3, 3)
+            deferred = True
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -406,9 +426,10 @@ def main():
             k = phase_iters
             barrier()
             t1 = time.perf_counter()
-            for i in range(k):
-                step(warmup + steps + i, tr_, sc_, defer=sc_ and not tr_)
+            us_ = [step(warmup + steps + i, tr_, sc_, defer=sc_ and not tr_) for i in range(k)]
             gscore.sync()
+            if world > 1 and sc_ and not tr_ and state['graph_ok']:
+                gather_scores(torch.cat(us_), B * world * k)
             barrier()
             d = time.perf_counter() - t1
             phase[name + '_img_per_s'] = round(B * world * k / d, 1)
@@ -496,7 +517,7 @@ def main():
                         secondary={k: dict(bound='hbm', launches=v[0], us=round(v[1] * 1e6, 1), achieved=round(v[2] / v[1] / 1e9, 1), peak=PEAK_HBM_GBS,
                                            unit='GB/s', frac=round(v[2] / v[1] / 1e9 / PEAK_HBM_GBS, 4)) for k, v in sec.items() if v[1] > 0})
         del gstep, gscore
-        return dict(dt=dt, steps=steps, phase=phase, roof=roof, use_graph=use_graph)
+        return dict(dt=dt, steps=steps, phase=phase, roof=roof, use_graph=use_graph, deferred=deferred, serial_ms=serial_ms)
 
     main_m = measure(args.precision, args.steps, args.warmup, not args.no_graph, args.phase_iters)
     dt, use_graph = main_m['dt'], main_m['use_graph']
@@ -556,6 +577,9 @@ def main():
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
                                 parallelism=f'dp{world}', collective_ranks=comm['ranks'], collective_backend=comm['backend'],
                                 phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
+                                scores_read=('after the loop (the pool loop\'s deferred form: selection half of batch k on its own stream; one sync + one all-gather '
+                                             'inside the timed region)' if main_m['deferred'] else 'after every step'),
+                                ms_per_step_scores_read_every_step=main_m['serial_ms'],
                                 arithmetic=PRECISIONS[args.precision][2],
                                 column_sums='ordered partial sums (--deterministic)' if args.deterministic else 'fp32 atomics (default)'),
                     phase_rates=main_m['phase'], hua=hua, precision=prec, roofline=roof, cpu_baseline=cpu)

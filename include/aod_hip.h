@@ -451,6 +451,15 @@ int aod_bottleneck64x3_ds_fwd(const void* x, int B, int H, int W, const void* w1
                               const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* wd,
                               const float* sd, const float* bd, void* y, aod_stream_t stream);
 
+/* aod_bottleneck128_fwd on X rows (reference-precision mode; csrc/bottleneck128_x3.hip): the IDENTITY bottleneck of the 128-plane stage
+ * (mmdet/models/backbones/resnet.py:262-301, layer2: 512 -> 128 -> 128 -> 512) in one launch.  x / y [B*H*W][1024], w1 [128][1024], w2
+ * [128][9][256], w3 [512][256] = the X filter images of aod_param_prep (flags bit 0), s / b the folded BN vectors; t1 / t2 [B*H*W][256]
+ * (both or neither; NULL: inference / frozen) receive the block's two intermediates -- the launch is then the forward of a training step, the
+ * three convs being recorded as autograd nodes around its outputs.  Same bits as the three aod_conv2d launches it replaces.  y must not alias x. */
+int aod_bottleneck128x3_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
+                            const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
+                            aod_stream_t stream);
+
 /* The frozen stem of the reference-precision mode in one launch (csrc/stem_x3.hip; resnet.py:630-637): fp32 NCHW image [B][3][H][W] (even
  * H, W) -> y = max_pool_3x3_s2_p1(relu(bn1(conv1_7x7_s2(img)))) as X rows [B][H4][W4][128], H4 = (H/2 - 1) / 2 + 1.  w_x = the X filter
  * image [64][4][4][64] of the space-to-depth form of conv1 (aod_param_prep, flags bit 0, of the [64][12][4][4] filter); replaces

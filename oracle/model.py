@@ -16,6 +16,34 @@ from . import detect, geometry, hua, losses
 ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 STRIDES = (8, 16, 32, 64, 128)
 
+# Parity diagnostics (tests/test_gpu_precision_x3.py, tools/dbg/x3_grad_table.py): evaluate the network with the ReLU SIGN PATTERN of another
+# run.  A ReLU whose input lies within the other implementation's rounding error of zero may open on one side and stay shut on the other; the
+# values differ by that rounding error, but the GRADIENTS differ by the whole upstream gradient of that element.  With `relu_masks` the oracle's
+# `relu(z)` at a keyed site becomes `z * mask` (mask: bool tensor of z's shape), so the two backward passes walk the same piecewise-linear
+# branch.  Keys: 'backbone.bn1'; '<block>.bn1' / '.bn2' / '.out'; 'bbox_head.<tower>.<i>@<level>'; 'bbox_head.retina_L@<level>'.
+_MASKS = None
+
+
+class relu_masks:
+    def __init__(self, masks):
+        self.masks = masks
+
+    def __enter__(self):
+        global _MASKS
+        self.prev, _MASKS = _MASKS, self.masks
+
+    def __exit__(self, *exc):
+        global _MASKS
+        _MASKS = self.prev
+
+
+def _relu(z, key):
+    m = _MASKS.get(key) if _MASKS is not None else None
+    if m is None:
+        return F.relu(z)
+    assert m.shape == z.shape, (key, m.shape, z.shape)
+    return z * m.to(z.dtype)
+
 
 def state_dict_spec(depth=50, num_classes=20, num_anchors=9):
     """Ordered (key, shape) list of the reference model's state_dict (SURVEY 8b 'Checkpoint keys';
@@ -94,20 +122,20 @@ def backbone(sd, img, depth=50):
     """ResNet.forward / Bottleneck.forward (backbones/resnet.py:630-645, :262-301), pytorch style
     (stride on conv2), BN in eval mode (norm_eval=True, :647-656)."""
     x = F.conv2d(img, sd['backbone.conv1.weight'], None, 2, 3)
-    x = F.relu(_bn(x, sd, 'backbone.bn1'))
+    x = _relu(_bn(x, sd, 'backbone.bn1'), 'backbone.bn1')
     x = F.max_pool2d(x, 3, 2, 1)
     outs = []
     for li, nb in enumerate(ARCH[depth]):
         for bi in range(nb):
             p = f'backbone.layer{li + 1}.{bi}'
             stride = 2 if (bi == 0 and li > 0) else 1
-            o = F.relu(_bn(F.conv2d(x, sd[p + '.conv1.weight']), sd, p + '.bn1'))
-            o = F.relu(_bn(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, 1), sd, p + '.bn2'))
+            o = _relu(_bn(F.conv2d(x, sd[p + '.conv1.weight']), sd, p + '.bn1'), p + '.bn1')
+            o = _relu(_bn(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, 1), sd, p + '.bn2'), p + '.bn2')
             o = _bn(F.conv2d(o, sd[p + '.conv3.weight']), sd, p + '.bn3')
             idt = x
             if bi == 0:
                 idt = _bn(F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride), sd, p + '.downsample.1')
-            x = F.relu(o + idt)
+            x = _relu(o + idt, p + '.out')
         outs.append(x)
     return outs
 
@@ -125,22 +153,22 @@ def fpn(sd, feats):
     return outs
 
 
-def _tower(sd, x, name, pred, relu_out=False):
+def _tower(sd, x, name, pred, relu_out=False, lvl=0):
     for i in range(4):
-        x = F.relu(F.conv2d(x, sd[f'bbox_head.{name}.{i}.conv.weight'], sd[f'bbox_head.{name}.{i}.conv.bias'], 1, 1))
+        x = _relu(F.conv2d(x, sd[f'bbox_head.{name}.{i}.conv.weight'], sd[f'bbox_head.{name}.{i}.conv.bias'], 1, 1), f'bbox_head.{name}.{i}@{lvl}')
     y = F.conv2d(x, sd[f'bbox_head.{pred}.weight'], sd[f'bbox_head.{pred}.bias'], 1, 1)
-    return F.relu(y) if relu_out else y
+    return _relu(y, f'bbox_head.{pred}@{lvl}') if relu_out else y
 
 
 def head_forward(sd, feats):
     """Lambda_L2Net.forward_single (Lambda_L2.py:85-94)."""
-    return ([_tower(sd, f, 'cls_convs', 'retina_cls') for f in feats],
-            [_tower(sd, f, 'reg_convs', 'retina_reg') for f in feats])
+    return ([_tower(sd, f, 'cls_convs', 'retina_cls', lvl=l) for l, f in enumerate(feats)],
+            [_tower(sd, f, 'reg_convs', 'retina_reg', lvl=l) for l, f in enumerate(feats)])
 
 
 def head_forward_L(sd, feats):
     """Lambda_L2Net.forward_single_L (Lambda_L2.py:96-103)."""
-    return [_tower(sd, f, 'L_convs', 'retina_L', relu_out=True) for f in feats]
+    return [_tower(sd, f, 'L_convs', 'retina_L', relu_out=True, lvl=l) for l, f in enumerate(feats)]
 
 
 def nhwc_flat(x, c):

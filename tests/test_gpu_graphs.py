@@ -13,6 +13,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(params=['bf16', 'bf16x3'])
+def arithmetic(request):
+    """The replayed step must equal the eager one.  In the fast mode the fp32 atomics of the column sums never reach an operand (8-bit
+    roundings absorb them), so the two agree for as long as one cares to look.  In the reference-precision mode a 1e-7 difference in a bias DOES
+    reach the 16-bit operands, and these tests' deliberately large steps amplify it: there the comparison runs in the
+    deterministic mode (ordered column sums), where eager and replayed iterations are the same bits."""
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision(request.param)
+    if request.param == 'bf16x3':
+        AF.set_deterministic(True)
+    yield request.param
+    AF.set_deterministic(False)
+    AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
+
+
 def _build():
     from aod_meh_hua_amd.mmcv_lite import Config
     from aod_meh_hua_amd.models import build_detector
@@ -47,7 +62,7 @@ def _eager_iter(model, opt, opt_L, data):
     return float(out['loss'].detach()), float(lossL['loss'].detach())
 
 
-def test_graphed_train_step_equals_eager():
+def test_graphed_train_step_equals_eager(arithmetic):
     from aod_meh_hua_amd.graphs import GraphedTrainStep
     batches = [_batch(31), _batch(32), _batch(33)]
     lrs = [2e-4, 2e-4, 5e-5]
@@ -101,7 +116,7 @@ def test_graphed_score_equals_eager_and_follows_inputs():
     assert gsc.maybe(synth.images(1, 128, 128).cuda(), synth.metas(1, 128, 128), torch.zeros(1, dtype=torch.int64, device='cuda')) is None
 
 
-def test_capture_applies_the_batch_once_and_eager_iterations_may_interleave():
+def test_capture_applies_the_batch_once_and_eager_iterations_may_interleave(arithmetic):
     """(a) maybe() returns None for a first-seen shape, captures on its second consecutive appearance and from then on replays
     it from the cache, also after other shapes ran eagerly in between; (b) every path applies exactly one update per batch: the sequence
     graph / eager / graph equals three eager iterations; (c) an eager iteration between replays (zero_grad(set_to_none) rebinding .grad)
@@ -146,7 +161,7 @@ def _ragged_batch(seed, shapes, H=128, W=160):
     return dict(img=img.cuda(), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
 
 
-def test_one_graph_serves_batches_that_differ_only_in_their_per_image_shapes():
+def test_one_graph_serves_batches_that_differ_only_in_their_per_image_shapes(arithmetic):
     """keep-ratio VOC batches of one padded tensor shape differ in their per-image pad shapes (valid-anchor flags), image
     sizes and scale factors (box clipping / rescaling in the scoring pass).  Those are STATIC device inputs of the captured graphs
     (L_AnchorHead.get_targets_batch, scoring.static_meta): the second batch REPLAYS the graph captured on the first and must equal eager."""

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from oracle import losses as olosses
 from tests import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("bf16_mode")]      # the FAST mode's own kernels (plain bf16 operands handed to hipops directly)
 
 G = os.path.join(os.path.dirname(__file__), 'golden')
 

@@ -92,7 +92,7 @@ def test_pool_scores_are_batching_and_sharding_invariant(pool_model, monkeypatch
             assert parts[-1].shape == (hi - lo,)
         # ... and of the INTERLEAVED partition (AOD_POOL_SHARD=interleaved: global batch k -> rank k mod 2)
         monkeypatch.setenv('AOD_POOL_SHARD', 'interleaved')
-        monkeypatch.setattr(apis_test, 'gather_scores_indexed', lambda local, idx, n_total: (local, idx))
+        monkeypatch.setattr(apis_test, 'gather_scores_indexed', lambda local, idx, n_total, per=None: (local, idx))
         inter = np.full(N_POOL, np.nan, np.float32)
         for r in range(2):
             monkeypatch.setattr(apis_test, 'get_dist_info', lambda r=r: (r, 2))

@@ -72,6 +72,8 @@ def test_bf16x3_mode_collapses_the_deviation_from_the_reference_golden():
     # same kernels, split operands: fp32-level agreement with the reference (the reference's own CPU summation order differs at ~1e-6)
     assert dev3['loss'] < 1e-4 and dev3['log_vars'] < 1e-4 and dev3['loss_L'] < 2e-4, dev3
     assert dev3['feat_l4'] < 2e-4 and dev3['cls_l3'] < 2e-4 and dev3['loss_noR_l4'] < 5e-4, dev3
+    # (gradient norms: bounded by the ReLU sign flips of elements within the forward rounding error of zero -- next test; the arithmetic
+    # of the backward pass itself holds 5e-5 once both sides walk the same branch)
     assert dev3['grad_norms'] < 2e-3 and dev3['grad_norms_L'] < 2e-3, dev3
     # and the product mode's residuals were rounding: they shrink by more than an order of magnitude in every quantity that is
     # measurably off in bf16
@@ -164,3 +166,70 @@ def test_bf16x3_scoring_pass_matches_the_fp32_oracle_and_replays_as_a_graph():
     # -- one pair of ~100 moves a score by ~0.3 % --, everything else agrees to 1e-5
     assert np.allclose(u3, ref_unc, rtol=1e-2), (u3, ref_unc)
     assert np.abs(u3 - ref_unc).min() / ref_unc.max() < 1e-4
+
+
+@pytest.mark.parametrize('size', [128, 256])
+def test_bf16x3_gradient_residual_is_relu_sign_flips(size):
+    """VERDICT r4 item 2.  The gradients of the reference-precision mode sit 1e-3 (worst tensor 3e-3 ... 5e-3) from the fp32 / fp64 oracle's
+    where its losses and features sit 1e-6 ... 1e-5.  Root cause, asserted here over ALL ~170 trainable tensors of both optimizer steps: 16-bit
+    operands put ~4 of every million ReLU inputs on the other side of zero than exact arithmetic does (25 of 5.5 M elements at 2 x 128^2); the
+    VALUES move by the rounding error, but a flipped element hands its WHOLE upstream gradient on (or blocks it), so a tensor's relative gradient
+    error is sqrt(share of the squared gradient carried by flipped elements) -- a property of any arithmetic with 1e-5 forward error in front of
+    a ReLU, not of the backward kernels.  With the HIP run's own ReLU sign pattern injected into the fp64 oracle (oracle.model.relu_masks: both
+    backward passes then walk the same piecewise-linear branch) every gradient agrees to 1e-4 (measured: worst 3.7e-5 / 4.6e-5, median 3e-5).
+    The fp32 oracle against the fp64 one shows the same mechanism at its own, 100 x smaller, flip rate (profiles/r05_x3_grad_error_*.json)."""
+    from aod_meh_hua_amd import functional as AF
+    from tests.maskcap import capture_relu_masks
+    model, sd0 = _model()
+    B, H = 2, size
+    gtb, gtl = synth.random_gts(B, H, H, seed=24, gmin=1, gmax=3)
+    img = synth.images(B, H, H)
+    data = dict(img=img.cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=[b.cuda() for b in gtb], gt_labels=[l.cuda() for l in gtl])
+    AF.set_precision('bf16x3')
+    with capture_relu_masks(model) as masks:
+        out, head_out, feat_out, prev = model.train_step(data, Labeled=True, Pseudo=False)
+    model.zero_grad()
+    out['loss'].backward()
+    pd = dict(model.named_parameters())
+    grads = {k: pd[k].grad.detach().double().cpu().clone() for k in pd if pd[k].grad is not None}
+    with capture_relu_masks(model, masks):
+        lossL = model.train_step_L(prev, head_out, feat_out)
+    model.zero_grad()
+    lossL['loss'].backward()
+    gradsL = {k: pd[k].grad.detach().double().cpu().clone() for k in pd if pd[k].grad is not None}
+    torch.cuda.synchronize()
+    assert len(masks) == 104, len(masks)          # 13 trainable blocks x 3 + (4 x 3 towers + retina_L) x 5 levels
+
+    def oracle(masked):
+        sd = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and not any(s in k for s in ('running', 'backbone.conv1.', 'backbone.bn1.', 'layer1.')):
+                v.requires_grad_(True)
+        import contextlib
+        with (omodel.relu_masks(masks) if masked else contextlib.nullcontext()):
+            o = omodel.train_step(sd, img.double(), gtb, gtl)
+            o['loss'].backward()
+            g1 = {k: v.grad.clone() for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+            for v in sd.values():
+                if v.is_floating_point():
+                    v.grad = None
+            oL = omodel.train_step_L(sd, o['feats'], o['loss_noR'], o['targets'])
+            oL['loss'].backward()
+            gL = {k: v.grad.clone() for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+        return float(o['loss']), g1, gL
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    lp, p1, pL = oracle(False)
+    lm, m1, mL = oracle(True)
+    assert abs(float(out['loss']) - lp) <= 1e-5 * abs(lp) and abs(lm - lp) <= 1e-6 * abs(lp)       # values: the flips move nothing measurable
+    raw, msk = [], []
+    for gh, gp, gm in ((grads, p1, m1), (gradsL, pL, mL)):
+        for k, ref in gm.items():
+            if k in gh and float(ref.norm()) > 0:
+                raw.append(float((gh[k] - gp[k]).norm() / gp[k].norm()))
+                msk.append(float((gh[k] - ref).norm() / ref.norm()))
+    assert len(msk) >= 170, len(msk)
+    print(f'{B}x{H}^2: {len(msk)} tensors; gradient error vs the fp64 oracle: worst {max(raw):.2e} median {np.median(raw):.2e}; '
+          f'with the HIP ReLU sign pattern: worst {max(msk):.2e} median {np.median(msk):.2e}')
+    assert max(msk) < 1e-4, max(msk)
+    assert max(raw) < 1e-2 and np.median(raw) < 2e-3, (max(raw), np.median(raw))

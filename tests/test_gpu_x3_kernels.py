@@ -347,3 +347,68 @@ def test_x3_fused_bottleneck64_equals_the_three_launch_block(shape):
             finally:
                 os.environ.pop('AOD_FUSE_BOTTLENECK_DS', None)
             assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 13, 37), (3, 7, 129), (16, 64, 64)])
+def test_x3_fused_bottleneck128_equals_the_three_launch_block(shape):
+    """aod_bottleneck128x3_fwd (identity blocks of the 128-plane stage in the reference-precision mode: conv1 on the halo, conv2 with the tap
+    innermost against a streamed filter ring, conv3 + residual in registers, one launch) against the same block as three x3 conv launches --
+    same products in the same order per accumulator -> identical bits --, as the inference / frozen forward and as the forward of a training
+    step (kept intermediates, autograd nodes recorded around the launch's outputs: identical gradients), and against fp32; whole and ragged
+    tiles."""
+    import os
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.models.backbones.resnet import Bottleneck
+    import torch.nn as nn
+    B, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(23)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    blk = Bottleneck(512, 128).cuda().eval()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(rnd(*m.weight.shape) / (m.weight[0].numel()) ** 0.5)
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, device='cuda', generator=g) + 0.5); m.bias.copy_(rnd(*m.bias.shape) * 0.1)
+                m.running_mean.copy_(rnd(*m.bias.shape) * 0.1); m.running_var.copy_(torch.rand(m.bias.shape, device='cuda', generator=g) + 0.5)
+    x = rnd(B, 512, H, W)
+    xx = AF.as_nchw(_x(x), B, H, W)
+
+    def run(fused, train):
+        os.environ['AOD_FUSE_BOTTLENECK128_X3'] = '1' if fused else '0'
+        try:
+            if not train:
+                with torch.no_grad():
+                    assert AF.bottleneck128_applies(blk, xx) == fused
+                    return blk(xx), None
+            xi = xx.detach().clone().requires_grad_()
+            assert AF.bottleneck128_train_applies(blk, xi) == fused
+            for q in blk.parameters():
+                q.grad = None
+            y = blk(xi)
+            gy = AF.as_nchw(_x(torch.randn(B, 512, H, W, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))), B, H, W)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach(), [xi.grad.clone()] + [q.grad.clone() for q in blk.parameters()]
+        finally:
+            os.environ.pop('AOD_FUSE_BOTTLENECK128_X3', None)
+
+    y1, _ = run(True, False)
+    y0, _ = run(False, False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        bnf = lambda z, n: F.batch_norm(z, n.running_mean, n.running_var, n.weight, n.bias, False, 0.0, n.eps)
+        t = torch.relu(bnf(F.conv2d(x, blk.conv1.weight), blk.norm1))
+        t = torch.relu(bnf(F.conv2d(t, blk.conv2.weight, None, 1, 1), blk.norm2))
+        ref = torch.relu(bnf(F.conv2d(t, blk.conv3.weight), blk.norm3) + x)
+    f1 = _f(AF.as_rows(y1), B, H, W, 512)
+    assert _err(f1, ref) < 1e-4, _err(f1, ref)
+    assert torch.equal(y1, y0), float((AF.as_rows(y1).float() - AF.as_rows(y0).float()).abs().max())
+    # training forward: the same output bits, and -- because the kept intermediates are the bits the separate launches store -- the same gradients
+    for q in blk.parameters():
+        q.requires_grad_(True)
+    yt1, g1 = run(True, True)
+    yt0, g0 = run(False, True)
+    assert torch.equal(yt1, y1) and torch.equal(yt0, y0)
+    for a, b_ in zip(g1, g0):
+        assert torch.equal(a, b_), float((a.float() - b_.float()).abs().max())
