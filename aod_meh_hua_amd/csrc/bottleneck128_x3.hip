@@ -34,6 +34,11 @@ struct Bw3Args {
   bf16_t* y;             // X rows [B*H*W][1024]
   bf16_t* t1;            // X rows [B*H*W][256] or null
   bf16_t* t2;            // X rows [B*H*W][256] or null
+  // backward form (BWD instance): ReLU masks = the block's saved activations (X rows: the head decides the sign), fp32 column sums of the results
+  const bf16_t* m1;      // [B*H*W][256]    mask of the first product  (forward t2)
+  const bf16_t* m2;      // [B*H*W][256]    mask of the second product (forward t1)
+  const bf16_t* m3;      // [B*H*W][1024]   mask of the third product  (forward x)
+  float* cs1; float* cs2; float* cs3;     // [128] [128] [512], += (atomics)
   int B, H, W, tiles_y, tiles_x;
 };
 
@@ -47,13 +52,25 @@ constexpr int T1SUB = HPIX * 128, T2SUB = TH * TW * 128;
 constexpr int OFF_VEC = OFF_T1 + 4 * T1SUB;                              // 157 696: s1 b1 s2 b2 [128] | s3 [512] | b3 [512] fp32
 constexpr int LDS_BYTES = OFF_VEC + (4 * P + 2 * 4 * P) * 4;             // 163 840 = all of the CU's LDS
 constexpr int NS2 = 36, NS = NS2 + 16;                                   // ring steps: conv2, then conv3
-static_assert(2 * STG1 <= OFF_VEC && 4 * T2SUB <= 4 * T1SUB && LDS_BYTES <= 160 * 1024, "LDS map");
+static_assert(3 * STG1 <= OFF_VEC && 4 * T2SUB <= 4 * T1SUB && LDS_BYTES <= 160 * 1024, "LDS map");
 constexpr unsigned OOB = 0xf0000000u;
+
+#ifdef AOD_TILE_TIMING
+// debug build only (tools/dbg/b128x3_timing.py): per-workgroup wall-clock stamps (100 MHz) at the phase boundaries
+__device__ unsigned long long* g_bw3_stamps = nullptr;
+#define WSTAMP(k) do { if (g_bw3_stamps && threadIdx.x == 0) g_bw3_stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define TICK() __builtin_amdgcn_s_memtime()
+#define TACC(acc, a, b) acc += (b) - (a)
+#else
+#define WSTAMP(k) do {} while (0)
+#define TICK() 0ull
+#define TACC(acc, a, b) do {} while (0)
+#endif
 
 #define AOD_VMCASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vm_dyn(int n) {      // n is wave-uniform
   switch (n) {
-    AOD_VMCASE(0) AOD_VMCASE(4) AOD_VMCASE(5) AOD_VMCASE(6) AOD_VMCASE(8) AOD_VMCASE(12) AOD_VMCASE(16) AOD_VMCASE(18) AOD_VMCASE(20)
+    AOD_VMCASE(0) AOD_VMCASE(4) AOD_VMCASE(5) AOD_VMCASE(6) AOD_VMCASE(8) AOD_VMCASE(12) AOD_VMCASE(16) AOD_VMCASE(18) AOD_VMCASE(20) AOD_VMCASE(22) AOD_VMCASE(24)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -80,16 +97,45 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& l
 //   t2 stores x8 | step s: [wait S_s] barrier, S_{s+3}, (first step of a chunk: 8 residual loads) ... (last step of a chunk: [wait the
 //   residual loads] epilogue, 8 output stores)                                                                (conv3: s = 36 .. 51)
 // WAIT[s] = operations younger than slice s at its wait (they may stay in flight); RESW = younger than a chunk's residual loads at its epilogue.
+// BWD: 4 mask loads of the second epilogue behind the t1 stores, and 12 loads (8 residual + 4 mask pieces) per chunk instead of 8.
+// (pipelined form: step s waits for slice s + 1 -- four slices go out ahead of the loop, step s issues slice s + 4)
+template <bool BWD>
+__device__ __forceinline__ int wait_pro() { return 6 + 12 + (BWD ? 4 : 0); }
+template <bool BWD>
 __device__ __forceinline__ int wait_of(int s) {
-  if (s < 3) return 16;
+  constexpr int R = BWD ? 12 : 8, MK2 = BWD ? 4 : 0;
+  if (s < 3) return 16 + MK2;
   if (s < NS2) return 4;
-  if (s == NS - 1) return 8;
-  if (s == NS - 2) return 18;
+  if (s == NS - 2) return 8 + R;                  // (slice 51: the last chunk's residual loads and the stores of the chunk before are younger)
+  if (s == NS - 3) return 10 + R;
   const int kg = (s - NS2) & 3;
-  return (kg == 0 || kg == 3) ? 12 : 20;
+  return kg == 0 ? 12 : (kg == 3 ? 4 + R : 12 + R);
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck128x3_fwd_kernel(const Bw3Args p) {
+// bit j of the result: element j of the 16-B piece (8 bf16 heads) is > 0 -- the ReLU mask of 8 channels in 8 bits
+__device__ __forceinline__ unsigned pos_bits(const u32x4_t q) {
+  unsigned m = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    m |= (__uint_as_float(q[w] << 16) > 0.f ? 1u : 0u) << (2 * w);
+    m |= (__uint_as_float(q[w] & 0xffff0000u) > 0.f ? 1u : 0u) << (2 * w + 1);
+  }
+  return m;
+}
+// sum over the 16 lanes that share lq (one DPP row): four rotate-and-add steps on the vector ALU, every lane ends up with the total
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum_lr(float v) {
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+  return v;
+}
+
+// BWD: the same three products are the block's DGRAD chain (csrc/conv.hip dgrad epilogue semantics: result = mask > 0 ? acc (+ res) : 0,
+// fp32 column sums of the results): x = the finished gradient G of the block output, w1 / w2 / w3 = the scale-folded X dgrad filters of
+// conv3 / conv2 / conv1, t1 / t2 / y = the gradients of forward t2 / t1 / x, residual = G (the skip branch).
+template <bool BWD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck128x3_kernel(const Bw3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -125,7 +171,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // folded BN vectors -> LDS once (an ordinary global load beside LDS-DMA makes hipcc drain the DMA queue where the value is used)
   float* const vec = reinterpret_cast<float*>(smem + OFF_VEC);
-  {
+  // BWD: the column sums of the three results are collected in LDS (ds_add_f32) and leave the workgroup as ONE global atomic per channel
+  float* const csl = vec;                          // [0, 512): third result, [512, 640): first, [640, 768): second
+  if constexpr (BWD) {
+    vec[t] = 0.f;
+    if (t < 2 * P) vec[512 + t] = 0.f;
+  } else {
     if (t < 128) vec[t] = p.s1[t];
     else if (t < 256) vec[t] = p.b1[t - 128];
     else if (t < 384) vec[t] = p.s2[t - 256];
@@ -135,7 +186,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const float* const vs1 = vec, * const vb1 = vec + 128, * const vs2 = vec + 256, * const vb2 = vec + 384, * const vs3 = vec + 512, * const vb3 = vec + 1024;
 
+  WSTAMP(0);
   // ------------------------------------------------------------------ phase 1: t1 = relu(bn1(conv1(x))) on the halo
+  const auto rsrc_m1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m1, 0, BWD ? (int)(npix * XP * 2) : 0, 0x00020000);
+  const auto rsrc_m2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m2, 0, BWD ? (int)(npix * XP * 2) : 0, 0x00020000);
+  const auto rsrc_m3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.m3, 0, BWD ? (int)(npix * XC * 2) : 0, 0x00020000);
+  u32x4_t mk1[3][2];                               // BWD: head pieces of the masks of this lane's halo pixels (out-of-image pixels read 0 = masked)
+  if constexpr (BWD) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int h = (3 * wp + i) * 16 + lr;
+      int y, x;
+      const unsigned hrow = halo_pix(h, y, x) ? (unsigned)((img0 + (long long)y * p.W + x) * (XP * 2)) : OOB;
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) mk1[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m1, (int)(hrow + (unsigned)((2 * wc + jp) * 128 + lq * 16)), 0, 0);
+    }
+  }
   unsigned xoff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -146,90 +212,144 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned w1off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) w1off[i] = (unsigned)(((8 * (uw + 8 * i) + drow) * XC + kcw * 8) * 2);
-  auto issue1 = [&](int buf) {                   // 3 x-halo instructions + 2 filter instructions per wave and stage
+  // (the K offset of a stage rides in the instruction's scalar offset: no per-stage vector arithmetic.  The loops of all three phases are
+  // fully unrolled and every LDS fragment address is a per-lane constant from a table built once + an immediate: with run-time step indices
+  // the ~70 vector instructions of address arithmetic per wave and step outran the issue slots the MFMAs leave -- 1 400 cycles per conv2 step
+  // for 768 cycles of matrix work, tools/dbg/b128x3_timing.py)
+  auto issue1 = [&](int buf, int kt) {            // 3 x-halo instructions + 2 filter instructions per wave and stage
     char* xs = smem + buf * STG1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const unsigned off = xoff[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(xs + (uw + 8 * i) * 1024), 16, off, 0, 0, 0);
-      xoff[i] += 128;                                  // (an OOB row stays out of range)
+      const unsigned off = xoff[i];               // (an OOB row stays out of range)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(xs + (uw + 8 * i) * 1024), 16, off, kt * 128, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned off = w1off[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(xs + XCH + (uw + 8 * i) * 1024), 16, off, 0, 0, 0);
-      w1off[i] += 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(xs + XCH + (uw + 8 * i) * 1024), 16, off, kt * 128, 0, 0);
     }
   };
+  // per-lane fragment addresses (heads; the tails sit 64 B further: chunk 4 + lq = the head's slot ^ 4)
+  unsigned wfrag[4], xfrag1[3], afrag2[2][9], afrag3[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wfrag[j] = (unsigned)wswz(wrow(4 * wc + j, lr), lq);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xfrag1[i] = (unsigned)swz((3 * wp + i) * 16 + lr, lq);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r0_ = tap / 3, q0_ = tap - r0_ * 3;
+      const int r = BWD ? 2 - r0_ : r0_, q = BWD ? 2 - q0_ : q0_;      // dgrad: tap (r, s) of the [I][R][S][O] pack reads pixel (y + 1 - r, x + 1 - s)
+      afrag2[i][tap] = (unsigned)(OFF_T1 + swz((2 * wp + i + r) * HW_ + lr + q, lq));
+    }
+    afrag3[i] = (unsigned)(OFF_T1 + swz((2 * wp + i) * 16 + lr, lq));
+  }
+  auto lds16 = [&](unsigned a) { return *reinterpret_cast<const bf16x8*>(smem + a); };
   f32x4 acc1[3][4];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // K loop, software-pipelined: THREE stages (the t1 area is dead until the epilogue), the fragments of K-step kt + 1 are read into a second
+  // register set while the MFMAs of step kt run -- with one set the eight waves read in a burst behind every barrier and the matrix pipe
+  // waited for it (2 225 cycles per step against 1 152 of MFMA work; tools/dbg/b128x3_timing.py)
   constexpr int NK1 = XC / 64;
-  issue1(0);
-  issue1(1);
-  for (int kt = 0; kt < NK1; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < NK1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (kt == 0: this thread's vec[] stores)
-    __builtin_amdgcn_s_barrier();                 // every wave's part of stage kt has landed
-    __builtin_amdgcn_sched_barrier(0);
-    const char* xs = smem + buf * STG1;
-    const char* ws = xs + XCH;
-    bf16x8 wh[4], wl[4];
+  struct F1 { bf16x8 wh[4], wl[4], xh[3], xl[3]; };
+  auto read1 = [&](int buf, F1& f) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      wh[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), lq));
-      wl[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), 4 + lq));
+      f.wh[j] = lds16(buf * STG1 + XCH + wfrag[j]);
+      f.wl[j] = lds16(buf * STG1 + XCH + (wfrag[j] ^ 64u));
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int row = (3 * wp + i) * 16 + lr;
-      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xs + swz(row, lq)), xl = *reinterpret_cast<const bf16x8*>(xs + swz(row, 4 + lq));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // (the order of conv_igemm_kernel<X3>: heads x heads, activation tails x filter heads, activation heads x filter tails)
-        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh, acc1[i][j], 0, 0, 0);
-        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl, acc1[i][j], 0, 0, 0);
-        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh, acc1[i][j], 0, 0, 0);
-      }
+      f.xh[i] = lds16(buf * STG1 + xfrag1[i]);
+      f.xl[i] = lds16(buf * STG1 + (xfrag1[i] ^ 64u));
     }
+  };
+  auto mma1 = [&](const F1& f) {
+    // per accumulator the order of conv_igemm_kernel<X3> -- heads x heads, activation tails x filter heads, activation heads x filter tails --,
+    // product-major over the accumulators so that no MFMA waits for the one before it
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[j], f.xh[i], acc1[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[j], f.xl[i], acc1[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[j], f.xh[i], acc1[i][j], 0, 0, 0);
+  };
+  // one pipeline step: stage kt + 1 has landed for every wave and every wave holds the fragments of stage kt in registers (so its buffer
+  // takes stage kt + 3); then the reads of kt + 1 go out and the MFMAs of kt run beside them
+  auto step1 = [&](int kt, const F1& cur, F1& nxt) {
+    if (kt + 1 < NK1) {
+      if (kt + 2 < NK1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of stage kt are complete
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // every wave is done reading stage kt: its buffer can be refilled
-    if (kt + 2 < NK1) issue1(buf);
+    if (kt + 3 < NK1) issue1(kt % 3, kt + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < NK1) read1((kt + 1) % 3, nxt);
+    mma1(cur);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  issue1(0, 0);
+  issue1(1, 1);
+  issue1(2, 2);
+  F1 fa, fb;
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (this thread's vec[] stores)
+  __builtin_amdgcn_s_barrier();                   // every wave's part of stage 0 has landed
+  __builtin_amdgcn_sched_barrier(0);
+  read1(0, fa);
+#pragma unroll
+  for (int kt = 0; kt < NK1; kt += 2) {
+    step1(kt, fa, fb);
+    step1(kt + 1, fb, fa);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                   // every wave is done with the stages
 
-  // the stages are dead: the first three filter slices stream into the ring under epilogue 1
+  WSTAMP(1);
+  // the stages are dead: the first four filter slices stream into the ring under epilogue 1
   unsigned w2lane[2], w3lane[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     w2lane[i] = (unsigned)(((8 * (uw + 8 * i) + drow) * 9 * XP + kcw * 8) * 2);
     w3lane[i] = (unsigned)(((8 * (uw + 8 * i) + drow) * XP + kcw * 8) * 2);
   }
-  auto issue_slice = [&](int s) {                // s: ring step (wave-uniform); conv2 step = channel group * 9 + tap, conv3 step = chunk * 4 + group
+  auto issue_slice = [&](int s) {                // s: ring step (compile-time after unrolling); conv2 step = channel group * 9 + tap, conv3 step = chunk * 4 + group
     char* dst = smem + (s & (NSLOT - 1)) * SLOT;
     if (s < NS2) {
       const int cg = s / 9, tap = s - cg * 9;
-      const unsigned koff = (unsigned)((tap * XP + cg * 64) * 2);
+      const int koff = (tap * XP + cg * 64) * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (__attribute__((address_space(3))) void*)(dst + (uw + 8 * i) * 1024), 16, w2lane[i] + koff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (__attribute__((address_space(3))) void*)(dst + (uw + 8 * i) * 1024), 16, w2lane[i], koff, 0, 0);
     } else {
       const int q = s - NS2, n3 = q >> 2, kg = q & 3;
-      const unsigned koff = (unsigned)((n3 * P * XP + kg * 64) * 2);
+      const int koff = (n3 * P * XP + kg * 64) * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(dst + (uw + 8 * i) * 1024), 16, w3lane[i] + koff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(dst + (uw + 8 * i) * 1024), 16, w3lane[i], koff, 0, 0);
     }
   };
   issue_slice(0);
   issue_slice(1);
   issue_slice(2);
+  issue_slice(3);
+  __builtin_amdgcn_sched_barrier(0);
   // epilogue 1: t1 -> LDS (zero outside the image) and, for the tile's own pixels, -> global (training forward)
+  u32x4_t mk2[2][2];                              // BWD: mask pieces of the second epilogue (forward t1 at the tile's own pixels)
   {
     char* t1 = smem + OFF_T1;
+    float cs1v[2][8] = {};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int h = (3 * wp + i) * 16 + lr;
@@ -242,11 +362,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int jp = 0; jp < 2; ++jp) {
         const int c = 64 * wc + 32 * jp + lq * 8;
         float v[8];
+        if constexpr (BWD) {
+          const unsigned mb = pos_bits(mk1[i][jp]);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(vs1 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb1 + c + 4 * q);
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * q + r] = ok ? fmaxf(acc1[i][2 * jp + q][r] * sc[r] + sh[r], 0.f) : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              v[4 * q + r] = ((mb >> (4 * q + r)) & 1u) ? acc1[i][2 * jp + q][r] + 0.f : 0.f;
+              cs1v[jp][4 * q + r] += inner ? v[4 * q + r] : 0.f;
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(vs1 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb1 + c + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = ok ? fmaxf(acc1[i][2 * jp + q][r] * sc[r] + sh[r], 0.f) : 0.f;
+          }
         }
         bf16x8 oh, ol;
         split8(v, oh, ol);
@@ -259,52 +390,101 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), rsrc_t1, (int)(grow + col + 64u), 0, 0);
       }
     }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int y = ty0 + 2 * wp + i, x = tx0 + lr;
+        const unsigned r2 = (y < p.H && x < p.W) ? (unsigned)((img0 + (long long)y * p.W + x) * (XP * 2)) : OOB;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) mk2[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m2, (int)(r2 + (unsigned)((2 * wc + jp) * 128 + lq * 16)), 0, 0);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = sum_lr(cs1v[jp][j]);
+          if (lr == 0) atomicAdd(csl + 4 * P + 64 * wc + 32 * jp + lq * 8 + j, v);
+        }
+    }
   }
 
+  WSTAMP(2);
   // ------------------------------------------------------------------ phase 2: t2 = relu(bn2(conv2(t1))), filter slices through the ring
   f32x4 acc2[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {
-    int cg = 0, tap = 0;
-    for (int s = 0; s < NS2; ++s) {
-      wait_vm_dyn(wait_of(s));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (s == 0: this wave's t1 pieces are written)
-      __builtin_amdgcn_s_barrier();               // slice s complete; every wave is done with step s - 1 (its slot is free)
-      __builtin_amdgcn_sched_barrier(0);
-      issue_slice(s + 3);                         // (always <= 51 here)
-      const int r = tap / 3, q = tap - r * 3;
-      const char* t1 = smem + OFF_T1 + cg * T1SUB;
-      const char* ws = smem + (s & (NSLOT - 1)) * SLOT;
-      bf16x8 wh[4], wl[4];
+  // Ring steps, software-pipelined like phase 1: at step s every wave holds the fragments of slice s in registers -- slot s % 4 takes slice
+  // s + 4 --, slice s + 1 has landed, its fragments (and the pixel fragments of step s + 1) are read while the MFMAs of step s run.
+  struct F2 { bf16x8 wh[4], wl[4], ah[2], al[2]; };
+  auto read_w = [&](int s, F2& f) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        wh[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), lq));
-        wl[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), 4 + lq));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wp + i + r) * HW_ + lr + q;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(t1 + swz(row, lq)), al = *reinterpret_cast<const bf16x8*>(t1 + swz(row, 4 + lq));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc2[i][j], 0, 0, 0);
-          acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc2[i][j], 0, 0, 0);
-          acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc2[i][j], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (++tap == 9) { tap = 0; ++cg; }
+    for (int j = 0; j < 4; ++j) {
+      f.wh[j] = lds16((s & (NSLOT - 1)) * SLOT + wfrag[j]);
+      f.wl[j] = lds16((s & (NSLOT - 1)) * SLOT + (wfrag[j] ^ 64u));
     }
+  };
+  auto read2 = [&](int s, F2& f) {                // conv2 step s = channel group * 9 + tap
+    read_w(s, f);
+    const int cg = s / 9, tap = s - cg * 9;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.ah[i] = lds16(cg * T1SUB + afrag2[i][tap]);
+      f.al[i] = lds16(cg * T1SUB + (afrag2[i][tap] ^ 64u));
+    }
+  };
+  auto mma2 = [&](const F2& f, f32x4 (&acc)[2][4]) {      // (product-major: see mma1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[j], f.ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wh[j], f.al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wl[j], f.ah[i], acc[i][j], 0, 0, 0);
+  };
+  [[maybe_unused]] unsigned long long tk_wait = 0, tk_lds = 0, tk_bar = 0, tk_work = 0;
+  auto step2 = [&](int s, const F2& cur, F2& nxt) {
+    [[maybe_unused]] const unsigned long long c0 = TICK();
+    wait_vm_dyn(wait_of<BWD>(s));                 // slice s + 1 has landed (this wave's part)
+    [[maybe_unused]] const unsigned long long c1 = TICK();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of slice s are complete
+    [[maybe_unused]] const unsigned long long c2 = TICK();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] const unsigned long long c3 = TICK();
+    issue_slice(s + 4);                           // (always <= 51 here)
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < NS2) read2(s + 1, nxt);           // (the pixel fragments of step 36 do not exist yet: t2 is this phase's result)
+    mma2(cur, acc2);
+    __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] const unsigned long long c4 = TICK();
+    TACC(tk_wait, c0, c1); TACC(tk_lds, c1, c2); TACC(tk_bar, c2, c3); TACC(tk_work, c3, c4);
+  };
+  F2 ga, gb;
+  wait_vm_dyn(wait_pro<BWD>());                   // slice 0 (younger: slices 1 - 3, the t1 stores, BWD: the mask loads)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's t1 pieces are written
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read2(0, ga);
+#pragma unroll
+  for (int s = 0; s < NS2; s += 2) {
+    step2(s, ga, gb);
+    step2(s + 1, gb, ga);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // every wave is done reading t1: t2 goes over it
   __builtin_amdgcn_sched_barrier(0);
+  WSTAMP(3);
   unsigned prow[2];                               // byte offset of the lane's pixel rows in a [B*H*W][1024] X tensor
   {
     char* t2 = smem + OFF_T1;
+    float cs2v[2][8] = {};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int y = ty0 + 2 * wp + i, x = tx0 + lr;
@@ -316,11 +496,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int jp = 0; jp < 2; ++jp) {
         const int c = 64 * wc + 32 * jp + lq * 8;
         float v[8];
+        if constexpr (BWD) {
+          const unsigned mb = pos_bits(mk2[i][jp]);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(vs2 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb2 + c + 4 * q);
+          for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaxf(acc2[i][2 * jp + q][r] * sc[r] + sh[r], 0.f);
+            for (int r = 0; r < 4; ++r) {
+              v[4 * q + r] = ((mb >> (4 * q + r)) & 1u) ? acc2[i][2 * jp + q][r] + 0.f : 0.f;
+              cs2v[jp][4 * q + r] += v[4 * q + r];
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(vs2 + c + 4 * q), sh = *reinterpret_cast<const f32x4*>(vb2 + c + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaxf(acc2[i][2 * jp + q][r] * sc[r] + sh[r], 0.f);
+          }
         }
         bf16x8 oh, ol;
         split8(v, oh, ol);
@@ -331,9 +522,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), rsrc_t2, (int)(grow + col + 64u), 0, 0);
       }
     }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = sum_lr(cs2v[jp][j]);
+          if (lr == 0) atomicAdd(csl + 5 * P + 64 * wc + 32 * jp + lq * 8 + j, v);
+        }
+    }
   }
 
+  WSTAMP(4);
   // ------------------------------------------------------------------ phase 3: y = relu(bn3(conv3(t2)) + x), 4 chunks of 128 output channels
+  auto read3 = [&](int s, F2& f) {                // conv3 step s = 36 + chunk * 4 + channel group
+    read_w(s, f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.ah[i] = lds16(((s - NS2) & 3) * T2SUB + afrag3[i]);
+      f.al[i] = lds16(((s - NS2) & 3) * T2SUB + (afrag3[i] ^ 64u));
+    }
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's t2 pieces are written
+  __builtin_amdgcn_s_barrier();                   // t2 complete (slice 36 was waited for at step 35)
+  __builtin_amdgcn_sched_barrier(0);
+  read3(NS2, ga);
 #pragma unroll
   for (int n3 = 0; n3 < 4; ++n3) {
     f32x4 acc3[2][4];
@@ -341,15 +554,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4_t rh[2][2], rl[2][2];
+    u32x4_t rh[2][2], rl[2][2], mk3[2][2];
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       const int s = NS2 + n3 * 4 + kg;
-      wait_vm_dyn(wait_of(s));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (first step: this wave's t2 pieces are written)
+      if (s + 1 < NS) wait_vm_dyn(wait_of<BWD>(s));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 3 < NS) issue_slice(s + 3);
+      if (s + 4 < NS) issue_slice(s + 4);
       if (kg == 0) {
         // residual pieces of this chunk (x was read by this XCD for conv1: L2 hits); 16-B heads and tails of the lane's 8 channels
 #pragma unroll
@@ -360,33 +573,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rh[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(prow[i] + col), 0, 0);
             rl[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(prow[i] + col + 64u), 0, 0);
           }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const char* t2 = smem + OFF_T1 + kg * T2SUB;
-      const char* ws = smem + (s & (NSLOT - 1)) * SLOT;
-      bf16x8 wh[4], wl[4];
+        if constexpr (BWD) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        wh[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), lq));
-        wl[j] = *reinterpret_cast<const bf16x8*>(ws + wswz(wrow(4 * wc + j, lr), 4 + lq));
-      }
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wp + i) * 16 + lr;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(t2 + swz(row, lq)), al = *reinterpret_cast<const bf16x8*>(t2 + swz(row, 4 + lq));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc3[i][j], 0, 0, 0);
-          acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc3[i][j], 0, 0, 0);
-          acc3[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc3[i][j], 0, 0, 0);
+            for (int jp = 0; jp < 2; ++jp)
+              mk3[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_m3, (int)(prow[i] + (unsigned)((n3 * 4 + 2 * wc + jp) * 128 + lq * 16)), 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (s + 1 < NS) read3(s + 1, (kg & 1) ? ga : gb);
+      mma2((kg & 1) ? gb : ga, acc3);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // the chunk's residual loads have landed when at most the slices issued since (3, or none behind the last chunk) are in flight
+    // the chunk's residual (and mask) loads have landed when at most the slices issued since (3, or none behind the last chunk) are in flight
     if (n3 < 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    float c3v[2][8] = {};                         // BWD: this lane's column sums of the chunk (its two pixel rows)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -396,45 +599,106 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float v[8];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(vs3 + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vb3 + c + 4 * h2);
+          if constexpr (BWD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * h2 + r] = acc3[i][2 * jp + h2][r] * sc[r] + sh[r];
+            for (int r = 0; r < 4; ++r) v[4 * h2 + r] = acc3[i][2 * jp + h2][r] + 0.f;
+          } else {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(vs3 + c + 4 * h2), sh = *reinterpret_cast<const f32x4*>(vb3 + c + 4 * h2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * h2 + r] = acc3[i][2 * jp + h2][r] * sc[r] + sh[r];
+          }
           v[4 * h2 + 0] += __uint_as_float(qh[2 * h2] << 16) + __uint_as_float(ql[2 * h2] << 16);
           v[4 * h2 + 1] += __uint_as_float(qh[2 * h2] & 0xffff0000u) + __uint_as_float(ql[2 * h2] & 0xffff0000u);
           v[4 * h2 + 2] += __uint_as_float(qh[2 * h2 + 1] << 16) + __uint_as_float(ql[2 * h2 + 1] << 16);
           v[4 * h2 + 3] += __uint_as_float(qh[2 * h2 + 1] & 0xffff0000u) + __uint_as_float(ql[2 * h2 + 1] & 0xffff0000u);
         }
+        if constexpr (BWD) {
+          const unsigned mb = pos_bits(mk3[i][jp]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 8; ++r) { v[r] = ((mb >> r) & 1u) ? v[r] : 0.f; c3v[jp][r] += v[r]; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
         bf16x8 oh, ol;
         split8(v, oh, ol);
         const unsigned col = (unsigned)((n3 * 4 + 2 * wc + jp) * 128 + lq * 16);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oh), rsrc_y, (int)(prow[i] + col), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), rsrc_y, (int)(prow[i] + col + 64u), 0, 0);
       }
+    if constexpr (BWD) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cs = sum_lr(c3v[jp][j]);
+          if (lr == 0) atomicAdd(csl + n3 * 128 + 64 * wc + 32 * jp + lq * 8 + j, cs);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  WSTAMP(5);
+#ifdef AOD_TILE_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WSTAMP(6);
+  if (g_bw3_stamps && (threadIdx.x & 63) == 0 && (uw == 0 || uw == 5)) {      // phase-2 cycle split of waves 0 and 5 (shader clock)
+    unsigned long long* o = g_bw3_stamps + (size_t)blockIdx.x * 16 + (uw == 0 ? 8 : 12);
+    o[0] = tk_wait; o[1] = tk_lds; o[2] = tk_bar; o[3] = tk_work;
+  }
+#endif
+  if constexpr (BWD) {                            // column sums: one global atomic per channel and workgroup
+    __syncthreads();
+    atomicAdd(p.cs3 + t, csl[t]);
+    if (t < P) atomicAdd(p.cs1 + t, csl[4 * P + t]);
+    else if (t < 2 * P) atomicAdd(p.cs2 + t - P, csl[4 * P + t]);
   }
 }
 
 }  // namespace
 
+#ifdef AOD_TILE_TIMING
+extern "C" int aod_dbg_set_bw3_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bw3_stamps), &buf, sizeof(buf)); }
+#endif
+
+static int launch_bw3(bool bwd, Bw3Args& a, int B, int H, int W, aod_stream_t stream) {
+  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck128x3: bad geometry");
+  AOD_CHECK_ARG((long long)B * H * W * XC * 2 < 0xe0000000ll, "bottleneck128x3: operand larger than 3.5 GiB");
+  AOD_CHECK_ARG((const void*)a.x != (const void*)a.y, "bottleneck128x3: the output must not alias the input (the residual is read after neighbouring tiles have stored)");
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
+  static unsigned long long attr_done = 0;
+  if (aod_first_on_device(&attr_done)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck128x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck128x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  if (bwd) hipLaunchKernelGGL(bottleneck128x3_kernel<true>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bottleneck128x3_kernel<false>, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int aod_bottleneck128x3_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1,
                                        void* t2, aod_stream_t stream) {
   AOD_CHECK_ARG(x && w1 && w2 && w3 && s1 && b1 && s2 && b2 && s3 && b3 && y, "bottleneck128x3: null pointer");
-  AOD_CHECK_ARG(B >= 1 && H >= 1 && W >= 1, "bottleneck128x3: bad geometry");
-  AOD_CHECK_ARG((long long)B * H * W * XC * 2 < 0xe0000000ll, "bottleneck128x3: operand larger than 3.5 GiB");
-  AOD_CHECK_ARG(x != y, "bottleneck128x3: y must not alias x (the residual is read after neighbouring tiles have stored)");
   Bw3Args a;
+  memset(&a, 0, sizeof(a));
   a.x = (const bf16_t*)x; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.w3 = (const bf16_t*)w3;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.y = (bf16_t*)y; a.t1 = (bf16_t*)t1; a.t2 = (bf16_t*)t2;
-  a.B = B; a.H = H; a.W = W;
-  a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
-  static unsigned long long attr_done = 0;
-  if (aod_first_on_device(&attr_done))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck128x3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL(bottleneck128x3_fwd_kernel, dim3(B * a.tiles_y * a.tiles_x), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-  AOD_LAUNCH_CHECK();
-  return 0;
+  return launch_bw3(false, a, B, H, W, stream);
+}
+
+extern "C" int aod_bottleneck128x3_bwd(const void* g, int B, int H, int W, const void* wd3, const void* wd2, const void* wd1, const void* act_t2,
+                                       const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2,
+                                       float* colsum_t1, float* colsum_x, aod_stream_t stream) {
+  AOD_CHECK_ARG(g && wd3 && wd2 && wd1 && act_t2 && act_t1 && act_x && gx && gt2 && gt1 && colsum_t2 && colsum_t1 && colsum_x,
+                "bottleneck128x3_bwd: null pointer");
+  Bw3Args a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)g; a.w1 = (const bf16_t*)wd3; a.w2 = (const bf16_t*)wd2; a.w3 = (const bf16_t*)wd1;
+  a.y = (bf16_t*)gx; a.t1 = (bf16_t*)gt2; a.t2 = (bf16_t*)gt1;
+  a.m1 = (const bf16_t*)act_t2; a.m2 = (const bf16_t*)act_t1; a.m3 = (const bf16_t*)act_x;
+  a.cs1 = colsum_t2; a.cs2 = colsum_t1; a.cs3 = colsum_x;
+  return launch_bw3(true, a, B, H, W, stream);
 }

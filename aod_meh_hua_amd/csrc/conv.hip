@@ -739,12 +739,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
       for (int j = 0; j < 8; ++j) v[j] = v[j] * cs1[j] + cb1[j];
       if (OPS > 1 && p.res) {
         const bf16x8 rv = PREFETCH ? pres[it] : *reinterpret_cast<const bf16x8*>(p.res + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
         if (xout) {
+          // v + (head + tail), the association of the fast path above (and of the fused bottleneck kernels): a ragged tile must not round an
+          // element differently from an interior one -- (v + head) + tail differs in the last bit for ~0.2 % of the elements, which made a
+          // row's bits depend on where the tile boundaries fall (i.e. on the batch size)
           const bf16x8 rl = *reinterpret_cast<const bf16x8*>(p.res + off + 32);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)rl[j];
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j] + (float)rl[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
         }
       }
       if (OPS > 0 && g_mask) {
@@ -2067,7 +2071,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ d
 // Slab form: dw = [nslabs][Opad][RS][Ipad] partial sums written by conv_wgrad_kernel's splits; one block per output channel adds the
 // slabs IN ORDER (deterministic), reading each slab row with consecutive lanes on consecutive channels, transposes [rs][c] -> [c][rs]
 // through LDS and writes the OIHW gradient with consecutive lanes on consecutive elements.
-constexpr int UNP_CH = 1024;      // channels per LDS chunk (x RS <= 9 taps)
+constexpr int UNP_CH = 1024;      // channels per LDS chunk at RS <= 9 taps (9 216 tile entries; fewer channels per chunk for 10 .. 16 taps)
 constexpr int UNP_T = 1024;       // threads: 16 waves per block keep enough slab loads in flight (one block per output channel)
 struct UnpackArgs {
   const float* dw; float* g; const float* scale; const float* w; float* wdot; const float* bn_s1; const float* bn_mean; const float* bn_invstd;
@@ -2083,8 +2087,9 @@ __device__ __forceinline__ void unpack_row(const UnpackArgs& a, int oo, float* t
   const long long slab_stride = a.slab_stride;
   const float sc = a.scale ? a.scale[oo] : 1.f;
   float dot = 0.f;
-  for (int c0 = 0; c0 < I; c0 += UNP_CH) {
-    const int nc = min(UNP_CH, I - c0);
+  const int CH = RS <= 9 ? UNP_CH : (UNP_CH * 9) / RS;            // (filters of 10 .. 16 taps -- SSD512's 4 x 4 extra conv -- take narrower chunks of the same tile)
+  for (int c0 = 0; c0 < I; c0 += CH) {
+    const int nc = min(CH, I - c0);
     for (int i = threadIdx.x; i < nc * RS; i += UNP_T) {
       const int rs = i / nc, c = i - rs * nc;                       // consecutive lanes on consecutive channels of one slab row
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                 // fixed association: ((s0+s4+..)+(s1+s5+..))+((s2+..)+(s3+..))
@@ -2312,7 +2317,7 @@ extern "C" int aod_unpack_wgrad_slabs(const float* dw_slabs, int nslabs, int64_t
                                       int accumulate, const float* scale, const float* w_oihw, float* wdot, const float* bn_s1,
                                       const float* bn_mean, const float* bn_invstd, aod_stream_t stream) {
   AOD_CHECK_ARG(dw_slabs && g && nslabs >= 1 && slab_stride > 0, "unpack_wgrad_slabs: null / empty");
-  AOD_CHECK_ARG(R * S <= 9, "unpack_wgrad_slabs: at most 9 taps (larger filters take aod_unpack_wgrad)");
+  AOD_CHECK_ARG(R * S <= 16, "unpack_wgrad_slabs: at most 16 taps (larger filters take aod_unpack_wgrad)");
   AOD_CHECK_ARG(!wdot || w_oihw, "unpack_wgrad_slabs: wdot needs the weights");
   AOD_CHECK_ARG(!bn_s1 || (wdot && bn_mean && bn_invstd), "unpack_wgrad_slabs: BN mode needs wdot, mean and invstd");
   if (O == 0) return 0;
@@ -2335,7 +2340,7 @@ extern "C" int aod_unpack_wgrad_slabs_grouped(int n, const float* const* dw_slab
   int blk = 0;
   for (int i = 0; i < n; ++i) {
     AOD_CHECK_ARG(dw_slabs[i] && g[i] && nslabs[i] >= 1 && slab_stride[i] > 0 && O[i] >= 1, "unpack_wgrad_slabs_grouped: null / empty member");
-    AOD_CHECK_ARG(R[i] * S[i] <= 9, "unpack_wgrad_slabs_grouped: at most 9 taps");
+    AOD_CHECK_ARG(R[i] * S[i] <= 16, "unpack_wgrad_slabs_grouped: at most 16 taps");
     AOD_CHECK_ARG(!wdot[i] || w_oihw[i], "unpack_wgrad_slabs_grouped: wdot needs the weights");
     AOD_CHECK_ARG(!bn_s1[i] || (wdot[i] && bn_mean[i] && bn_invstd[i]), "unpack_wgrad_slabs_grouped: BN mode needs wdot, mean and invstd");
     UnpackArgs& a = gp.g[i];

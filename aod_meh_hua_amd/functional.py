@@ -311,8 +311,10 @@ def bwd_chain_for(blk, x):
     """a BwdChain for a block whose training forward qualifies for the fused kernels (same conditions; AOD_FUSE_BOTTLENECK_BWD=0 switches
     the fused backward off), else None"""
     on = _os.environ.get('AOD_FUSE_BOTTLENECK_BWD', '1') != '0' and not ho.DETERMINISTIC     # (the fused chain sums its columns with atomics of its own)
-    # (reference-precision mode: the forward is fused -- aod_bottleneck128x3_fwd --, the dgrads stay three launches)
-    return BwdChain() if on and _FUSE_ACT and not ho.X3 and bottleneck128_train_applies(blk, x) else None
+    # (reference-precision mode: aod_bottleneck128x3_bwd, the 128-plane stage only like the forward; AOD_FUSE_BOTTLENECK128_X3_BWD=0 switches it off)
+    if ho.X3 and _os.environ.get('AOD_FUSE_BOTTLENECK128_X3_BWD', '1') == '0':
+        return None
+    return BwdChain() if on and _FUSE_ACT and bottleneck128_train_applies(blk, x) else None
 
 
 def set_deterministic(on=True):

@@ -368,9 +368,10 @@ def conv2d_wgrad_rows(x_rows, x_segs, dz_rows, dz_segs, R, S, stride=1, pad=0, d
     Cin, Npad = x_rows.shape[1], dz_rows.shape[1]
     d = make_desc(Cin, Npad, R, S, stride, pad, dil, x_segs, dz_segs, False, False, False)
     nslabs = 0
-    if dw is None and R * S <= 9 and SLAB_WGRAD:
+    # (slab form: filters of at most 9 taps; in the reference-precision mode, which has no other form, up to 16 -- SSD512's 4 x 4 extra conv)
+    if dw is None and R * S <= (16 if X3 else 9) and SLAB_WGRAD:
         nslabs = int(lib.aod_conv2d_wgrad_splits(C.byref(d)))
-    assert not X3 or nslabs, 'x3 weight gradients exist in the slab form only (at most 9 taps)'
+    assert not X3 or nslabs, 'x3 weight gradients exist in the slab form only (at most 16 taps)'
     if dw is None and nslabs == 0:
         dw = _dw_scratch(Npad * R * S * Cin, x_rows.device).view(Npad, R, S, Cin)
     tab = _row_table(d, x_segs, dz_segs, Cin, Npad, R, S, stride, pad, dil, x_rows.device)
@@ -542,6 +543,17 @@ def bottleneck128_fwd(x_rows, B, H, W, w1, s1, b1, w2, s2, b2, w3, s3, b3, keep=
 def bottleneck_bwd(g_rows, B, H, W, wd3, wd2, wd1, act_t2, act_t1, act_x, frag=False):
     """aod_bottleneck_bwd: dgrad chain of an identity bottleneck (128 / 256 planes) in one launch -> (gx, gt2, gt1, colsum_x, colsum_t2, colsum_t1)"""
     M, Cin = g_rows.shape
+    if X3:          # X rows, 128 planes (csrc/bottleneck128_x3.hip, the BWD instance)
+        assert M == B * H * W and Cin == 1024 and act_x.shape == g_rows.shape and act_t2.shape == (M, 256) and act_t1.shape == (M, 256) and not frag
+        dev = g_rows.device
+        gx = torch.empty(M, 1024, dtype=torch.bfloat16, device=dev)
+        gt2 = torch.empty(M, 256, dtype=torch.bfloat16, device=dev)
+        gt1 = torch.empty(M, 256, dtype=torch.bfloat16, device=dev)
+        cx, c2, c1 = zeros_f32(512, dev), zeros_f32(128, dev), zeros_f32(128, dev)
+        prof_flops('dgrad', (M, 512, 2 * (512 + 9 * 128 + 128), 11, 1), 2.0 * M * (512 * 128 + 9 * 128 * 128 + 128 * 512),
+                   lambda: call('aod_bottleneck128x3_bwd', ptr(g_rows), B, H, W, ptr(wd3), ptr(wd2), ptr(wd1), ptr(act_t2), ptr(act_t1), ptr(act_x),
+                                ptr(gx), ptr(gt2), ptr(gt1), ptr(c2), ptr(c1), ptr(cx), stream()))
+        return gx, gt2, gt1, cx, c2, c1
     assert M == B * H * W and Cin in (512, 1024) and act_x.shape == g_rows.shape
     Pl = Cin // 4
     assert act_t2.shape == (M, Pl) and act_t1.shape == (M, Pl)

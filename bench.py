@@ -9,7 +9,7 @@ i.e. the metric "images/sec train + HUA-score".  value = SURVEY 8(d)'s AL-cycle 
 (images through BOTH phases per second); `phase_rates` holds the two phases separately (>= 50 iterations each).
 
 Arithmetic: --precision bf16x3 (default) is the REFERENCE-PRECISION mode -- the reference is fp32 end to end, so the headline is measured
-with fp32-grade products (bf16 head/tail pairs, three MFMAs per product, aod_meh_hua_amd/precision_x3.py); --precision bf16 is the fast
+with fp32-grade products (bf16 head/tail pairs, three MFMAs per product, aod_meh_hua_amd/functional.py set_precision, csrc/conv.hip "X3"); --precision bf16 is the fast
 mode with plain bf16 operands.  The line carries the other mode's figures under precision.other_mode (N = 1).
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
@@ -277,8 +277,12 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
     comm = dict(backend=None, ranks=1)
     if world > 1:
-        comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=dist.get_world_size())
-        assert comm['ranks'] == args.gpus
+        # the number of ranks a COLLECTIVE actually spanned (one all-reduce of ones over the freshly initialised group), not the launcher's claim
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=int(ones.item()))
+        assert comm['ranks'] == args.gpus == dist.get_world_size(), (comm, args.gpus, dist.get_world_size())
     from aod_meh_hua_amd import functional as AF
     from aod_meh_hua_amd import hipops as ho
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
@@ -646,6 +650,7 @@ def pool_mode(args, cd, pool_model, dev, rank, world, B, H, W, cal_k, cal_frac, 
                                          f'contiguous shard per rank, batches of {B}, one score all-gather',
                                 pool=args.pool, global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], parallelism=f'dp{world}',
                                 collective_ranks=comm['ranks'], collective_backend=comm['backend'],
+                                pool_partition=os.environ.get('AOD_POOL_SHARD', 'auto'), scores_sha16=__import__('hashlib').sha256(unc_h.numpy().tobytes()).hexdigest()[:16],
                                 launch='hip-graph replay inside apis/test.py single_gpu_uncertainty'),
                     pool=dict(nonzero_scores=int((unc_h > 0).sum()), mean_score=round(float(unc_h.mean()), 5), gpu_ms=round(e0.elapsed_time(e1), 2),
                               wall_ms=round(dt * 1e3, 2), host_gap_ms=round(dt * 1e3 - e0.elapsed_time(e1), 2), selection=sel,

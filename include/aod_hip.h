@@ -205,7 +205,7 @@ int aod_unpack_wgrad(float* dw_orsi, float* grad_oihw, int O, int I, int R, int 
                      const float* scale, const float* w_oihw, float* wdot, const float* bn_s1, const float* bn_mean,
                      const float* bn_invstd, aod_stream_t stream);
 
-/* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 9 taps.
+/* Slab form (aod_conv2d_wgrad_slabs): dw_slabs = [nslabs][Opad][R][S][Ipad] partial sums, added in slab order; at most 16 taps (the product uses it for 10 .. 16 taps in the reference-precision mode only).
  * The slabs of an x3 launch (aod_conv_desc_t.x3) are LOGICAL -- [N/2][R][S][C/2] for the physical widths N, C of the descriptor, slab_stride
  * >= N*R*S*C/4: the (head, head) + (head, tail) + (tail, head) bands of an entry are added in the wgrad epilogue -- and unpack like any
  * other: Opad = N/2, Ipad = C/2. */
@@ -459,6 +459,16 @@ int aod_bottleneck64x3_ds_fwd(const void* x, int B, int H, int W, const void* w1
 int aod_bottleneck128x3_fwd(const void* x, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                             const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, void* y, void* t1, void* t2,
                             aod_stream_t stream);
+
+/* aod_bottleneck_bwd (planes = 128) on X rows: the DGRAD chain of the same block in one launch -- the three x3 dgrad launches of conv3, conv2,
+ * conv1 with their fused epilogues (mask / res / colsum) back to back, the two intermediate gradients staying in LDS:
+ *   gt2 = [act_t2 > 0] * conv3_T(g)        gt1 = [act_t1 > 0] * conv2_T(gt2)        gx = [act_x > 0] * (conv1_T(gt1) + g)
+ * g / act_x / gx [B*H*W][1024], act_t2 / act_t1 / gt2 / gt1 [B*H*W][256] X rows; wd3 [128][1024], wd2 [128][3][3][256], wd1 [512][256]: the X dgrad
+ * images of aod_param_prep (BN scale folded in before the split); colsum_*: fp32 [128] [128] [512], += column sums of the three results (atomics:
+ * the launch stands aside in the deterministic mode).  Gradients equal those of the three launches bit for bit.  gx must not alias g. */
+int aod_bottleneck128x3_bwd(const void* g, int B, int H, int W, const void* wd3, const void* wd2, const void* wd1, const void* act_t2,
+                            const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
+                            float* colsum_x, aod_stream_t stream);
 
 /* The frozen stem of the reference-precision mode in one launch (csrc/stem_x3.hip; resnet.py:630-637): fp32 NCHW image [B][3][H][W] (even
  * H, W) -> y = max_pool_3x3_s2_p1(relu(bn1(conv1_7x7_s2(img)))) as X rows [B][H4][W4][128], H4 = (H/2 - 1) / 2 + 1.  w_x = the X filter

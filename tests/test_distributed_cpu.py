@@ -25,6 +25,11 @@ def _worker(rank, world, port, n_total, q):
     mine = [i for b in shard_batches(n_total, 3, interleaved=True) for i in b]
     full_i = gather_scores_indexed(torch.tensor([float(i * i % 17) + 0.25 for i in mine]), mine, n_total)
     assert torch.equal(full_i, full), (full_i, full)
+    # ... and with the slot count the caller knows without communication (apis/test.py: ceil(ceil(N / bs) / world) * bs): ONE all-gather, no
+    # all-reduce, no host read -- the form the pool loop uses
+    per = -(-(-(-n_total // 3)) // world) * 3
+    full_p = gather_scores_indexed(torch.tensor([float(i * i % 17) + 0.25 for i in mine]), mine, n_total, per=per)
+    assert torch.equal(full_p, full), (full_p, full)
     assert [i for b in shard_batches(n_total, 3) for i in b] == list(range(lo, hi))       # contiguous form = the shard_range block
     # gradient averaging: rank r holds grads r+1 on two tensors spanning two buckets
     p1, p2 = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))

@@ -79,13 +79,21 @@ def test_r101_80class_train_step_vs_oracle(built, B, H, W):
     lab = torch.cat([l.reshape(B, -1) for l in head_out[4]], 1).cpu()
     assert torch.equal(lab, torch.cat(o['targets']['labels'], 1))
     assert int(lab.max()) == NC and int(lab.min()) >= 0
+    from aod_meh_hua_amd import functional as AF
+    x3 = AF.get_precision() == 'bf16x3'          # the suite's default: the headline arithmetic, held to 1e-3 where the fast mode is held to 2e-2
+    tol = 1e-3 if x3 else 2e-2
     got = [float(out['log_vars'][k]) for k in ('loss_cls', 'loss_bbox', 'loss_noR')]
     exp = [float(sum(o['loss_cls'])), float(sum(o['loss_bbox'])), float(sum(x.mean() for x in o['loss_noR']))]
-    assert np.allclose(got, exp, rtol=2e-2), (got, exp)
-    assert np.allclose(float(out['loss']), float(o['loss']), rtol=2e-2)
+    print('R101 log_vars', got, exp, 'loss', float(out['loss']), float(o['loss']))
+    assert np.allclose(got, exp, rtol=tol), (got, exp)
+    assert np.allclose(float(out['loss']), float(o['loss']), rtol=tol)
     for l in range(5):                                                                        # per-anchor loss rows, every level
         a, b = prev[l].cpu().numpy(), o['loss_noR'][l].detach().numpy()
-        assert np.abs(a - b).max() <= 0.1 * np.abs(b).max() + 1e-6 and np.abs(a - b).mean() <= 4e-2 * np.abs(b).mean(), l    # bf16 operands, 100+ layers; focal rows amplify logit error ~3x
+        print('  level', l, 'loss rows: max err / max', np.abs(a - b).max() / np.abs(b).max(), 'mean err / mean', np.abs(a - b).mean() / np.abs(b).mean())
+        if x3:
+            assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() + 1e-6 and np.abs(a - b).mean() <= 1e-3 * np.abs(b).mean(), l
+        else:
+            assert np.abs(a - b).max() <= 0.1 * np.abs(b).max() + 1e-6 and np.abs(a - b).mean() <= 4e-2 * np.abs(b).mean(), l    # bf16 operands, 100+ layers; focal rows amplify logit error ~3x
     model.zero_grad()
     out['loss'].backward()
     pd = dict(model.named_parameters())
@@ -94,17 +102,21 @@ def test_r101_80class_train_step_vs_oracle(built, B, H, W):
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         # (the stride-2 conv that makes P7 sees 5 x 8 pixels per image at 608 x 1024: a few hundred bf16 products per weight, heavy cancellation)
         p7 = k == 'neck.fpn_convs.4.conv.weight'
-        assert cos > (0.93 if p7 else 0.99), (k, cos)
-        assert abs(float(a.norm() / b.norm()) - 1) < (0.1 if p7 else 6e-2), (k, float(a.norm()), float(b.norm()))
+        print(f'  {k:44s} 1-cos {1 - cos:.2e}  norm dev {abs(float(a.norm() / b.norm()) - 1):.2e}')
+        if x3:       # (what is left is ReLU sign flips: tests/test_gpu_precision_x3.py::test_bf16x3_gradient_residual_is_relu_sign_flips)
+            assert cos > 0.9995 and abs(float(a.norm() / b.norm()) - 1) < 1e-2, (k, cos, float(a.norm()), float(b.norm()))
+        else:
+            assert cos > (0.93 if p7 else 0.99), (k, cos)
+            assert abs(float(a.norm() / b.norm()) - 1) < (0.1 if p7 else 6e-2), (k, float(a.norm()), float(b.norm()))
     lossL = model.train_step_L(prev, head_out, feat_out)
     model.zero_grad()
     lossL['loss'].backward()
     torch.cuda.synchronize()
-    assert np.allclose(float(lossL['loss']), float(oL['loss']), rtol=3e-2), (float(lossL['loss']), float(oL['loss']))
+    assert np.allclose(float(lossL['loss']), float(oL['loss']), rtol=2e-3 if x3 else 3e-2), (float(lossL['loss']), float(oL['loss']))
     for k in NAMES_L:
         a, b = pd[k].grad.float().cpu().flatten(), gL[k].flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-        assert cos > 0.99, (k, cos)
+        assert cos > (0.9995 if x3 else 0.99), (k, cos)
 
 
 def test_80class_loss_kernels_vs_oracle():
@@ -281,7 +293,7 @@ def test_hua_sampler_81_columns_ragged_quarter_samples():
 
 def test_r101_p7_gradient_noise_is_operand_rounding(built):
     """The one outlier of the R101 comparison above -- the weight gradient of the stride-2 conv that makes P7 (cosine 0.96 in bf16 at
-    608 x 1024) -- in the bf16x3 debug precision of the same kernels (aod_meh_hua_amd/precision_x3.py): the deviation disappears, i.e. it
+    608 x 1024) -- in the bf16x3 debug precision of the same kernels (aod_meh_hua_amd/functional.py set_precision; csrc/conv.hip "X3"): the deviation disappears, i.e. it
     is bf16 rounding under heavy cancellation, not logic."""
     from aod_meh_hua_amd import functional as AF
     model, sd0 = built

@@ -197,3 +197,36 @@ def test_one_graph_serves_batches_that_differ_only_in_their_per_image_shapes(ari
         _, unc_g = gsc(d['img'], d['img_metas'], ids)
         assert torch.equal(torch.as_tensor(unc_e).float().cpu(), unc_g.float().cpu()), (base, unc_e, unc_g)
     assert len(gsc.cache) == 1 and float(unc_g.abs().sum()) > 0
+
+
+def test_multi_scale_shape_sequence_through_the_graph_cache(arithmetic):
+    """BASELINE configs[4] trains multi-scale (short side drawn per batch from {640 ... 800},
+    configs/retinanet/retinanet_r50_caffe_fpn_mstrain_1x_coco.py:15-19 of the reference): the padded batch shape changes from iteration to
+    iteration and comes back.  Scaled-down shapes of the same aspect ratios through GraphedTrainStep.maybe(): a shape is run eagerly when first
+    seen, captured when it repeats, replayed from the cache when it returns after other shapes -- and the sequence equals the all-eager run."""
+    from aod_meh_hua_amd.graphs import GraphedTrainStep
+    shapes = {'a': (160, 272), 'b': (176, 288), 'c': (200, 336)}
+    order = ['a', 'a', 'b', 'b', 'c', 'c', 'a', 'b', 'c']
+
+    def batch(seed, hw):
+        H, W = hw
+        gtb, gtl = synth.random_gts(2, H, W, seed=seed, gmin=1, gmax=3)
+        return dict(img=synth.images(2, H, W, seed=seed).cuda(), img_metas=synth.metas(2, H, W), gt_bboxes=gtb, gt_labels=gtl)
+    seq = [batch(80 + i, shapes[k]) for i, k in enumerate(order)]
+    model, opt, opt_L = _build()
+    ref = [_eager_iter(model, opt, opt_L, d) for d in seq]
+    model2, opt2, opt_L2 = _build()
+    gs = GraphedTrainStep(model2, opt2, opt_L2, warmup=1, Labeled=True, Pseudo=False)
+    got, how = [], []
+    for d in seq:
+        o = gs.maybe(d)
+        if o is None:
+            how.append('eager')
+            got.append(_eager_iter(model2, opt2, opt_L2, d))
+        else:
+            how.append('graph')
+            got.append((float(o['loss']), float(o['log_vars']['loss_L'])))
+    torch.cuda.synchronize()
+    assert how == ['eager', 'graph', 'eager', 'graph', 'eager', 'graph', 'graph', 'graph', 'graph'], how
+    assert len(gs.cache) == 3
+    assert np.allclose(np.array(got), np.array(ref), rtol=3e-3), (got, ref)

@@ -23,6 +23,29 @@ def test_two_rank_bench_on_one_gpu():
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert out['config']['launch'] == 'hip-graph replay' and out['roofline'] is not None
+    assert out['config']['collective_ranks'] == 2            # counted by an all-reduce over the group, not taken from the launcher
+    assert out['config']['scores_read'].startswith('after the loop')
+
+
+def test_two_rank_pool_mode_on_one_gpu_equals_one_rank_in_both_partitions():
+    """`bench.py --mode pool` (BASELINE configs[3]: the product's pool loop, sharded, scores all-gathered) end to end at
+    world size 2 through the code path the RCCL run takes (only the backend string differs), with the contiguous AND the interleaved
+    partition (the indexed all-gather): the gathered score vector must be the one a single rank computes, bit for bit."""
+    sha = {}
+    for tag, world, shard, port in (('one', 1, 'contiguous', '29561'), ('contig', 2, 'contiguous', '29563'), ('inter', 2, 'interleaved', '29565')):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', AOD_POOL_SHARD=shard)
+        if world > 1:
+            env['AOD_BENCH_ONE_GPU'] = '1'
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', port, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--mode', 'pool', '--pool', '44', '--batch', '4',
+               '--size', '128', '--warmup', '1', '--no-cpu-baseline']
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        assert out['n_gpus'] == world and out['config']['collective_ranks'] == world and out['value'] > 0
+        assert out['config']['pool_partition'] == shard and out['pool']['nonzero_scores'] > 0, out
+        sha[tag] = out['config']['scores_sha16']
+    assert sha['one'] == sha['contig'] == sha['inter'], sha
 
 
 def test_two_rank_replicas_stay_equal_and_match_a_mean_gradient_run():

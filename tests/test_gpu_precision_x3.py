@@ -1,4 +1,4 @@
-"""GPU: the reference-precision mode `bf16x3` (aod_meh_hua_amd/precision_x3.py: head/tail-split activations, gradients and filters in the
+"""GPU: the reference-precision mode `bf16x3` (aod_meh_hua_amd/functional.py set_precision, csrc/conv.hip "X3": head/tail-split activations, gradients and filters in the
 X-layout, three MFMAs per product inside the SAME implicit-GEMM / dgrad / wgrad kernels with their fused epilogues) against the golden values
 the REFERENCE produced (tests/golden/train_step.npz) and the fp32 oracle's gradients: fp32-level agreement, where the bf16 mode's residuals
 (operand rounding, not logic) are two to three orders of magnitude larger."""
