@@ -19,6 +19,7 @@ from oracle import model as omodel      # noqa: E402  (seeded weights only)
 from tests import synth                 # noqa: E402
 
 STEPS = int(os.environ.get('MULTIRANK_STEPS', '3'))       # iterations of the graph / eager / emulation runs that are compared
+LR = float(os.environ.get('MULTIRANK_LR', '2e-4'))
 
 
 def build():
@@ -33,8 +34,8 @@ def build():
     head = model.bbox_head
     meh = set(id(p) for n in ('retina_L', 'L_convs') for p in getattr(head, n).parameters())
     main = [p for p in model.parameters() if p.requires_grad and id(p) not in meh]
-    opt = FusedSGD(main, lr=2e-4, momentum=0.9, weight_decay=1e-4)
-    opt_L = FusedSGD([p for p in model.parameters() if id(p) in meh], lr=2e-4, momentum=0.9, weight_decay=1e-4)
+    opt = FusedSGD(main, lr=LR, momentum=0.9, weight_decay=1e-4)
+    opt_L = FusedSGD([p for p in model.parameters() if id(p) in meh], lr=LR, momentum=0.9, weight_decay=1e-4)
     return model, opt, opt_L
 
 
