@@ -231,8 +231,29 @@ def measured_peaks(dev):
         torch.cuda.synchronize()
         copy = 2.0 * src.numel() * 4 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
+        # the shader clock the chip holds under matrix load (csrc/probe.hip): ~0.4 s of back-to-back MFMA launches, median over workgroups
+        clock = mfma_tf = None
+        try:
+            from aod_meh_hua_amd import hipops as ho_
+            nwg, iters = 512, 20000
+            outp = torch.zeros(2 * nwg, dtype=torch.int64, device=dev)
+            sink = torch.zeros(1, device=dev)
+            for _ in range(6):
+                ho_.call('aod_mfma_clock_probe', iters, nwg, ho_.ptr(outp), ho_.ptr(sink), ho_.stream())
+            e0.record()
+            ho_.call('aod_mfma_clock_probe', iters, nwg, ho_.ptr(outp), ho_.ptr(sink), ho_.stream())
+            e1.record()
+            torch.cuda.synchronize()
+            o = outp.cpu().numpy().reshape(nwg, 2).astype(np.float64)
+            clock = float(np.median(o[:, 0] / np.maximum(o[:, 1], 1) * 0.1))          # cycles per 10-ns tick -> GHz
+            mfma_tf = 2.0 * 16 * 16 * 32 * 16 * iters * nwg * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        except Exception:      # noqa: BLE001
+            pass
         return dict(gemm_bf16_tflops=round(gemm, 1), gemm='torch.matmul (hipBLASLt) 8192^3 bf16, random operands', stream_copy_GBs=round(copy, 1),
-                    stream_copy='1 GiB fp32 device-to-device copy, read + write bytes')
+                    stream_copy='1 GiB fp32 device-to-device copy, read + write bytes',
+                    mfma_loop_clock_ghz=None if clock is None else round(clock, 3), mfma_loop_tflops=None if mfma_tf is None else round(mfma_tf, 1),
+                    mfma_loop='register-resident v_mfma_f32_16x16x32_bf16 loop on random operands, every SIMD busy (csrc/probe.hip): the clock the chip '
+                              'holds under matrix load and the rate the pipe delivers at it (the 2.5 PFLOP/s peak is quoted at 2.4 GHz)')
     except Exception as e:      # noqa: BLE001
         return dict(error=f'{type(e).__name__}: {e}'[:200])
 
@@ -561,6 +582,14 @@ def main():
         roof['measured_peaks'] = peaks
         if peaks and peaks.get('gemm_bf16_tflops'):
             roof['frac_of_measured_gemm'] = round(roof['achieved'] * PRECISIONS[args.precision][1] / peaks['gemm_bf16_tflops'], 4)
+        if peaks and peaks.get('mfma_loop_tflops'):
+            # issued MFMA rate of the dominant kernel class against what a register-resident MFMA loop delivers on THIS box at the clock the chip
+            # holds under matrix load (the ceiling any kernel that also has to move operands stays under)
+            roof['frac_of_measured_mfma_loop'] = round(roof['achieved'] * PRECISIONS[args.precision][1] / peaks['mfma_loop_tflops'], 4)
+            for part in ('backbone_fpn', 'heads'):
+                tot_ = (roof.get(part) or {}).get('total')
+                if tot_:
+                    tot_['frac_of_measured_mfma_loop'] = round(tot_['tflops'] * PRECISIONS[args.precision][1] / peaks['mfma_loop_tflops'], 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

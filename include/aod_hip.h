@@ -470,6 +470,11 @@ int aod_bottleneck128x3_bwd(const void* g, int B, int H, int W, const void* wd3,
                             const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
                             float* colsum_x, aod_stream_t stream);
 
+/* Calibration only (bench.py `roofline.measured_peaks`; no reference call site): `workgroups` x 4 waves issue `iters` x 16 independent bf16
+ * MFMAs each and write {shader cycles, 100-MHz ticks} per workgroup to out_u64_pairs -- the clock the chip holds under matrix load
+ * (csrc/probe.hip).  sink: one float the kernel may write (keeps the work alive). */
+int aod_mfma_clock_probe(int iters, int workgroups, void* out_u64_pairs, float* sink, aod_stream_t stream);
+
 /* The frozen stem of the reference-precision mode in one launch (csrc/stem_x3.hip; resnet.py:630-637): fp32 NCHW image [B][3][H][W] (even
  * H, W) -> y = max_pool_3x3_s2_p1(relu(bn1(conv1_7x7_s2(img)))) as X rows [B][H4][W4][128], H4 = (H/2 - 1) / 2 + 1.  w_x = the X filter
  * image [64][4][4][64] of the space-to-depth form of conv1 (aod_param_prep, flags bit 0, of the [64][12][4][4] filter); replaces

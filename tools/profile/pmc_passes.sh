@@ -68,3 +68,35 @@ if s and s.get('SQ_BUSY_CYCLES'):
 json.dump(res, open('$R/gpurun_out/profiles/pmc_hua.json', 'w'), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != 'kernels'}))
 PY
+# ---- effective clock and matrix-pipe occupancy of the conv kernels (round 5: the reference-precision step is bound by what the chip delivers
+# at the clock it holds under matrix load, not by HBM -- DESIGN 10).  One more pass, counters only.
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $D/clock -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph --phase-iters 2 > $D/bench_clock.json 2>$D/err_clock.txt
+python3 - <<PY
+import csv, glob, collections, json
+sha = '$SHA'
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); dur = collections.defaultdict(list)
+name = lambda r: r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:72]
+for f in glob.glob('$D/clock/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = name(r); agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
+for f in glob.glob('$D/clock/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[name(r)].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+out = {}
+for k, d in agg.items():
+    n = cnt[(k, 'GRBM_GUI_ACTIVE')]
+    if not n or not dur[k]: continue
+    us = sum(dur[k]) / len(dur[k]) / 1e3
+    gui = d['GRBM_GUI_ACTIVE'] / n                      # summed over the 8 XCDs (MI355X_MICROARCH.md, 'DVFS give-back')
+    cyc = gui / 8.0
+    e = dict(launches=n, avg_us=round(us, 2), effective_clock_ghz=round(cyc / (us * 1e3), 3) if us >= 100 else None,
+             mfma_busy_frac=round(d['SQ_VALU_MFMA_BUSY_CYCLES'] / n / max(cyc * 1024.0, 1.0), 4),
+             wave_cycles_waiting=round(d['SQ_WAIT_ANY'] / max(d['SQ_WAVE_CYCLES'], 1.0), 4),
+             wave_cycles_issue_stalled=round(d['SQ_WAIT_INST_ANY'] / max(d['SQ_WAVE_CYCLES'], 1.0), 4),
+             wave_cycles_issuing=round(d['SQ_ACTIVE_INST_ANY'] / max(d['SQ_WAVE_CYCLES'], 1.0), 4))
+    out[k] = e
+json.dump(dict(kernels_sha16=sha, note='effective clock = GRBM_GUI_ACTIVE / 8 / duration (reads high below ~0.1 ms: omitted there); mfma_busy_frac = '
+               'SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)', kernels=out), open('$R/gpurun_out/profiles/pmc_clock.json', 'w'), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['launches'])[:14]:
+    print('%-72s n=%4d %8.1f us  clock %s GHz  mfma busy %.3f  waiting %.2f' % (k, v['launches'], v['avg_us'], v['effective_clock_ghz'], v['mfma_busy_frac'], v['wave_cycles_waiting']))
+PY
