@@ -86,7 +86,7 @@ template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST, bool X3>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(ST == 2 || (ST == 3 && NT == 256), "LDS stages: 2, or 3 for the 4-wave forms");
-  static_assert(!X3 || NT == 256 || (NT == 512 && BM == 256), "X3: the 4-wave forms and the 8-wave 256 x 256 tile");
+  static_assert(!X3 || NT == 256 || (NT == 512 && (BM == 256 || BM == 128)), "X3: the 4-wave forms, the 8-wave 256 x 256 tile and (A/B) the 8-wave 128 x 128 tile");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
   constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
@@ -1138,7 +1138,22 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
         return 0;
       }
     }
+    // Layers whose 128 x 128 tiles fill ONE round of the CUs but not two (the 16 384-row layers of stage 3 and of the neck: 256 - 511 tiles) ran on
+    // the 64 x 128 three-stage tile; the 128 x 128 tile on EIGHT waves -- 16 waves per CU instead of 8 to sit out the operand latency, the bytes
+    // per MFMA of the bigger tile -- takes 7 - 9 % less time on them (tools/dbg/x3_w8_ab.sh: 80.0 -> 73.2 us for the 3 x 3, 38.0 -> 35.4 us for
+    // the 1 x 1; same K order per accumulator: same bits).  Not with a residual operand (its registers), not for >= 512 tiles (+3 %).
+    // AOD_X3_128_W8=0 switches it off, =1 takes it for every tile count >= 256.
+    static const char* dbg_w8x = getenv("AOD_X3_128_W8");
+    const long long t128 = ntiles(128, 128);
+    const bool w8 = !(dbg_w8x && dbg_w8x[0] == '0') && !p.res && !p.out_f32 && p.N % 128 == 0 && t128 >= 256 && (t128 < want || (dbg_w8x && dbg_w8x[0] == '1'));
+    if (w8) {
+      if (!p.mask) launch_conv<128, 128, 512, 0, false, 2, true>(p, st); else launch_conv<128, 128, 512, 1, false, 2, true>(p, st);
+      AOD_LAUNCH_CHECK();
+      return 0;
+    }
+    static const char* dbg_st3 = getenv("AOD_X3_128_ST3");        // (debug / A-B: the 128 x 128 x3 tile on a three-stage ring, one workgroup per CU)
     if (ragged && ntiles(128, 64) >= want) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
+    else if (p.N > 64 && dbg_st3 && dbg_st3[0] == '1' && ntiles(128, 128) >= 256) launch_conv<128, 128, 256, 2, false, 3, true>(p, st);
     else if (p.N > 64 && ntiles(128, 128) >= want) launch_conv<128, 128, 256, 2, false, 2, true>(p, st);
     else if (p.N > 64 && ntiles(64, 128) >= want) launch_conv<64, 128, 256, 2, false, 3, true>(p, st);
     else if (p.N <= 64 && ntiles(128, 64) >= want) launch_conv<128, 64, 256, 2, false, 2, true>(p, st);
