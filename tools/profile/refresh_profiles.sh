@@ -1,8 +1,8 @@
 #!/bin/bash
 # Every measured artefact the docs / the bench line cite, from ONE build on ONE GPU box:
-#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r04'
+#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r05'
 # then copy gpurun_out/profiles/* into profiles/ and commit.  (rocprofv3: kernel trace + stats in one pass; --pmc passes separately.)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -10,7 +10,7 @@ mkdir -p $O
 SHA=$(cd $R && python3 -c "from aod_meh_hua_amd.build import source_digest; print(source_digest())")
 echo "kernels_sha16 $SHA" > $O/${TAG}_build.txt
 # 1. the default bench line (what the driver runs) + per-shape conv listing of its instrumented step
-python3 $R/bench.py --steps 20 --warmup 5 --shapes $O/${TAG}_conv_shapes_one_step.txt > $O/${TAG}_bench_default.json 2>/dev/null
+python3 $R/bench.py --shapes $O/${TAG}_conv_shapes_one_step.txt > $O/${TAG}_bench_default.json 2>/dev/null
 # 2. rocprofv3 kernel trace + stats of the same command, normalised per step
 D=$R/gpurun_out/prof_$TAG
 mkdir -p $D
