@@ -1138,14 +1138,13 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
         return 0;
       }
     }
-    // Layers whose 128 x 128 tiles fill ONE round of the CUs but not two (the 16 384-row layers of stage 3 and of the neck: 256 - 511 tiles) ran on
-    // the 64 x 128 three-stage tile; the 128 x 128 tile on EIGHT waves -- 16 waves per CU instead of 8 to sit out the operand latency, the bytes
-    // per MFMA of the bigger tile -- takes 7 - 9 % less time on them (tools/dbg/x3_w8_ab.sh: 80.0 -> 73.2 us for the 3 x 3, 38.0 -> 35.4 us for
-    // the 1 x 1; same K order per accumulator: same bits).  Not with a residual operand (its registers), not for >= 512 tiles (+3 %).
-    // AOD_X3_128_W8=0 switches it off, =1 takes it for every tile count >= 256.
+    // A/B knob (AOD_X3_128_W8=1): the 128 x 128 x3 tile on EIGHT waves for launches without a residual operand.  Back to back on warm operands
+    // it beats the 64 x 128 three-stage tile on the 16 384-row layers (80.0 -> 73.2 us for the stage-3 3 x 3, tools/dbg/x3_w8_ab.sh); INSIDE the
+    // step, on operands that come from HBM / the Infinity Cache, it loses 8 % (80.2 -> 86.3 us forward, 77.9 -> 89.3 us dgrad in the instrumented
+    // step, profiles/r05_conv_shapes_one_step.txt against the run before it): not taken.
     static const char* dbg_w8x = getenv("AOD_X3_128_W8");
     const long long t128 = ntiles(128, 128);
-    const bool w8 = !(dbg_w8x && dbg_w8x[0] == '0') && !p.res && !p.out_f32 && p.N % 128 == 0 && t128 >= 256 && (t128 < want || (dbg_w8x && dbg_w8x[0] == '1'));
+    const bool w8 = dbg_w8x && dbg_w8x[0] == '1' && !p.res && !p.out_f32 && p.N % 128 == 0 && t128 >= 256;
     if (w8) {
       if (!p.mask) launch_conv<128, 128, 512, 0, false, 2, true>(p, st); else launch_conv<128, 128, 512, 1, false, 2, true>(p, st);
       AOD_LAUNCH_CHECK();

@@ -3,7 +3,7 @@ scoring passes).  The bench's own calibration launches (torch's spin kernel behi
 roofline.measured_peaks) are listed apart and not counted."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-calib = lambda n: n.startswith('at::cuda::(anonymous namespace)::spin_kernel') or n.startswith('Cijk_')
+calib = lambda n: n.startswith('at::cuda::(anonymous namespace)::spin_kernel') or n.startswith('Cijk_') or 'mfma_clock_probe_kernel' in n
 work = [r for r in rows if not calib(r["Name"])]
 tot = sum(float(r["TotalDurationNs"]) for r in work)
 nms = [int(r["Calls"]) for r in rows if r["Name"].startswith("nms_kernel")][0]
