@@ -41,6 +41,8 @@ _SIGS = {
     'aod_bottleneck64x3_fwd': (C.c_int, [P, I32, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck64x3_ds_fwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck64_ds_fwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'aod_halo_conv3x3_x3_applies': (C.c_int, [P]),
+    'aod_halo_conv3x3_x3': (C.c_int, [P, P, P, P, P, P]),
     'aod_mfma_clock_probe': (C.c_int, [I32, I32, P, P, P]),
     'aod_bottleneck128x3_bwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck128x3_fwd': (C.c_int, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P]),

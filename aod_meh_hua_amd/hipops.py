@@ -209,6 +209,12 @@ def conv2d_rows(x_rows, src_segs, w_packed, N, R, S, stride=1, pad=0, dil=1, *, 
     if R == 3 and not save_z and _halo_applies(d, N, pre_scale, res, mask, post_scale):
         _prof('fwd', d, lambda: call('aod_halo_conv3x3', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_shift), None, None, stream()), alg)
         return out, dst_segs
+    # reference-precision mode: the narrow prediction convs (retina_reg 36, retina_L 9 fp32 output channels) on the chunk-resident halo kernel
+    # (csrc/halo_x3.hip; AOD_HALO_X3=0: the general kernel, which computes 64 columns for them) -- identical bits
+    if (X3 and R == 3 and out_f32 and N <= 48 and not save_z and pre_scale is None and res is None and mask is None and post_scale is None
+            and os.environ.get('AOD_HALO_X3', '1') != '0' and lib.aod_halo_conv3x3_x3_applies(C.byref(d))):
+        _prof('fwd', d, lambda: call('aod_halo_conv3x3_x3', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_shift), stream()), alg)
+        return out, dst_segs
     ws, wsb = _splitk_ws(d, x_rows.device)
     _prof('fwd', d, lambda: call('aod_conv2d_ws', C.byref(d), ptr(x_rows), ptr(w_packed), ptr(out), ptr(pre_scale), ptr(pre_shift),
                                  ptr(res), ptr(mask), ptr(post_scale), ptr(z), None, ptr(ws), wsb, stream()), alg)

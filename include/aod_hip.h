@@ -470,6 +470,14 @@ int aod_bottleneck128x3_bwd(const void* g, int B, int H, int W, const void* wd3,
                             const void* act_t1, const void* act_x, void* gx, void* gt2, void* gt1, float* colsum_t2, float* colsum_t1,
                             float* colsum_x, aod_stream_t stream);
 
+/* The narrow prediction convs in the reference-precision mode (Lambda_L2.py:52-54,100-103: retina_reg 256 -> 36, retina_L 256 -> 9 over the five
+ * pyramid levels; csrc/halo_x3.hip): x3 forward 3x3 / stride 1 / pad 1, fp32 destination of at most 48 channels, X-layout source rows and X
+ * filter image [N][3][3][C].  A K-step is a whole 32-channel chunk (halo + the nine taps' filter slices resident in LDS together).  Same bits as
+ * aod_conv2d with the same descriptor.  aod_halo_conv3x3_x3_applies() tells whether a descriptor qualifies. */
+int aod_halo_conv3x3_x3_applies(const aod_conv_desc_t* desc);
+int aod_halo_conv3x3_x3(const aod_conv_desc_t* desc, const void* src, const void* w_packed, void* dst, const float* pre_shift,
+                        aod_stream_t stream);
+
 /* Calibration only (bench.py `roofline.measured_peaks`; no reference call site): `workgroups` x 4 waves issue `iters` x 16 independent bf16
  * MFMAs each and write {shader cycles, 100-MHz ticks} per workgroup to out_u64_pairs -- the clock the chip holds under matrix load
  * (csrc/probe.hip).  sink: one float the kernel may write (keeps the work alive). */

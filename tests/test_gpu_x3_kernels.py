@@ -465,3 +465,40 @@ def test_x3_fused_bottleneck128_backward_equals_the_three_dgrad_launches(shape, 
             scale = float(a.abs().max()) + 1e-12
             assert float((a - b_).abs().max()) <= 1e-5 * scale + 1e-7, (n_, float((a - b_).abs().max()), scale)
     assert float(res['1'][0].float().abs().mean()) > 0
+
+
+@pytest.mark.parametrize('N,relu', [(36, False), (9, True), (48, False), (20, True)])
+def test_x3_narrow_prediction_convs_on_the_halo_kernel_equal_the_general_kernel(N, relu, monkeypatch):
+    """aod_halo_conv3x3_x3 (csrc/halo_x3.hip: retina_reg / retina_L of Lambda_L2.py:52-54,100-103 in the reference-precision mode -- a 32-channel
+    chunk of the 10 x 18 halo and of all nine taps' filter slices resident in LDS per K-step) against the general implicit-GEMM kernel, which walks
+    these layers in the same (chunk, tap) order: identical bits over a five-level pyramid with whole, ragged and single-pixel levels; and against
+    fp32."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    g = torch.Generator(device='cuda').manual_seed(31 + N)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    conv = Conv2d(256, N, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(rnd(N, 256, 3, 3) / 48.0); conv.bias.copy_(rnd(N) * 0.1)
+    for B, sizes in ((2, ((16, 16), (8, 8), (4, 4), (2, 2), (1, 1))), (3, ((21, 37), (11, 19), (6, 10), (3, 5), (2, 3))), (16, ((64, 64),))):
+        xs = [rnd(B, 256, h, w) for h, w in sizes]
+        feats = [AF.as_nchw(_x(x), B, x.shape[2], x.shape[3]) for x in xs]
+        calls = []
+        orig = ho.call
+        monkeypatch.setattr(ho, 'call', lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        outs = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('AOD_HALO_X3', mode)
+            monkeypatch.setattr(ho, 'SPLITK', False)        # (small pyramids: the general kernel would slice K, a different summation order)
+            calls.clear()
+            with torch.no_grad():
+                outs[mode] = [o.clone() for o in conv(list(feats), out_f32=True, relu=relu)]
+            assert ('aod_halo_conv3x3_x3' in calls) == (mode == '1'), calls
+        monkeypatch.undo()
+        torch.cuda.synchronize()
+        for x, a, b_ in zip(xs, outs['1'], outs['0']):
+            ref = F.conv2d(x, conv.weight, conv.bias, 1, 1)
+            ref = torch.relu(ref) if relu else ref
+            assert a.shape == ref.shape and _err(a, ref) < 1e-4, _err(a, ref)
+            assert torch.equal(a, b_), float((a - b_).abs().max())
