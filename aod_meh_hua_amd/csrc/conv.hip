@@ -83,10 +83,10 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // sums) and writes head and tail of each value, 64 B apart.  p.N stays the LOGICAL output channel count (vector operands, fp32
 // destinations); p.C / p.K are the physical (X-layout) widths of the source and of the packed filter rows.
 template <int BM, int BN, int NT, int OPS, bool GROUPED, int ST, bool X3>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 2 : (NT == 512 ? 4 : 1), BM >= 256 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 192 ? 2 : (NT == 512 ? 4 : 1), BM >= 192 ? 2 : (NT == 512 ? 4 : 8)))) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
   static_assert(ST == 2 || (ST == 3 && NT == 256), "LDS stages: 2, or 3 for the 4-wave forms");
-  static_assert(!X3 || NT == 256 || (NT == 512 && (BM == 256 || BM == 128)), "X3: the 4-wave forms, the 8-wave 256 x 256 tile and (A/B) the 8-wave 128 x 128 tile");
+  static_assert(!X3 || NT == 256 || (NT == 512 && (BM == 256 || BM == 192 || BM == 128)), "X3: the 4-wave forms, the 8-wave 256 x 256 / 192 x 192 tiles and (A/B) the 8-wave 128 x 128 tile");
   constexpr int BK = 64;
   constexpr int CPR = BK / 8;        // 16-B chunks per tile row
   constexpr int RPP = NT / CPR;      // tile rows covered per pass of the NT threads
@@ -385,8 +385,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // together with the first operand tile and consumed after the main loop -- a load-use chain per store iteration would expose one
   // memory latency per 16 B and cap memory-bound layers at a third of the bandwidth
   constexpr int NCH = BN / 8;              // 8-column chunks per tile row
-  constexpr int E_IT = EBM * NCH / NT;     // row segments per thread and epilogue pass
-  const int ec = t % NCH, er = t / NCH;
+  // (thread -> chunk mapping over a power-of-two chunk count: the 192-column tile leaves a quarter of its epilogue lanes idle)
+  constexpr int NCHT = (NCH & (NCH - 1)) == 0 ? NCH : (NCH <= 32 ? 32 : 64);
+  static_assert((EBM * NCHT) % NT == 0 && NT % NCHT == 0, "epilogue mapping");
+  constexpr int E_IT = EBM * NCHT / NT;    // row segments per thread and epilogue pass
+  const int ec = t % NCHT, er = t / NCHT;
+  const bool ecok = NCHT == NCH || ec < NCH;
   float cs1[8], cb1[8], cs2[8];
   bf16x8 pres[PREFETCH ? E_IT : 1], pmask[PREFETCH ? E_IT : 1];
   // LATE (the 4-wave X3 forms, which cannot spare the registers during the K loop): the same operands are fetched once the accumulators
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   auto xcol = [&](int n) { return xout ? ((n >> 5) << 6) + (n & 31) : n; };
   const long long drow_lin = linear ? p.seg_dst0[sg_first] - (long long)gu.mstart : 0;
   const long long lin_off = (drow_lin + m0 + er) * NP + xcol(n0 + ec * 8);     // element offset of this thread's first row segment
-  const long long lin_step = (long long)(NT / NCH) * NP;                // ... and the distance to its next one
+  const long long lin_step = (long long)(NT / NCHT) * NP;                // ... and the distance to its next one
   auto prefetch_epilogue = [&](bool from_table) {
     const int n = n0 + ec * 8;
     if (fast) {
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     if (PREFETCH && OPS > 0 && (p.res || g_mask)) {
 #pragma unroll
       for (int it = 0; it < E_IT; ++it) {
-        const int row = er + it * (NT / NCH);
+        const int row = er + it * (NT / NCHT);
         const bool ok = (m0 + row < p.M) && (n + 8 <= p.N);
         const long long drow = from_table ? s_drow[row] : drow_lin + m0 + row;
         const long long off = ok ? drow * NP + xcol(n) : 0;
@@ -651,10 +655,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         for (int r = 0; r < 4; ++r)
           sc[(wm * WM - r0e + i * 16 + lq * 4 + r) * CP + wn * WN + j * 16 + lr] = acc[i][j][r];
   }
-  if (LATE && fast && OPS > 0) {
+  if (LATE && fast && OPS > 0 && ecok) {
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
-      const long long eoff = linear ? lin_off + (long long)r0e * NP + it * lin_step : s_drow[r0e + er + it * (NT / NCH)] * NP + xcol(n0 + ec * 8);
+      const long long eoff = linear ? lin_off + (long long)r0e * NP + it * lin_step : s_drow[r0e + er + it * (NT / NCHT)] * NP + xcol(n0 + ec * 8);
       if (OPS > 1 && p.res) {
         lres[it] = *reinterpret_cast<const bf16x8*>(p.res + eoff);
         if constexpr (X3) lrl[it] = *reinterpret_cast<const bf16x8*>(p.res + eoff + 32);
@@ -668,11 +672,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
   // fast tiles: no per-thread predicates at all, only workgroup-uniform branches -- the general loop below costs ~500 instructions
   // per 16-B store, this one under 100
   if (fast) {
+    if (ecok) {
     bf16_t* const yb = reinterpret_cast<bf16_t*>(g_y) + xcol(n0 + ec * 8);
     bf16_t* const yl = reinterpret_cast<bf16_t*>(g_y) + lin_off + (long long)r0e * NP;
 #pragma unroll
     for (int it = 0; it < E_IT; ++it) {
-      const int row = er + it * (NT / NCH);
+      const int row = er + it * (NT / NCHT);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
       float v[8];
@@ -717,13 +722,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
         *reinterpret_cast<bf16x8*>(yo + 32) = ol;
       }
     }
+    }
   } else
 #pragma unroll
   for (int it = 0; it < E_IT; ++it) {
-    const int row = er + it * (NT / NCH);
+    const int row = er + it * (NT / NCHT);
     const int m = m0 + r0e + row;
     const int n = n0 + ec * 8;
-    if (m >= p.M || n >= p.N) continue;
+    if (m >= p.M || n >= p.N || !ecok) continue;
     const long long drow = s_drow[r0e + row];
     float v[8], raw[8];
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
@@ -820,15 +826,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 256 ? 
     g_tile_stamps[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 #endif
   if (g_colsum) {
-    // column sums of this tile: per-thread partials -> LDS [NT / NCH][BN] -> one fp32 atomic per column
+    // column sums of this tile: per-thread partials -> LDS [NT / NCHT][BN] -> one fp32 atomic per column
     __syncthreads();
     float* sr = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sr[er * BN + ec * 8 + j] = csum[j];
+    for (int j = 0; j < 8; ++j) if (ecok) sr[er * BN + ec * 8 + j] = csum[j];
     __syncthreads();
     if (t < BN && n0 + t < p.N) {
       float s = 0.f;
-      for (int r = 0; r < NT / NCH; ++r) s += sr[r * BN + t];
+      for (int r = 0; r < NT / NCHT; ++r) s += sr[r * BN + t];
       if (p.cs_ws) p.cs_ws[((long long)gi * p.tiles_m + tile_m) * p.N + n0 + t] = s;
       else atomicAdd(g_colsum + n0 + t, s);
     }
@@ -1134,6 +1140,18 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
       const bool fits = t256 >= 240 && t256 * 100 >= ((t256 + 255) / 256) * 256 * 92;
       if (!(dbg_t256x && dbg_t256x[0] == '0') && !p.res && !p.out_f32 && p.N % 256 == 0 && p.K >= 2048 && fits) {
         if (!p.mask) launch_conv<256, 256, 512, 0, false, 2, true>(p, st); else launch_conv<256, 256, 512, 1, false, 2, true>(p, st);
+        AOD_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    // 129 .. 192 output columns without epilogue operands (retina_cls, 180 columns, fp32 destination): a 192 x 192 tile on eight waves, one
+    // workgroup per CU like the 256 x 256 tile (96 FLOP per staged byte; 64-wide tiles: 43, and the L2 -> LDS path bounds the 4-wave x3
+    // forms), same K order -> same bits.  AOD_X3_TILE_192=0: the 128 x 64 tile.
+    {
+      const char* dbg_t192 = getenv("AOD_X3_TILE_192");      // (read per call: tests switch it in-process)
+      const long long t192 = ntiles(192, 192);
+      if (!(dbg_t192 && dbg_t192[0] == '0') && p.N > 128 && p.N <= 192 && !p.res && !p.mask && !p.zraw && p.K >= 2048 && t192 >= 240) {
+        launch_conv<192, 192, 512, 0, false, 2, true>(p, st);
         AOD_LAUNCH_CHECK();
         return 0;
       }

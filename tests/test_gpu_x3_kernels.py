@@ -502,3 +502,29 @@ def test_x3_narrow_prediction_convs_on_the_halo_kernel_equal_the_general_kernel(
             ref = torch.relu(ref) if relu else ref
             assert a.shape == ref.shape and _err(a, ref) < 1e-4, _err(a, ref)
             assert torch.equal(a, b_), float((a - b_).abs().max())
+
+
+def test_x3_retina_cls_on_the_192_tile_equals_the_64_wide_tiles(monkeypatch):
+    """retina_cls (Lambda_L2.py:52, 9 anchors x 20 classes = 180 fp32 columns) at configs[1]'s pyramid (16 x 512^2: 87 296 rows) takes the
+    192 x 192 eight-wave tile (conv.hip, AOD_X3_TILE_192); same K order and products as the 128 x 64 tile it replaces -> identical bits; a
+    sample of rows against fp32."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    g = torch.Generator(device='cuda').manual_seed(77)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    conv = Conv2d(256, 180, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(rnd(180, 256, 3, 3) / 48.0); conv.bias.copy_(rnd(180) * 0.1)
+    B = 16
+    xs = [rnd(B, 256, s, s) for s in (64, 32, 16, 8, 4)]
+    feats = [AF.as_nchw(_x(x), B, x.shape[2], x.shape[3]) for x in xs]
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('AOD_X3_TILE_192', mode)
+        with torch.no_grad():
+            outs[mode] = [o.clone() for o in conv(list(feats), out_f32=True)]
+    torch.cuda.synchronize()
+    for x, a, b_ in zip(xs, outs['1'], outs['0']):
+        assert torch.equal(a, b_), float((a - b_).abs().max())
+        ref = F.conv2d(x[:2], conv.weight, conv.bias, 1, 1)
+        assert _err(a[:2], ref) < 1e-4, _err(a[:2], ref)
