@@ -75,16 +75,43 @@ __device__ __forceinline__ float edl_row_fwd(const float* x, int n, int c0, long
   return grp_sum<LPR>(tot);
 }
 
+// One launch over ALL pyramid levels (Lambda_L2.py:105-121 runs loss_single once per level through multi_apply): the levels' anchor rows are
+// adjacent row ranges of the same buffers (level-batched prediction convs, level-major targets), and a block belongs to exactly one level --
+// level l owns the blocks [blk_end[l-1], blk_end[l]) and the rows [row_end[l-1], row_end[l]), its blocks start at its first row.  Blocks, rows
+// per block and the order of every sum are those of a per-level launch: identical bits.  (Unused entries: blk_end = INT_MAX.)
+constexpr int MAXLV = 8;
+struct LossLevels { int n; int blk_end[MAXLV]; long long row_end[MAXLV]; };
+// (constant indices only: a run-time index into the by-value argument would move it to scratch memory)
+__device__ __forceinline__ void level_of_block(const LossLevels& lv, int bid, int& level, int& blk0, long long& row0, long long& rend) {
+  level = 0; blk0 = 0; row0 = 0; rend = lv.row_end[0];
+#pragma unroll
+  for (int q = 0; q + 1 < MAXLV; ++q)
+    if (bid >= lv.blk_end[q]) { level = q + 1; blk0 = lv.blk_end[q]; row0 = lv.row_end[q]; rend = lv.row_end[q + 1]; }
+}
+static int fill_levels(LossLevels& lv, int nlevels, const int64_t* level_rows, int rows_per_block, long long& total_rows) {
+  lv.n = nlevels;
+  long long r = 0, b = 0;
+  for (int l = 0; l < MAXLV; ++l) {
+    if (l < nlevels) { r += level_rows[l]; b += (level_rows[l] + rows_per_block - 1) / rows_per_block; }
+    lv.row_end[l] = r;
+    lv.blk_end[l] = l < nlevels ? (int)b : 0x7fffffff;
+  }
+  total_rows = r;
+  return (int)b;
+}
+
 template <int CT, int LPR>
 __global__ __launch_bounds__(LB) void edl_l1_fwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
-                                                        const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
+                                                        const float* __restrict__ bt, const float* __restrict__ bw, const LossLevels lv, int C,
                                                         float gamma, float alpha, float* __restrict__ loss_noR, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   constexpr int RB = LB / LPR;   // rows per block
   const int P = C | 1;  // odd pitch -> conflict-free row reads
-  const long long r0 = (long long)blockIdx.x * RB;
-  const int nr = (int)min((long long)RB, nrows - r0);
+  int level, blk0; long long row0, rend;
+  level_of_block(lv, (int)blockIdx.x, level, blk0, row0, rend);
+  const long long r0 = row0 + (long long)((int)blockIdx.x - blk0) * RB;
+  const int nr = (int)min((long long)RB, rend - r0);
   aod_stage_rows<LB>(cls + r0 * C, srow, nr, C, P);
   __syncthreads();
   float s_cls = 0.f, s_box = 0.f, s_nor = 0.f;
@@ -136,6 +163,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// ... the same for every level of a level-fused launch: block l sums level l's partials (same order) and WRITES out[j * kstride + l * lstride]
+__global__ __launch_bounds__(256) void reduce_partials_levels_kernel(const float* __restrict__ partials, const LossLevels lv, int k, float* __restrict__ out,
+                                                                    int lstride, int kstride) {
+  __shared__ float red[4];
+  int b0 = 0, b1 = lv.blk_end[0];
+#pragma unroll
+  for (int q = 0; q + 1 < MAXLV; ++q)
+    if ((int)blockIdx.x > q) { b0 = lv.blk_end[q]; b1 = lv.blk_end[q + 1]; }
+  const long long nblocks = b1 - b0;
+  const float* pp = partials + (long long)b0 * k;
+  for (int j = 0; j < k; ++j) {
+    float v = 0.f;
+    for (long long i = threadIdx.x; i < nblocks; i += 256) v += pp[i * k + j];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(long long)j * kstride + (long long)blockIdx.x * lstride] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
 static inline int edl_lpr(int C) { return C <= 24 ? 1 : 4; }
 static inline long long edl_blocks(int64_t nrows, int C) { const int rb = LB / edl_lpr(C); return (nrows + rb - 1) / rb; }
 
@@ -149,14 +197,44 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(cls && labels && label_w && loss_noR && sums3 && partials, "edl_fwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC, "edl_fwd: C=%d out of range", C);
   AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_fwd: bbox_pred needs targets and weights");
-  const long long nb = edl_blocks(nrows, C);
+  LossLevels lv; long long tot;
+  const long long nb = fill_levels(lv, 1, &nrows, LB / edl_lpr(C), tot);
   if (C <= 24)
     hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 1>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
-                       label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
+                       label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, loss_noR, partials);
   else
     hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 4>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / 4) * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
-                       label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, loss_noR, partials);
+                       label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, loss_noR, partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 3, sums3);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t aod_loss_levels_partials_len(int nlevels, const int64_t* level_rows) {
+  size_t n = 0;
+  for (int l = 0; l < nlevels; ++l) n += (size_t)((level_rows[l] + LB / 4 - 1) / (LB / 4)) * 3;
+  return n;
+}
+
+extern "C" int aod_edl_focal_l1_levels_fwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
+                                           const float* bbox_tgt, const float* bbox_w, int nlevels, const int64_t* level_rows, int C, float gamma,
+                                           float alpha, float* loss_noR, float* sums, float* partials, aod_stream_t stream) {
+  AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "edl_levels_fwd: 1..8 levels");
+  AOD_CHECK_ARG(cls && labels && label_w && loss_noR && sums && partials, "edl_levels_fwd: null pointer");
+  AOD_CHECK_ARG(C >= 1 && C <= MAXC, "edl_levels_fwd: C=%d out of range", C);
+  AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_levels_fwd: bbox_pred needs targets and weights");
+  LossLevels lv; long long tot;
+  const int nb = fill_levels(lv, nlevels, level_rows, LB / edl_lpr(C), tot);
+  if (nb) {
+    if (C <= 24)
+      hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 1>), dim3((unsigned)nb), dim3(LB), (size_t)LB * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+                         label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, loss_noR, partials);
+    else
+      hipLaunchKernelGGL((edl_l1_fwd_kernel<24, 4>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / 4) * (C | 1) * 4, (hipStream_t)stream, cls, (const long long*)labels,
+                         label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, loss_noR, partials);
+  }
+  // sums[3][nlevels]: row 0 = sum l * w, row 1 = sum |d| * bw, row 2 = sum l, one column per level (an empty level: zeros)
+  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 3, sums, 1, nlevels);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -166,16 +244,19 @@ extern "C" int aod_edl_focal_l1_fwd(const float* cls, const int64_t* labels, con
 template <bool OUT_BF16, int CT, int LPR>
 __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict__ cls, const long long* __restrict__ labels,
                                                         const float* __restrict__ lw, const float* __restrict__ bp,
-                                                        const float* __restrict__ bt, const float* __restrict__ bw, long long nrows, int C,
+                                                        const float* __restrict__ bt, const float* __restrict__ bw, const LossLevels lv, int C,
                                                         float gamma, float alpha, const float* __restrict__ g_cls,
                                                         const float* __restrict__ g_bbox, const float* __restrict__ g_noR, float g_noR_s, int g_noR_bcast,
                                                         void* __restrict__ grad_cls, void* __restrict__ grad_bbox, int A, int pitch_cls,
-                                                        int pitch_box) {
+                                                        int pitch_box, int g_lstride) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   constexpr int RB = LB / LPR;
   const int P = C | 1;
-  const long long r0 = (long long)blockIdx.x * RB;
-  const int nr = (int)min((long long)RB, nrows - r0);
+  int level, blk0; long long row0, rend;
+  level_of_block(lv, (int)blockIdx.x, level, blk0, row0, rend);
+  const long long r0 = row0 + (long long)((int)blockIdx.x - blk0) * RB;
+  const int nr = (int)min((long long)RB, rend - r0);
+  const int gl = level * g_lstride;          // the level's upstream gradients (per-level scalars of a level-fused launch; 0 otherwise)
   const int tot = nr * C;
   aod_stage_rows<LB>(cls + r0 * C, srow, nr, C, P);
   __shared__ long long s_obase[LB];       // element offset of each row's class 0 in the destination
@@ -200,7 +281,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
     for (int c = 0; c < CT; ++c) if (c < n) { p[c] = l_exp(x[c] - m); S += p[c]; }
     S = grp_sum<LPR>(S);
     const long long label = labels[r];
-    const float coef = g_cls[0] * lw[r] + (g_noR ? g_noR[g_noR_bcast ? 0 : r] : g_noR_s);
+    const float coef = g_cls[gl] * lw[r] + (g_noR ? g_noR[g_noR_bcast ? gl : r] : g_noR_s);
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) if (c < n) {
@@ -228,7 +309,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
       for (int c = 0; c < CT; ++c) if (c < n) srow[row * P + c0 + c] = p[c] * (gp[c] - dot);
     }
     if (live && part == 0 && bp && grad_bbox) {
-      const float gb = g_bbox[0];
+      const float gb = g_bbox[gl];
       const long long bb = (r / A) * pitch_box + (r % A) * 4;
       for (int j = 0; j < 4; ++j) {
         const float d = bp[r * 4 + j] - bt[r * 4 + j];
@@ -262,11 +343,35 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(cls && labels && label_w && g_cls && grad_cls, "edl_bwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_bwd: bad C/A/pitch");
   AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && g_bbox && pitch_box >= A * 4), "edl_bwd: bbox args");
-  const long long nb = edl_blocks(nrows, C);
+  LossLevels lv; long long tot;
+  const long long nb = fill_levels(lv, 1, &nrows, LB / edl_lpr(C), tot);
+  const int g_lstride = 0;
 #define AOD_EDL_BWD(BF, LPR_)                                                                                                              \
   hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, 24, LPR_>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / LPR_) * (C | 1) * 4, (hipStream_t)stream, cls, \
-                     (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, (long long)nrows, C, gamma, alpha, g_cls, g_bbox, g_noR, \
-                     g_noR_scalar, g_noR_is_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box)
+                     (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, g_cls, g_bbox, g_noR, \
+                     g_noR_scalar, g_noR_is_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box, g_lstride)
+  if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
+  else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+
+// g_sums[3][nlevels] = the gradients of aod_edl_focal_l1_levels_fwd's sums (row 0: classification sums, row 1: box sums, row 2: row sums);
+// g_noR_rows (optional): a gradient per anchor row of loss_noR, replaces row 2.
+extern "C" int aod_edl_focal_l1_levels_bwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
+                                           const float* bbox_tgt, const float* bbox_w, int nlevels, const int64_t* level_rows, int C, float gamma,
+                                           float alpha, const float* g_sums, const float* g_noR_rows, void* grad_cls, void* grad_bbox, int out_bf16,
+                                           int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
+  AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "edl_levels_bwd: 1..8 levels");
+  AOD_CHECK_ARG(cls && labels && label_w && g_sums && grad_cls, "edl_levels_bwd: null pointer");
+  AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_levels_bwd: bad C/A/pitch");
+  AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && pitch_box >= A * 4), "edl_levels_bwd: bbox args");
+  LossLevels lv; long long tot;
+  const int nb = fill_levels(lv, nlevels, level_rows, LB / edl_lpr(C), tot);
+  if (nb == 0) return 0;
+  const float* g_cls = g_sums; const float* g_bbox = g_sums + nlevels;
+  const float* g_noR = g_noR_rows ? g_noR_rows : g_sums + 2 * nlevels;
+  const float g_noR_scalar = 0.f; const int g_noR_is_scalar = g_noR_rows ? 0 : 1, g_lstride = 1;
   if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
   else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
 #undef AOD_EDL_BWD
@@ -276,9 +381,11 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
 
 // ---------------------------------------------------------------- MEH loss
 __global__ __launch_bounds__(256) void meh_fwd_kernel(const float* __restrict__ lam, const float* __restrict__ loss, const float* __restrict__ bw4,
-                                                      long long n, float* __restrict__ partials) {
+                                                      const LossLevels lv, float* __restrict__ partials) {
   float s = 0.f;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int level, blk0; long long row0, n;
+  level_of_block(lv, (int)blockIdx.x, level, blk0, row0, n);
+  const long long i = row0 + (long long)((int)blockIdx.x - blk0) * 256 + threadIdx.x;
   if (i < n) {
     const float d = fabsf(lam[i] + 1e-9f - loss[i]) * bw4[i * 4];
     s = d * d;
@@ -290,12 +397,14 @@ __global__ __launch_bounds__(256) void meh_fwd_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 template <bool OUT_BF16>
-__global__ void meh_bwd_kernel(const float* __restrict__ lam, const float* __restrict__ loss, const float* __restrict__ bw4, long long n,
-                               const float* __restrict__ g, void* __restrict__ grad, int A, int pitch) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void meh_bwd_kernel(const float* __restrict__ lam, const float* __restrict__ loss, const float* __restrict__ bw4, const LossLevels lv,
+                               const float* __restrict__ g, void* __restrict__ grad, int A, int pitch, int g_lstride) {
+  int level, blk0; long long row0, n;
+  level_of_block(lv, (int)blockIdx.x, level, blk0, row0, n);
+  const long long i = row0 + (long long)((int)blockIdx.x - blk0) * 256 + threadIdx.x;
   if (i < n) {
     const float w = bw4[i * 4];
-    const float v = g[0] * 2.f * w * w * (lam[i] + 1e-9f - loss[i]);
+    const float v = g[level * g_lstride] * 2.f * w * w * (lam[i] + 1e-9f - loss[i]);
     const long long o = (i / A) * pitch + (i % A);
     if (OUT_BF16) ((bf16_t*)grad)[o] = (bf16_t)v; else ((float*)grad)[o] = v;
   }
@@ -304,9 +413,22 @@ extern "C" int aod_meh_loss_fwd(const float* lam, const float* loss_noR, const f
                                 aod_stream_t stream) {
   AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && out_sum && partials, "meh_fwd: null pointer");
   if (n == 0) return 0;
-  const long long nb = (n + 255) / 256;
-  hipLaunchKernelGGL(meh_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, partials);
+  LossLevels lv; long long tot;
+  const long long nb = fill_levels(lv, 1, &n, 256, tot);
+  hipLaunchKernelGGL(meh_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, 1, out_sum);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+// all levels in one launch (Lambda_L2.py:235-241 once per level): out_sums[nlevels]
+extern "C" int aod_meh_loss_levels_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int nlevels, const int64_t* level_rows,
+                                       float* out_sums, float* partials, aod_stream_t stream) {
+  AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "meh_levels_fwd: 1..8 levels");
+  AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && out_sums && partials, "meh_levels_fwd: null pointer");
+  LossLevels lv; long long tot;
+  const int nb = fill_levels(lv, nlevels, level_rows, 256, tot);
+  if (nb) hipLaunchKernelGGL(meh_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, partials);
+  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 1, out_sums, 1, nlevels);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -314,9 +436,22 @@ extern "C" int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const f
                                 int out_bf16, int A, int pitch, aod_stream_t stream) {
   AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && g && grad_lam && A >= 1 && pitch >= A, "meh_bwd: bad args");
   if (n == 0) return 0;
-  const long long nb = (n + 255) / 256;
-  if (out_bf16) hipLaunchKernelGGL((meh_bwd_kernel<true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, g, grad_lam, A, pitch);
-  else hipLaunchKernelGGL((meh_bwd_kernel<false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, (long long)n, g, grad_lam, A, pitch);
+  LossLevels lv; long long tot;
+  const long long nb = fill_levels(lv, 1, &n, 256, tot);
+  if (out_bf16) hipLaunchKernelGGL((meh_bwd_kernel<true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, g, grad_lam, A, pitch, 0);
+  else hipLaunchKernelGGL((meh_bwd_kernel<false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, g, grad_lam, A, pitch, 0);
+  AOD_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int aod_meh_loss_levels_bwd(const float* lam, const float* loss_noR, const float* bbox_w4, int nlevels, const int64_t* level_rows,
+                                       const float* g, void* grad_lam, int out_bf16, int A, int pitch, aod_stream_t stream) {
+  AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "meh_levels_bwd: 1..8 levels");
+  AOD_CHECK_ARG(lam && loss_noR && bbox_w4 && g && grad_lam && A >= 1 && pitch >= A, "meh_levels_bwd: bad args");
+  LossLevels lv; long long tot;
+  const int nb = fill_levels(lv, nlevels, level_rows, 256, tot);
+  if (nb == 0) return 0;
+  if (out_bf16) hipLaunchKernelGGL((meh_bwd_kernel<true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, g, grad_lam, A, pitch, 1);
+  else hipLaunchKernelGGL((meh_bwd_kernel<false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, g, grad_lam, A, pitch, 1);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -1270,6 +1270,109 @@ class RetinaLossFn(Function):
                 None, None, None, None, None, None, None, None, None)
 
 
+def dense_concat(tensors):
+    """The tensors as ONE contiguous view when each is contiguous and starts where the previous one ends (pyramid levels of a level-batched
+    conv's output, level-major target arrays): tensors[0]'s storage seen as [sum(rows), *shape[1:]].  None otherwise."""
+    t0 = tensors[0]
+    tail = tuple(t0.shape[1:])
+    end = t0.data_ptr()
+    rows = 0
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != t0.dtype or tuple(t.shape[1:]) != tail or t.data_ptr() != end:
+            return None
+        end += t.numel() * t.element_size()
+        rows += t.shape[0]
+    if t0.untyped_storage().data_ptr() + t0.untyped_storage().nbytes() < end:
+        return None
+    shape = (rows,) + tail
+    stride, acc = [], 1
+    for d in reversed(shape):
+        stride.append(acc)
+        acc *= d
+    return t0.as_strided(shape, tuple(reversed(stride)))
+
+
+LOSS_LEVELS = __import__('os').environ.get('AOD_LOSS_LEVELS', '1') != '0'      # 0: one loss launch per pyramid level (the earlier form)
+
+
+class RetinaLossLevelsFn(Function):
+    """RetinaLossFn for ALL pyramid levels in one launch per pass (the reference: loss_single once per level through multi_apply,
+    L_anchor_head.py:306-314 -> Lambda_L2.py:105-121).  Inputs are the dense all-level views (dense_concat); returns (sums [3, L], loss_noR
+    [all rows]).  Same blocks, same summation orders as the per-level launches: identical bits (tests/test_gpu_kernels.py)."""
+
+    @staticmethod
+    def forward(ctx, cls_rows, box_rows, labels, label_w, bbox_t, bbox_w, gamma, alpha, level_rows, shapes):
+        ctx.set_materialize_grads(False)
+        noR, sums = ho.edl_focal_l1_levels_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, gamma, alpha)
+        ctx.save_for_backward(cls_rows, box_rows, labels, label_w, bbox_t, bbox_w)
+        ctx.cfg = (gamma, alpha, tuple(level_rows), shapes)
+        return sums, noR
+
+    @staticmethod
+    def backward(ctx, g_sums, g_noR):
+        cls_rows, box_rows, labels, label_w, bbox_t, bbox_w = ctx.saved_tensors
+        gamma, alpha, level_rows, (A, AC, A4) = ctx.cfg
+        dev = cls_rows.device
+        L = len(level_rows)
+        g_sums = torch.zeros(3, L, device=dev) if g_sums is None else g_sums.float().contiguous()
+        g_rows = None
+        if g_noR is not None:              # (nobody on the training path differentiates the rows: train_step detaches them)
+            g_rows = (g_noR.float() + torch.repeat_interleave(g_sums[2], torch.tensor(level_rows, device=dev))).contiguous()
+        gc = torch.empty(cls_rows.shape[0] // A, AC, dtype=torch.float32, device=dev)
+        gb = torch.empty(cls_rows.shape[0] // A, A4, dtype=torch.float32, device=dev)
+        ho.edl_focal_l1_levels_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, g_sums, g_rows, gc, gb, A, gamma, alpha)
+        return gc.view(cls_rows.shape), gb.view(box_rows.shape), None, None, None, None, None, None, None, None
+
+
+class MEHLossLevelsFn(Function):
+    """MEHLossFn for all pyramid levels in one launch per pass (Lambda_L2.py:235-241 once per level): lam / loss_noR / bbox_w are the dense
+    all-level views; returns the per-level sums [L]."""
+
+    @staticmethod
+    def forward(ctx, lam, loss_noR, bbox_w, level_rows, A):
+        out = ho.meh_loss_levels_fwd(lam, loss_noR, bbox_w, level_rows)
+        ctx.save_for_backward(lam, loss_noR, bbox_w)
+        ctx.cfg = (tuple(level_rows), A)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lam, loss_noR, bw = ctx.saved_tensors
+        level_rows, A = ctx.cfg
+        gl = torch.empty(lam.numel() // A, A, dtype=torch.float32, device=lam.device)
+        ho.meh_loss_levels_bwd(lam, loss_noR, bw, level_rows, g.float().contiguous(), gl, A)
+        return gl.view(lam.shape), None, None, None, None
+
+
+class _LevelViewsFn(Function):
+    """[B, C, H, W] pyramid-level tensors (adjacent row ranges of one buffer) -> their dense [all rows, C] view, for the level-fused loss
+    launches; backward hands every level its row range of the ONE gradient buffer as a view -- what GradArena does for the per-level launches:
+    the prediction conv's level-batched backward reads the ranges in place (`_grad_rows`), nothing is concatenated or copied."""
+
+    @staticmethod
+    def forward(ctx, dense, *levels):
+        ctx.shapes = [tuple(t.shape) for t in levels]
+        return dense.view_as(dense)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, r = [], 0
+        for B, C, H, W in ctx.shapes:
+            outs.append(as_nchw(g[r:r + B * H * W].view(B * H * W, C), B, H, W))
+            r += B * H * W
+        return (None,) + tuple(outs)
+
+
+def dense_levels(levels):
+    """Dense [sum(B*H*W), C] fp32 view of adjacent pyramid-level tensors that carries their autograd history (None when not adjacent)."""
+    rows = [as_rows(t) for t in levels]
+    with torch.no_grad():
+        dense = dense_concat([r.detach() for r in rows])
+    if dense is None:
+        return None
+    return _LevelViewsFn.apply(dense, *levels)
+
+
 class MEHLossFn(Function):
     """sum(((|lambda + 1e-9 - loss_noR|) * w)^2) for one level (Lambda_L2.py:235-241)."""
 

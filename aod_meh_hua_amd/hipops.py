@@ -693,6 +693,58 @@ def meh_loss_bwd(lam, loss_noR, bbox_w4, g, out_bf16=False, A=1, pitch=None, gra
     return grad
 
 
+def _level_rows(rows):
+    """HOST int64 array of per-level row counts for the level-fused loss launches (kept alive by the caller for the duration of the call)."""
+    return (C.c_int64 * len(rows))(*[int(r) for r in rows])
+
+
+def edl_focal_l1_levels_fwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, level_rows, gamma=2.0, alpha=0.25):
+    """All pyramid levels in one launch: cls [rows, C] fp32 with level l = rows [sum(level_rows[:l]), +level_rows[l]).  Returns
+    (loss_noR [rows], sums [3, L]) -- bit-identical to L calls of edl_focal_l1_fwd on the level slices."""
+    rows, Cc = cls.shape
+    L = len(level_rows)
+    assert sum(level_rows) == rows
+    lr = _level_rows(level_rows)
+    loss_noR = torch.empty(rows, dtype=torch.float32, device=cls.device)
+    sums = torch.empty(3, L, dtype=torch.float32, device=cls.device)
+    part = torch.empty(max(int(_C.lib.aod_loss_levels_partials_len(L, lr)), 1), dtype=torch.float32, device=cls.device)
+    prof_bytes('edl_l1_fwd', rows * (Cc * 4 + 8 + 4 + (48 if bbox_pred is not None else 0) + 4),
+               lambda: call('aod_edl_focal_l1_levels_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), L, lr, Cc,
+                            gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream()))
+    return loss_noR, sums
+
+
+def edl_focal_l1_levels_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, level_rows, g_sums, g_noR_rows, grad_cls, grad_bbox, A,
+                            gamma=2.0, alpha=0.25):
+    """g_sums [3, L] fp32 contiguous; gradients are written into grad_cls [rows / A, A * C] / grad_bbox [rows / A, A * 4] (fp32, unpadded)."""
+    rows, Cc = cls.shape
+    L = len(level_rows)
+    lr = _level_rows(level_rows)
+    assert g_sums.shape == (3, L) and g_sums.is_contiguous() and g_sums.dtype == torch.float32
+    prof_bytes('edl_l1_bwd', rows * (Cc * 4 + 8 + 4 + (4 if g_noR_rows is not None else 0) + Cc * 4 + ((48 + 16) if bbox_pred is not None else 0)),
+               lambda: call('aod_edl_focal_l1_levels_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), L, lr, Cc,
+                            gamma, alpha, ptr(g_sums), ptr(g_noR_rows), ptr(grad_cls), ptr(grad_bbox), 0, A, A * Cc, A * 4, stream()))
+    return grad_cls, grad_bbox
+
+
+def meh_loss_levels_fwd(lam, loss_noR, bbox_w4, level_rows):
+    L = len(level_rows)
+    assert sum(level_rows) == lam.numel()
+    lr = _level_rows(level_rows)
+    out = torch.empty(L, dtype=torch.float32, device=lam.device)
+    part = torch.empty(max(int(_C.lib.aod_loss_levels_partials_len(L, lr)), 1), dtype=torch.float32, device=lam.device)
+    call('aod_meh_loss_levels_fwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), L, lr, ptr(out), ptr(part), stream())
+    return out
+
+
+def meh_loss_levels_bwd(lam, loss_noR, bbox_w4, level_rows, g, grad, A):
+    L = len(level_rows)
+    lr = _level_rows(level_rows)
+    assert g.shape == (L,) and g.is_contiguous() and g.dtype == torch.float32
+    call('aod_meh_loss_levels_bwd', ptr(lam), ptr(loss_noR), ptr(bbox_w4), L, lr, ptr(g), ptr(grad), 0, A, A, stream())
+    return grad
+
+
 def pad_cast_colsum(g, npad, relu_out=None):
     M, N = g.shape
     assert relu_out is None or relu_out.dtype == torch.float32

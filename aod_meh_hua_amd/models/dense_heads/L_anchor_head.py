@@ -167,20 +167,30 @@ class L_AnchorHead(BaseModule):
         head_info = ['cls_scores', 'bbox_preds', 'all_anchor_list', 'labels_list', 'label_weights_list', 'bbox_targets_list',
                      'bbox_weights_list', 'num_total_samples']
         head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
-        if self._can_defer_avg:             # (heads on the HIP loss kernels) one gradient buffer per prediction conv, a row range per level
+        fused = None
+        if self._can_defer_avg:             # (heads on the HIP loss kernels)
             from ... import functional as AF
-            kwargs = dict(kwargs, grad_arena=AF.GradArena([c.shape[0] * c.shape[2] * c.shape[3] for c in cls_scores]))
-        outs = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list,
-                           list(range(len(cls_scores))), num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
-                           defer_avg=self._can_defer_avg, **kwargs)
-        losses_cls, losses_bbox, losses_noR = outs[0], outs[1], outs[2]
+            # every level in ONE launch per pass when the levels are adjacent row ranges of their buffers (they are: level-batched prediction
+            # convs, level-major targets); sums [3, L] and the per-level loss_noR rows come back bit-identical to the per-level launches
+            fused = self.loss_all_levels(cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, **kwargs) if AF.LOSS_LEVELS else None
+            if fused is None:               # one gradient buffer per prediction conv, a row range per level
+                kwargs = dict(kwargs, grad_arena=AF.GradArena([c.shape[0] * c.shape[2] * c.shape[3] for c in cls_scores]))
+        if fused is None:
+            outs = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list,
+                               list(range(len(cls_scores))), num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
+                               defer_avg=self._can_defer_avg, **kwargs)
+            losses_cls, losses_bbox, losses_noR = outs[0], outs[1], outs[2]
         if self._can_defer_avg:
             # the per-level "sum / num_total_samples" of loss_single (L_anchor_head.py:266-288) and the "mean(loss_noR)" of
             # _parse_losses (SSL_Lambda.py:136-141) for all levels at once: the same quotients from three launches (stack, divisor, divide)
             # instead of ten divisions and five row reductions -- and as many fewer in backward
             from ... import functional as AF
-            L = len(losses_cls)
-            S = torch.stack(list(losses_cls) + list(losses_bbox) + list(outs[3])).view(3, L)
+            if fused is not None:
+                S, losses_noR = fused
+                L = S.shape[1]
+            else:
+                L = len(losses_cls)
+                S = torch.stack(list(losses_cls) + list(losses_bbox) + list(outs[3])).view(3, L)
             counts = self._level_counts([int(t.numel()) for t in losses_noR], S.device)
             D = torch.cat([num_total_samples.reshape(1).expand(2 * L), counts]).view(3, L)
             Q = S / D
@@ -200,11 +210,21 @@ class L_AnchorHead(BaseModule):
 
     _can_defer_avg = False      # set by heads whose loss_single understands defer_avg
 
+    def loss_all_levels(self, *args, **kwargs):     # heads with a level-fused loss launch override these; None = the per-level path
+        return None
+
+    def loss_all_levels_L(self, *args, **kwargs):
+        return None
+
     @force_fp32(apply_to=('L_scores'))
     def loss_L(self, L_scores, head_out, losses, **kwargs):
         """L_anchor_head.py:322-327."""
         if self._can_defer_avg:
             from ... import functional as AF
+            fused = self.loss_all_levels_L(L_scores, losses, head_out[7], **kwargs) if AF.LOSS_LEVELS else None
+            if fused is not None:
+                Q = fused * self._level_counts([5.0 / int(t.numel()) for t in losses], fused.device)     # 5 * mean(.) per level
+                return dict(loss_L=AF.PackedLosses(Q.unbind(0), Q))
             arena = AF.GradArena([l.shape[0] * l.shape[2] * l.shape[3] for l in L_scores])
             sums, scales = multi_apply(self.loss_single_L, L_scores, losses, head_out[5], head_out[7], list(range(len(L_scores))),
                                        defer_scale=True, grad_arena=arena, **kwargs)

@@ -126,6 +126,39 @@ class Lambda_L2Net(L_AnchorHead):
         loss_bbox = scaled(wb, sum_box) / num_total_samples
         return loss_cls, loss_bbox, scaled(wc, loss_noR)
 
+    def loss_all_levels(self, cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, **kwargs):
+        """loss_single (Lambda_L2.py:105-121) for every level in one launch per pass: (sums [3, L] = per-level (sum l*w, sum |d|*bw, sum l),
+        [loss_noR rows per level]) or None when the levels are not adjacent row ranges / the loss weights are not 1 (then: per level)."""
+        if not (kwargs.get('Labeled', True) and not kwargs.get('Pseudo', False)):
+            raise NotImplementedError('pseudo-label branch (Lambda_L2.py:122-232) is dead code in the reference driver')
+        if self.loss_cls.loss_weight != 1.0 or self.loss_bbox.loss_weight != 1.0:
+            return None
+        assert type(self.loss_bbox).__name__ == 'L1Loss' and type(self.loss_cls).__name__ == 'EDL_Softmax_FocalLoss'
+        C = self.cls_out_channels
+        cls_d, box_d = AF.dense_levels(cls_scores), AF.dense_levels(bbox_preds)
+        flat = [AF.dense_concat([t.reshape(-1, *t.shape[2:]) for t in ts]) for ts in (labels_list, lw_list, bt_list, bw_list)]
+        if cls_d is None or box_d is None or any(f is None for f in flat) or cls_d.dtype != torch.float32 or box_d.dtype != torch.float32:
+            return None
+        A = cls_d.shape[1] // C
+        level_rows = [c.shape[0] * c.shape[2] * c.shape[3] * A for c in cls_scores]
+        sums, noR = AF.RetinaLossLevelsFn.apply(cls_d.view(-1, C), box_d.view(-1, 4), flat[0], flat[1], flat[2], flat[3],
+                                                float(self.loss_cls.gamma), float(self.loss_cls.alpha), level_rows,
+                                                (A, cls_d.shape[1], box_d.shape[1]))
+        return sums, list(noR.split(level_rows))
+
+    def loss_all_levels_L(self, L_scores, losses, bw_list, **kwargs):
+        """loss_single_L (Lambda_L2.py:235-241) for every level in one launch per pass: the per-level sums [L], or None."""
+        lam_d = AF.dense_levels(L_scores)
+        noR = AF.dense_concat([t.reshape(-1) for t in losses])
+        bw = AF.dense_concat([t.reshape(-1, 4) for t in bw_list])
+        if lam_d is None or noR is None or bw is None or lam_d.dtype != torch.float32 or noR.dtype != torch.float32 or noR.requires_grad:
+            return None
+        A = lam_d.shape[1]
+        level_rows = [l.shape[0] * l.shape[2] * l.shape[3] * A for l in L_scores]
+        if [int(t.numel()) for t in losses] != level_rows:
+            return None
+        return AF.MEHLossLevelsFn.apply(lam_d.view(-1), noR, bw, level_rows, A)
+
     @force_fp32(apply_to=('L_score'))
     def loss_single_L(self, L_score, loss, label_weights, bbox_weights, sIdx=0, **kwargs):
         """Lambda_L2.py:235-241: mean(((|lambda + 1e-9 - loss|) * bbox_weights[...,0])^2) * 5."""

@@ -312,6 +312,28 @@ int aod_meh_loss_fwd(const float* lam, const float* loss_noR, const float* bbox_
                      float* out_sum, float* partials, aod_stream_t stream);
 int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const float* bbox_w4, int64_t n,
                      const float* g, void* grad_lam, int out_bf16, int A, int pitch, aod_stream_t stream);
+/* The same four passes over ALL pyramid levels in one launch each (the reference runs loss_single / loss_single_L once per level through
+ * multi_apply: L_anchor_head.py:306-314,322-327, Lambda_L2.py:105-121,235-241).  The levels' anchor rows are adjacent row ranges of every
+ * operand (level l = rows [sum(level_rows[:l]), + level_rows[l]), what the level-batched prediction convs and the level-major targets of
+ * aod_max_iou_assign produce); level_rows: HOST array of nlevels <= 8 row counts.  Blocks never straddle a level and every sum runs in the
+ * order of a per-level call: loss_noR, the sums and the gradients are bit-identical to nlevels separate calls.
+ *   sums [3][nlevels]  (written, not accumulated): row 0 = sum(l*w), row 1 = sum(|p-t|*bw), row 2 = sum(loss_noR) of each level
+ *   g_sums [3][nlevels]: their gradients (device); g_noR_rows: optional per-row gradient of loss_noR, then used INSTEAD of row 2
+ *   out_sums [nlevels] / g [nlevels]: the MEH sums and their gradients.  partials: >= aod_loss_levels_partials_len floats. */
+size_t aod_loss_levels_partials_len(int nlevels, const int64_t* level_rows);
+int aod_edl_focal_l1_levels_fwd(const float* cls, const int64_t* labels, const float* label_w,
+                                const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
+                                int nlevels, const int64_t* level_rows, int C, float gamma, float alpha,
+                                float* loss_noR, float* sums, float* partials, aod_stream_t stream);
+int aod_edl_focal_l1_levels_bwd(const float* cls, const int64_t* labels, const float* label_w,
+                                const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
+                                int nlevels, const int64_t* level_rows, int C, float gamma, float alpha,
+                                const float* g_sums, const float* g_noR_rows, void* grad_cls, void* grad_bbox, int out_bf16,
+                                int A, int pitch_cls, int pitch_box, aod_stream_t stream);
+int aod_meh_loss_levels_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int nlevels, const int64_t* level_rows,
+                            float* out_sums, float* partials, aod_stream_t stream);
+int aod_meh_loss_levels_bwd(const float* lam, const float* loss_noR, const float* bbox_w4, int nlevels, const int64_t* level_rows,
+                            const float* g, void* grad_lam, int out_bf16, int A, int pitch, aod_stream_t stream);
 
 /* ------------------------------------------------------------------ geometry (K9, K10)
  * replaces: AnchorGenerator.grid_anchors/valid_flags (core/anchor/anchor_generator.py:308-438),
