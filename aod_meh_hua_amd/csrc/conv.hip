@@ -1817,6 +1817,15 @@ static void wgrad_plan(int M, int N, int K, bool slabs, int& tiles_n, int& tiles
   if (x3 && !(dbg_wide && dbg_wide[0] == '0')) {
     if (N % 512 == 0 && K % 512 == 0 && M >= big_min_m && !(dbg_big && dbg_big[0] == '0')) big = 2;
     else if (N % 256 == 0 && K % 256 == 0) big = 3;
+    else {
+      // narrow dZ (the prediction convs: 384 / 128 / 64 physical columns) on a long pixel axis: the wide 4-wave form with a ragged column
+      // tile (its loads of columns >= N return zeros, its stores are bounds-checked) -- 128 FLOP per staged byte instead of 64, which is what
+      // bounds the 128 x 128 form.  AOD_WGRAD_X3_RAGGED=0: the 128 x 128 form.
+      static const char* dbg_rag = getenv("AOD_WGRAD_X3_RAGGED");
+      // (64 columns -- retina_L -- stay on the 128 x 128 form: 118 vs 137 us; the 8-wave wide form for the 384-column retina_cls measured the
+      // same as this one, profiles/r05_x3_tile_ab.txt)
+      if (!(dbg_rag && dbg_rag[0] == '0') && N % 64 == 0 && N >= 128 && K % 256 == 0 && M >= 16384) big = 3;
+    }
   }
   const int T = big == 2 ? 512 : (big ? 256 : 128);
   tiles_n = (N + T - 1) / T;
