@@ -96,8 +96,8 @@ _SIGS = {
     'aod_meh_loss_fwd': (C.c_int, [P, P, P, I64, P, P, P]),
     'aod_meh_loss_bwd': (C.c_int, [P, P, P, I64, P, P, I32, I32, I32, P]),
     'aod_loss_levels_partials_len': (SZ, [I32, P]),
-    'aod_edl_focal_l1_levels_fwd': (C.c_int, [P, P, P, P, P, P, I32, P, I32, F32, F32, P, P, P, P]),
-    'aod_edl_focal_l1_levels_bwd': (C.c_int, [P, P, P, P, P, P, I32, P, I32, F32, F32, P, P, P, P, I32, I32, I32, I32, P]),
+    'aod_edl_focal_l1_levels_fwd': (C.c_int, [P, P, P, P, P, P, I32, P, I32, F32, F32, P, P, P, P, I32, P, P, P]),
+    'aod_edl_focal_l1_levels_bwd': (C.c_int, [P, P, P, P, P, P, I32, P, I32, F32, F32, P, P, P, P, P, I32, I32, I32, I32, P]),
     'aod_meh_loss_levels_fwd': (C.c_int, [P, P, P, I32, P, P, P, P]),
     'aod_meh_loss_levels_bwd': (C.c_int, [P, P, P, I32, P, P, P, I32, I32, I32, P]),
     'aod_softmax_rowmax': (C.c_int, [P, I32, I64, I32, F32, P, P, I32, P]),

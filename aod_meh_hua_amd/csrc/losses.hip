@@ -164,13 +164,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ... the same for every level of a level-fused launch: block l sums level l's partials (same order) and WRITES out[j * kstride + l * lstride]
+// With `num_pos` (per-image positive counts of aod_max_iou_assign): the sums leave as the per-level loss terms of L_anchor_head.py:266-288 /
+// SSL_Lambda.py:136-141 -- rows 0, 1 divided by num_total_samples = sum_b max(num_pos[b], 1) (L_anchor_head.py:300-303), row 2 (k = 3) by the
+// level's row count (the mean of loss_noR) --, IEEE divisions like the tensor ops they replace; the divisors are kept for the backward pass.
 __global__ __launch_bounds__(256) void reduce_partials_levels_kernel(const float* __restrict__ partials, const LossLevels lv, int k, float* __restrict__ out,
-                                                                    int lstride, int kstride) {
+                                                                    int lstride, int kstride, const int* __restrict__ num_pos, int nimg,
+                                                                    float* __restrict__ divisors, float* __restrict__ num_total) {
   __shared__ float red[4];
   int b0 = 0, b1 = lv.blk_end[0];
+  long long r0 = 0, r1 = lv.row_end[0];
 #pragma unroll
   for (int q = 0; q + 1 < MAXLV; ++q)
-    if ((int)blockIdx.x > q) { b0 = lv.blk_end[q]; b1 = lv.blk_end[q + 1]; }
+    if ((int)blockIdx.x > q) { b0 = lv.blk_end[q]; b1 = lv.blk_end[q + 1]; r0 = lv.row_end[q]; r1 = lv.row_end[q + 1]; }
+  float nt = 1.f;
+  if (num_pos && threadIdx.x == 0) {
+    long long tot = 0;
+    for (int b = 0; b < nimg; ++b) tot += max(num_pos[b], 1);
+    nt = (float)tot;
+    if (blockIdx.x == 0 && num_total) num_total[0] = nt;
+  }
   const long long nblocks = b1 - b0;
   const float* pp = partials + (long long)b0 * k;
   for (int j = 0; j < k; ++j) {
@@ -179,7 +191,15 @@ __global__ __launch_bounds__(256) void reduce_partials_levels_kernel(const float
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) out[(long long)j * kstride + (long long)blockIdx.x * lstride] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+      const long long o = (long long)j * kstride + (long long)blockIdx.x * lstride;
+      const float v = red[0] + red[1] + red[2] + red[3];
+      if (num_pos) {
+        const float d = j < 2 ? nt : (float)(r1 - r0);
+        divisors[o] = d;
+        out[o] = v / d;
+      } else out[o] = v;
+    }
     __syncthreads();
   }
 }
@@ -218,8 +238,10 @@ extern "C" size_t aod_loss_levels_partials_len(int nlevels, const int64_t* level
 
 extern "C" int aod_edl_focal_l1_levels_fwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
                                            const float* bbox_tgt, const float* bbox_w, int nlevels, const int64_t* level_rows, int C, float gamma,
-                                           float alpha, float* loss_noR, float* sums, float* partials, aod_stream_t stream) {
+                                           float alpha, float* loss_noR, float* sums, float* partials, const int32_t* num_pos, int num_images,
+                                           float* divisors, float* num_total, aod_stream_t stream) {
   AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "edl_levels_fwd: 1..8 levels");
+  AOD_CHECK_ARG(!num_pos || (num_images >= 1 && divisors), "edl_levels_fwd: num_pos needs the image count and a divisor buffer");
   AOD_CHECK_ARG(cls && labels && label_w && loss_noR && sums && partials, "edl_levels_fwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC, "edl_levels_fwd: C=%d out of range", C);
   AOD_CHECK_ARG(!bbox_pred || (bbox_tgt && bbox_w), "edl_levels_fwd: bbox_pred needs targets and weights");
@@ -234,7 +256,8 @@ extern "C" int aod_edl_focal_l1_levels_fwd(const float* cls, const int64_t* labe
                          label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, loss_noR, partials);
   }
   // sums[3][nlevels]: row 0 = sum l * w, row 1 = sum |d| * bw, row 2 = sum l, one column per level (an empty level: zeros)
-  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 3, sums, 1, nlevels);
+  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 3, sums, 1, nlevels, (const int*)num_pos,
+                     num_images, divisors, num_total);
   AOD_LAUNCH_CHECK();
   return 0;
 }
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
                                                         float gamma, float alpha, const float* __restrict__ g_cls,
                                                         const float* __restrict__ g_bbox, const float* __restrict__ g_noR, float g_noR_s, int g_noR_bcast,
                                                         void* __restrict__ grad_cls, void* __restrict__ grad_bbox, int A, int pitch_cls,
-                                                        int pitch_box, int g_lstride) {
+                                                        int pitch_box, int g_lstride, const float* __restrict__ g_div, int nlv) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   constexpr int RB = LB / LPR;
   const int P = C | 1;
@@ -281,7 +304,10 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
     for (int c = 0; c < CT; ++c) if (c < n) { p[c] = l_exp(x[c] - m); S += p[c]; }
     S = grp_sum<LPR>(S);
     const long long label = labels[r];
-    const float coef = g_cls[gl] * lw[r] + (g_noR ? g_noR[g_noR_bcast ? gl : r] : g_noR_s);
+    // (g_div: the upstream gradients are those of the DIVIDED sums -- the quotient is what autograd's division backward forms)
+    const float gc_ = g_div ? g_cls[gl] / g_div[gl] : g_cls[gl];
+    const float gn_ = g_noR ? (g_noR_bcast ? (g_div ? g_noR[gl] / g_div[2 * nlv + gl] : g_noR[gl]) : g_noR[r]) : g_noR_s;
+    const float coef = gc_ * lw[r] + gn_;
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) if (c < n) {
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(LB) void edl_l1_bwd_kernel(const float* __restrict_
       for (int c = 0; c < CT; ++c) if (c < n) srow[row * P + c0 + c] = p[c] * (gp[c] - dot);
     }
     if (live && part == 0 && bp && grad_bbox) {
-      const float gb = g_bbox[gl];
+      const float gb = g_div ? g_bbox[gl] / g_div[nlv + gl] : g_bbox[gl];
       const long long bb = (r / A) * pitch_box + (r % A) * 4;
       for (int j = 0; j < 4; ++j) {
         const float d = bp[r * 4 + j] - bt[r * 4 + j];
@@ -345,23 +371,25 @@ extern "C" int aod_edl_focal_l1_bwd(const float* cls, const int64_t* labels, con
   AOD_CHECK_ARG(!grad_bbox || (bbox_pred && bbox_tgt && bbox_w && g_bbox && pitch_box >= A * 4), "edl_bwd: bbox args");
   LossLevels lv; long long tot;
   const long long nb = fill_levels(lv, 1, &nrows, LB / edl_lpr(C), tot);
-  const int g_lstride = 0;
+  const int g_lstride = 0, nlv_ = 1;
+  const float* const g_div = nullptr;
 #define AOD_EDL_BWD(BF, LPR_)                                                                                                              \
   hipLaunchKernelGGL((edl_l1_bwd_kernel<BF, 24, LPR_>), dim3((unsigned)nb), dim3(LB), (size_t)(LB / LPR_) * (C | 1) * 4, (hipStream_t)stream, cls, \
                      (const long long*)labels, label_w, bbox_pred, bbox_tgt, bbox_w, lv, C, gamma, alpha, g_cls, g_bbox, g_noR, \
-                     g_noR_scalar, g_noR_is_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box, g_lstride)
+                     g_noR_scalar, g_noR_is_scalar, grad_cls, grad_bbox, A, pitch_cls, pitch_box, g_lstride, g_div, nlv_)
   if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
   else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
   AOD_LAUNCH_CHECK();
   return 0;
 }
 
-// g_sums[3][nlevels] = the gradients of aod_edl_focal_l1_levels_fwd's sums (row 0: classification sums, row 1: box sums, row 2: row sums);
+// g_sums[3][nlevels] = the gradients of aod_edl_focal_l1_levels_fwd's sums (row 0: classification sums, row 1: box sums, row 2: row sums) --
+// of the DIVIDED sums when `divisors` (the forward's) is given: the kernel forms g / divisor itself;
 // g_noR_rows (optional): a gradient per anchor row of loss_noR, replaces row 2.
 extern "C" int aod_edl_focal_l1_levels_bwd(const float* cls, const int64_t* labels, const float* label_w, const float* bbox_pred,
                                            const float* bbox_tgt, const float* bbox_w, int nlevels, const int64_t* level_rows, int C, float gamma,
-                                           float alpha, const float* g_sums, const float* g_noR_rows, void* grad_cls, void* grad_bbox, int out_bf16,
-                                           int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
+                                           float alpha, const float* g_sums, const float* divisors, const float* g_noR_rows, void* grad_cls,
+                                           void* grad_bbox, int out_bf16, int A, int pitch_cls, int pitch_box, aod_stream_t stream) {
   AOD_CHECK_ARG(nlevels >= 1 && nlevels <= MAXLV && level_rows, "edl_levels_bwd: 1..8 levels");
   AOD_CHECK_ARG(cls && labels && label_w && g_sums && grad_cls, "edl_levels_bwd: null pointer");
   AOD_CHECK_ARG(C >= 1 && C <= MAXC && A >= 1 && pitch_cls >= A * C, "edl_levels_bwd: bad C/A/pitch");
@@ -371,7 +399,8 @@ extern "C" int aod_edl_focal_l1_levels_bwd(const float* cls, const int64_t* labe
   if (nb == 0) return 0;
   const float* g_cls = g_sums; const float* g_bbox = g_sums + nlevels;
   const float* g_noR = g_noR_rows ? g_noR_rows : g_sums + 2 * nlevels;
-  const float g_noR_scalar = 0.f; const int g_noR_is_scalar = g_noR_rows ? 0 : 1, g_lstride = 1;
+  const float g_noR_scalar = 0.f; const int g_noR_is_scalar = g_noR_rows ? 0 : 1, g_lstride = 1, nlv_ = nlevels;
+  const float* const g_div = divisors;
   if (out_bf16) { if (C <= 24) AOD_EDL_BWD(true, 1); else AOD_EDL_BWD(true, 4); }
   else { if (C <= 24) AOD_EDL_BWD(false, 1); else AOD_EDL_BWD(false, 4); }
 #undef AOD_EDL_BWD
@@ -428,7 +457,8 @@ extern "C" int aod_meh_loss_levels_fwd(const float* lam, const float* loss_noR, 
   LossLevels lv; long long tot;
   const int nb = fill_levels(lv, nlevels, level_rows, 256, tot);
   if (nb) hipLaunchKernelGGL(meh_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lam, loss_noR, bbox_w4, lv, partials);
-  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 1, out_sums, 1, nlevels);
+  hipLaunchKernelGGL(reduce_partials_levels_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, partials, lv, 1, out_sums, 1, nlevels, (const int*)nullptr,
+                     0, (float*)nullptr, (float*)nullptr);
   AOD_LAUNCH_CHECK();
   return 0;
 }

@@ -1196,9 +1196,12 @@ class PackedLosses(list):
     (SSL_Lambda.py:126-154) -- a list -- plus `.packed`: ONE device vector whose sum is the sum of the per-level means the reference
     forms with a `.mean()` and an add per level.  `_parse_losses` sums the vector (one launch, and one in backward) instead."""
 
-    def __init__(self, items, packed):
+    def __init__(self, items, packed, group=None):
         super().__init__(items)
         self.packed = packed
+        # (matrix, row): `packed` is row `row` of a matrix whose rows are the packed vectors of several loss names (the level-fused loss launch
+        # returns loss_cls / loss_bbox / loss_noR as one [3, L] tensor): `_parse_losses` then sums the matrix once instead of row by row
+        self.group = group
 
 
 class GradArena:
@@ -1301,27 +1304,39 @@ class RetinaLossLevelsFn(Function):
     [all rows]).  Same blocks, same summation orders as the per-level launches: identical bits (tests/test_gpu_kernels.py)."""
 
     @staticmethod
-    def forward(ctx, cls_rows, box_rows, labels, label_w, bbox_t, bbox_w, gamma, alpha, level_rows, shapes):
+    def forward(ctx, cls_rows, box_rows, labels, label_w, bbox_t, bbox_w, gamma, alpha, level_rows, shapes, num_pos=None):
+        """num_pos (int32 [B], the assigner's per-image positive counts): the sums come back divided -- rows 0, 1 by num_total_samples =
+        sum_b max(num_pos[b], 1), row 2 by the level's row count (L_anchor_head.py:266-288,300-303; SSL_Lambda.py:136-141) -- and
+        num_total_samples as a third output; the clamp / sum / cast / cat / divide launches of the tensor form are inside the reduction."""
         ctx.set_materialize_grads(False)
-        noR, sums = ho.edl_focal_l1_levels_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, gamma, alpha)
-        ctx.save_for_backward(cls_rows, box_rows, labels, label_w, bbox_t, bbox_w)
+        div = nt = None
+        if num_pos is None:
+            noR, sums = ho.edl_focal_l1_levels_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, gamma, alpha)
+        else:
+            noR, sums, div, nt = ho.edl_focal_l1_levels_fwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, gamma, alpha, num_pos)
+        ctx.save_for_backward(cls_rows, box_rows, labels, label_w, bbox_t, bbox_w, div)
         ctx.cfg = (gamma, alpha, tuple(level_rows), shapes)
-        return sums, noR
+        if nt is None:
+            return sums, noR
+        nt = nt.view(())
+        ctx.mark_non_differentiable(nt)
+        return sums, noR, nt
 
     @staticmethod
-    def backward(ctx, g_sums, g_noR):
-        cls_rows, box_rows, labels, label_w, bbox_t, bbox_w = ctx.saved_tensors
+    def backward(ctx, g_sums, g_noR, g_nt=None):
+        cls_rows, box_rows, labels, label_w, bbox_t, bbox_w, div = ctx.saved_tensors
         gamma, alpha, level_rows, (A, AC, A4) = ctx.cfg
         dev = cls_rows.device
         L = len(level_rows)
         g_sums = torch.zeros(3, L, device=dev) if g_sums is None else g_sums.float().contiguous()
         g_rows = None
         if g_noR is not None:              # (nobody on the training path differentiates the rows: train_step detaches them)
-            g_rows = (g_noR.float() + torch.repeat_interleave(g_sums[2], torch.tensor(level_rows, device=dev))).contiguous()
+            g2 = g_sums[2] if div is None else g_sums[2] / div[2]
+            g_rows = (g_noR.float() + torch.repeat_interleave(g2, torch.tensor(level_rows, device=dev))).contiguous()
         gc = torch.empty(cls_rows.shape[0] // A, AC, dtype=torch.float32, device=dev)
         gb = torch.empty(cls_rows.shape[0] // A, A4, dtype=torch.float32, device=dev)
-        ho.edl_focal_l1_levels_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, g_sums, g_rows, gc, gb, A, gamma, alpha)
-        return gc.view(cls_rows.shape), gb.view(box_rows.shape), None, None, None, None, None, None, None, None
+        ho.edl_focal_l1_levels_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, g_sums, g_rows, gc, gb, A, gamma, alpha, divisors=div)
+        return gc.view(cls_rows.shape), gb.view(box_rows.shape), None, None, None, None, None, None, None, None, None
 
 
 class MEHLossLevelsFn(Function):

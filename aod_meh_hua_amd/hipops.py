@@ -698,24 +698,31 @@ def _level_rows(rows):
     return (C.c_int64 * len(rows))(*[int(r) for r in rows])
 
 
-def edl_focal_l1_levels_fwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, level_rows, gamma=2.0, alpha=0.25):
+def edl_focal_l1_levels_fwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, level_rows, gamma=2.0, alpha=0.25, num_pos=None):
     """All pyramid levels in one launch: cls [rows, C] fp32 with level l = rows [sum(level_rows[:l]), +level_rows[l]).  Returns
-    (loss_noR [rows], sums [3, L]) -- bit-identical to L calls of edl_focal_l1_fwd on the level slices."""
+    (loss_noR [rows], sums [3, L]) -- bit-identical to L calls of edl_focal_l1_fwd on the level slices.  With num_pos (int32 [B], the
+    assigner's per-image positive counts): (loss_noR, sums / divisors, divisors [3, L], num_total_samples [1])."""
     rows, Cc = cls.shape
     L = len(level_rows)
     assert sum(level_rows) == rows
     lr = _level_rows(level_rows)
     loss_noR = torch.empty(rows, dtype=torch.float32, device=cls.device)
     sums = torch.empty(3, L, dtype=torch.float32, device=cls.device)
+    div = nt = None
+    if num_pos is not None:
+        assert num_pos.dtype == torch.int32 and num_pos.is_contiguous()
+        div = torch.empty(3, L, dtype=torch.float32, device=cls.device)
+        nt = torch.empty(1, dtype=torch.float32, device=cls.device)
     part = torch.empty(max(int(_C.lib.aod_loss_levels_partials_len(L, lr)), 1), dtype=torch.float32, device=cls.device)
     prof_bytes('edl_l1_fwd', rows * (Cc * 4 + 8 + 4 + (48 if bbox_pred is not None else 0) + 4),
                lambda: call('aod_edl_focal_l1_levels_fwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), L, lr, Cc,
-                            gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), stream()))
-    return loss_noR, sums
+                            gamma, alpha, ptr(loss_noR), ptr(sums), ptr(part), ptr(num_pos), 0 if num_pos is None else int(num_pos.numel()), ptr(div),
+                            ptr(nt), stream()))
+    return (loss_noR, sums) if num_pos is None else (loss_noR, sums, div, nt)
 
 
 def edl_focal_l1_levels_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, level_rows, g_sums, g_noR_rows, grad_cls, grad_bbox, A,
-                            gamma=2.0, alpha=0.25):
+                            gamma=2.0, alpha=0.25, divisors=None):
     """g_sums [3, L] fp32 contiguous; gradients are written into grad_cls [rows / A, A * C] / grad_bbox [rows / A, A * 4] (fp32, unpadded)."""
     rows, Cc = cls.shape
     L = len(level_rows)
@@ -723,7 +730,7 @@ def edl_focal_l1_levels_bwd(cls, labels, label_w, bbox_pred, bbox_tgt, bbox_w, l
     assert g_sums.shape == (3, L) and g_sums.is_contiguous() and g_sums.dtype == torch.float32
     prof_bytes('edl_l1_bwd', rows * (Cc * 4 + 8 + 4 + (4 if g_noR_rows is not None else 0) + Cc * 4 + ((48 + 16) if bbox_pred is not None else 0)),
                lambda: call('aod_edl_focal_l1_levels_bwd', ptr(cls), ptr(labels), ptr(label_w), ptr(bbox_pred), ptr(bbox_tgt), ptr(bbox_w), L, lr, Cc,
-                            gamma, alpha, ptr(g_sums), ptr(g_noR_rows), ptr(grad_cls), ptr(grad_bbox), 0, A, A * Cc, A * 4, stream()))
+                            gamma, alpha, ptr(g_sums), ptr(divisors), ptr(g_noR_rows), ptr(grad_cls), ptr(grad_bbox), 0, A, A * Cc, A * 4, stream()))
     return grad_cls, grad_bbox
 
 

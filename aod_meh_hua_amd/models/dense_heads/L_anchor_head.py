@@ -103,7 +103,7 @@ class L_AnchorHead(BaseModule):
         valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, m['pad_shape'], device) for m in img_metas]
         return anchor_list, valid_flag_list
 
-    def get_targets_batch(self, featmap_sizes, img_metas, gt_bboxes, gt_labels, device):
+    def get_targets_batch(self, featmap_sizes, img_metas, gt_bboxes, gt_labels, device, raw_num_pos=False):
         """get_targets + _get_targets_single (L_anchor_head.py:155-257) for the whole batch on the GPU.
         Returns per-level lists (labels [B,A_l], label_weights, bbox_targets [B,A_l,4], bbox_weights),
         num_total_pos (0-d device tensor = sum_b max(#pos_b, 1)), num_level_anchors."""
@@ -141,6 +141,8 @@ class L_AnchorHead(BaseModule):
             s, e = starts[l] * B, starts[l + 1] * B
             labels_l.append(lab_f[s:e].view(B, n)), lw_l.append(lw_f[s:e].view(B, n))
             bt_l.append(bt_f[s:e].view(B, n, 4)), bw_l.append(bw_f[s:e].view(B, n, 4))
+        if raw_num_pos:         # (the level-fused loss launch forms num_total_samples itself)
+            return labels_l, lw_l, bt_l, bw_l, num_pos, nla
         num_total_pos = num_pos.clamp(min=1).sum().float()
         return labels_l, lw_l, bt_l, bw_l, num_total_pos, nla
 
@@ -158,23 +160,28 @@ class L_AnchorHead(BaseModule):
         featmap_sizes = [tuple(f.shape[-2:]) for f in cls_scores]
         assert len(featmap_sizes) == self.anchor_generator.num_levels
         device = cls_scores[0].device
-        labels_list, lw_list, bt_list, bw_list, num_total_pos, nla = self.get_targets_batch(featmap_sizes, img_metas, gt_bboxes, gt_labels, device)
+        want_fused = False
+        if self._can_defer_avg:
+            from ... import functional as AF
+            want_fused = AF.LOSS_LEVELS
+        labels_list, lw_list, bt_list, bw_list, num_pos, nla = self.get_targets_batch(featmap_sizes, img_metas, gt_bboxes, gt_labels, device,
+                                                                                      raw_num_pos=True)
         assert not self.sampling
-        num_total_samples = num_total_pos
+        fused = None
+        if want_fused:                      # (heads on the HIP loss kernels)
+            # every level in ONE launch per pass when the levels are adjacent row ranges of their buffers (they are: level-batched prediction
+            # convs, level-major targets); the per-level loss terms [3, L] -- already divided by num_total_samples / the level's row count --
+            # and the per-level loss_noR rows come back bit-identical to the per-level launches followed by the tensor divisions
+            fused = self.loss_all_levels(cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, num_pos=num_pos, **kwargs)
+        num_total_samples = fused[2] if fused is not None else num_pos.clamp(min=1).sum().float()
         B = cls_scores[0].shape[0]
         mlvl = self.anchor_generator.grid_anchors(featmap_sizes, device)
         all_anchor_list = [a[None].expand(B, a.shape[0], 4) for a in mlvl]
         head_info = ['cls_scores', 'bbox_preds', 'all_anchor_list', 'labels_list', 'label_weights_list', 'bbox_targets_list',
                      'bbox_weights_list', 'num_total_samples']
         head_out = (head_info, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list, num_total_samples)
-        fused = None
-        if self._can_defer_avg:             # (heads on the HIP loss kernels)
-            from ... import functional as AF
-            # every level in ONE launch per pass when the levels are adjacent row ranges of their buffers (they are: level-batched prediction
-            # convs, level-major targets); sums [3, L] and the per-level loss_noR rows come back bit-identical to the per-level launches
-            fused = self.loss_all_levels(cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, **kwargs) if AF.LOSS_LEVELS else None
-            if fused is None:               # one gradient buffer per prediction conv, a row range per level
-                kwargs = dict(kwargs, grad_arena=AF.GradArena([c.shape[0] * c.shape[2] * c.shape[3] for c in cls_scores]))
+        if self._can_defer_avg and fused is None:               # one gradient buffer per prediction conv, a row range per level
+            kwargs = dict(kwargs, grad_arena=AF.GradArena([c.shape[0] * c.shape[2] * c.shape[3] for c in cls_scores]))
         if fused is None:
             outs = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list, lw_list, bt_list, bw_list,
                                list(range(len(cls_scores))), num_total_samples=num_total_samples, featmap_sizes=featmap_sizes,
@@ -186,11 +193,11 @@ class L_AnchorHead(BaseModule):
             # instead of ten divisions and five row reductions -- and as many fewer in backward
             from ... import functional as AF
             if fused is not None:
-                S, losses_noR = fused
-                L = S.shape[1]
-            else:
-                L = len(losses_cls)
-                S = torch.stack(list(losses_cls) + list(losses_bbox) + list(outs[3])).view(3, L)
+                Q, losses_noR = fused[0], fused[1]
+                return dict(loss_cls=AF.PackedLosses(Q[0].unbind(0), Q[0], group=(Q, 0)), loss_bbox=AF.PackedLosses(Q[1].unbind(0), Q[1], group=(Q, 1)),
+                            loss_noR=AF.PackedLosses(losses_noR, Q[2], group=(Q, 2))), head_out
+            L = len(losses_cls)
+            S = torch.stack(list(losses_cls) + list(losses_bbox) + list(outs[3])).view(3, L)
             counts = self._level_counts([int(t.numel()) for t in losses_noR], S.device)
             D = torch.cat([num_total_samples.reshape(1).expand(2 * L), counts]).view(3, L)
             Q = S / D

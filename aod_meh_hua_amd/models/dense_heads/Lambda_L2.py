@@ -126,9 +126,11 @@ class Lambda_L2Net(L_AnchorHead):
         loss_bbox = scaled(wb, sum_box) / num_total_samples
         return loss_cls, loss_bbox, scaled(wc, loss_noR)
 
-    def loss_all_levels(self, cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, **kwargs):
+    def loss_all_levels(self, cls_scores, bbox_preds, labels_list, lw_list, bt_list, bw_list, num_pos=None, **kwargs):
         """loss_single (Lambda_L2.py:105-121) for every level in one launch per pass: (sums [3, L] = per-level (sum l*w, sum |d|*bw, sum l),
-        [loss_noR rows per level]) or None when the levels are not adjacent row ranges / the loss weights are not 1 (then: per level)."""
+        [loss_noR rows per level]) or None when the levels are not adjacent row ranges / the loss weights are not 1 (then: per level).
+        With num_pos (the assigner's per-image positive counts): (Q [3, L] = the per-level loss terms -- sums divided by num_total_samples /
+        the level's row count --, rows, num_total_samples)."""
         if not (kwargs.get('Labeled', True) and not kwargs.get('Pseudo', False)):
             raise NotImplementedError('pseudo-label branch (Lambda_L2.py:122-232) is dead code in the reference driver')
         if self.loss_cls.loss_weight != 1.0 or self.loss_bbox.loss_weight != 1.0:
@@ -141,10 +143,10 @@ class Lambda_L2Net(L_AnchorHead):
             return None
         A = cls_d.shape[1] // C
         level_rows = [c.shape[0] * c.shape[2] * c.shape[3] * A for c in cls_scores]
-        sums, noR = AF.RetinaLossLevelsFn.apply(cls_d.view(-1, C), box_d.view(-1, 4), flat[0], flat[1], flat[2], flat[3],
-                                                float(self.loss_cls.gamma), float(self.loss_cls.alpha), level_rows,
-                                                (A, cls_d.shape[1], box_d.shape[1]))
-        return sums, list(noR.split(level_rows))
+        out = AF.RetinaLossLevelsFn.apply(cls_d.view(-1, C), box_d.view(-1, 4), flat[0], flat[1], flat[2], flat[3],
+                                          float(self.loss_cls.gamma), float(self.loss_cls.alpha), level_rows,
+                                          (A, cls_d.shape[1], box_d.shape[1]), num_pos)
+        return (out[0], list(out[1].split(level_rows))) + tuple(out[2:])
 
     def loss_all_levels_L(self, L_scores, losses, bw_list, **kwargs):
         """loss_single_L (Lambda_L2.py:235-241) for every level in one launch per pass: the per-level sums [L], or None."""

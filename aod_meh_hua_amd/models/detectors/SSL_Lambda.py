@@ -64,8 +64,26 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
         log_vars = OrderedDict()
         # (.mean() of a 0-d tensor is the tensor itself, bit for bit; skipping it saves a reduce launch and its backward per level)
         mean = lambda t: t if t.dim() == 0 else t.mean()
+        # functional.PackedLosses whose vectors are the rows of ONE matrix (the level-fused loss launch hands back loss_cls / loss_bbox / loss_noR
+        # as a [3, L] tensor): one row-sum launch for all names, and -- when every loss term of this call is such a row -- the total as the sum of
+        # the row sums: 2 launches instead of 5 here and 2 instead of 14 in backward (three select-backward fills and copies, adds, ...)
+        groups = {}
         for loss_name, loss_value in losses.items():
-            if isinstance(loss_value, torch.Tensor):
+            g = getattr(loss_value, 'group', None)
+            if g is not None:
+                groups.setdefault(id(g[0]), [g[0], {}])[1][loss_name] = g[1]
+        row_sums, whole = {}, None
+        for mat, rows in groups.values():
+            if sorted(rows.values()) == list(range(mat.shape[0])):
+                lv = mat.sum(1)
+                for loss_name, r in rows.items():
+                    row_sums[loss_name] = lv[r]
+                if len(groups) == 1 and len(rows) == len(losses) and all('loss' in k for k in rows):
+                    whole = lv.sum()
+        for loss_name, loss_value in losses.items():
+            if loss_name in row_sums:
+                log_vars[loss_name] = row_sums[loss_name]
+            elif isinstance(loss_value, torch.Tensor):
                 log_vars[loss_name] = mean(loss_value)
             elif getattr(loss_value, 'packed', None) is not None:
                 log_vars[loss_name] = loss_value.packed.sum()        # functional.PackedLosses: the per-level means in one vector
@@ -78,9 +96,12 @@ class SSLBase_L_Detector(BaseModule, metaclass=ABCMeta):
             else:
                 raise TypeError(f'{loss_name} is not a tensor or list of tensors')
         terms = [_value for _key, _value in log_vars.items() if 'loss' in _key]
-        loss = terms[0]
-        for _value in terms[1:]:           # (sum() would start from the int 0: one more launch)
-            loss = loss + _value
+        if whole is not None:
+            loss = whole
+        else:
+            loss = terms[0]
+            for _value in terms[1:]:           # (sum() would start from the int 0: one more launch)
+                loss = loss + _value
         for loss_name, loss_value in log_vars.items():
             log_vars[loss_name] = loss_value.detach()
         return loss, log_vars

@@ -318,17 +318,22 @@ int aod_meh_loss_bwd(const float* lam, const float* loss_noR, const float* bbox_
  * aod_max_iou_assign produce); level_rows: HOST array of nlevels <= 8 row counts.  Blocks never straddle a level and every sum runs in the
  * order of a per-level call: loss_noR, the sums and the gradients are bit-identical to nlevels separate calls.
  *   sums [3][nlevels]  (written, not accumulated): row 0 = sum(l*w), row 1 = sum(|p-t|*bw), row 2 = sum(loss_noR) of each level
- *   g_sums [3][nlevels]: their gradients (device); g_noR_rows: optional per-row gradient of loss_noR, then used INSTEAD of row 2
+ *   num_pos (optional, device int32 [num_images], aod_max_iou_assign's per-image positive counts): the sums are then DIVIDED in place --
+ *     rows 0, 1 by num_total_samples = sum_b max(num_pos[b], 1) (L_anchor_head.py:300-303, what loss_single divides by at :266-288), row 2 by
+ *     the level's row count (the mean of SSL_Lambda.py:136-141) -- with IEEE divisions; divisors [3][nlevels] and num_total [1] are written
+ *   g_sums [3][nlevels]: their gradients (device) -- of the divided sums when the forward's `divisors` are passed (else NULL);
+ *   g_noR_rows: optional per-row gradient of loss_noR, then used INSTEAD of row 2
  *   out_sums [nlevels] / g [nlevels]: the MEH sums and their gradients.  partials: >= aod_loss_levels_partials_len floats. */
 size_t aod_loss_levels_partials_len(int nlevels, const int64_t* level_rows);
 int aod_edl_focal_l1_levels_fwd(const float* cls, const int64_t* labels, const float* label_w,
                                 const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
                                 int nlevels, const int64_t* level_rows, int C, float gamma, float alpha,
-                                float* loss_noR, float* sums, float* partials, aod_stream_t stream);
+                                float* loss_noR, float* sums, float* partials, const int32_t* num_pos, int num_images,
+                                float* divisors, float* num_total, aod_stream_t stream);
 int aod_edl_focal_l1_levels_bwd(const float* cls, const int64_t* labels, const float* label_w,
                                 const float* bbox_pred, const float* bbox_tgt, const float* bbox_w,
                                 int nlevels, const int64_t* level_rows, int C, float gamma, float alpha,
-                                const float* g_sums, const float* g_noR_rows, void* grad_cls, void* grad_bbox, int out_bf16,
+                                const float* g_sums, const float* divisors, const float* g_noR_rows, void* grad_cls, void* grad_bbox, int out_bf16,
                                 int A, int pitch_cls, int pitch_box, aod_stream_t stream);
 int aod_meh_loss_levels_fwd(const float* lam, const float* loss_noR, const float* bbox_w4, int nlevels, const int64_t* level_rows,
                             float* out_sums, float* partials, aod_stream_t stream);

@@ -42,6 +42,19 @@ def test_level_fused_loss_launches_equal_the_per_level_launches(C, A, pixels):
                                                  g_sums[1, l:l + 1].contiguous(), gn, 0.0, g_noR_is_scalar=g_rows is None, A=A)
                 assert torch.equal(gc[r // A:(r + n) // A], gc_l) and torch.equal(gb[r // A:(r + n) // A], gb_l), l
             r += n
+    # the divided form: Q = sums / (num_total_samples | level rows) inside the reduction, g / divisor inside the backward kernel -- the IEEE
+    # quotients of the tensor divisions they replace (L_anchor_head.py:266-288,300-303; SSL_Lambda.py:136-141)
+    num_pos = torch.tensor([3, 0, 17, 1], dtype=torch.int32, device='cuda')
+    if all(rows):
+        noR2, Q, D, nt = ho.edl_focal_l1_levels_fwd(cls, labels, lw, bp, bt, bw, rows, num_pos=num_pos)
+        assert float(nt) == 22.0 and torch.equal(noR2, noR)
+        Dref = torch.tensor([[22.0] * L, [22.0] * L, [float(n) for n in rows]], device='cuda')
+        assert torch.equal(D, Dref) and torch.equal(Q, sums / Dref)
+        gc1, gb1 = torch.empty(R // A, A * C, device='cuda'), torch.empty(R // A, A * 4, device='cuda')
+        gc2, gb2 = torch.empty_like(gc1), torch.empty_like(gb1)
+        ho.edl_focal_l1_levels_bwd(cls, labels, lw, bp, bt, bw, rows, g_sums, None, gc1, gb1, A, divisors=D)
+        ho.edl_focal_l1_levels_bwd(cls, labels, lw, bp, bt, bw, rows, (g_sums / D).contiguous(), None, gc2, gb2, A)
+        assert torch.equal(gc1, gc2) and torch.equal(gb1, gb2)
     # MEH loss: lam per anchor row, weights = column 0 of bbox_w
     lam = rnd(R).abs()
     out = ho.meh_loss_levels_fwd(lam, noR, bw, rows)
@@ -101,7 +114,9 @@ def test_train_iteration_with_level_fused_losses_equals_the_per_level_form(monke
     finally:
         ho.set_deterministic(False)
     a, b = res[True], res[False]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]), (a[0], b[0], a[3], b[3])
+    # (the total is sum(row sums of the [3, L] term matrix) in the fused form, (cls + bbox) + noR of per-name sums otherwise: last-bit differences)
+    assert abs(float(a[0]) - float(b[0])) <= 2e-7 * abs(float(b[0])) and torch.equal(a[3], b[3]), (a[0], b[0], a[3], b[3])
+    assert a[1].keys() == b[1].keys() and all(abs(float(a[1][k]) - float(b[1][k])) <= 2e-7 * abs(float(b[1][k])) for k in a[1]), (a[1], b[1])
     assert len(a[2]) == len(b[2]) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     for ga, gb_ in ((a[4], b[4]), (a[5], b[5])):
         assert ga.keys() == gb_.keys() and len(ga) >= 10
