@@ -397,11 +397,13 @@ SLAB_WGRAD = os.environ.get('AOD_WGRAD_SLABS', '1') != '0'      # debug switch: 
 
 
 def _slab_scratch(n, device):
-    """Per-device scratch for the wgrad slabs (at most 512 workgroups x 64 KB = 33.5 MB per launch); need not be initialised."""
-    buf = _SLABS.get(device)
+    """Scratch for the wgrad slabs (at most 512 workgroups x 64 KB = 33.5 MB per launch), one per (device, stream): a launch and the unpack
+    that reads its slabs are ordered by their stream, launches of two streams must not share one; need not be initialised."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SLABS.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, (1 << 23) + (1 << 21)), dtype=torch.float32, device=device)
-        _SLABS[device] = buf
+        _SLABS[key] = buf
     return buf[:n]
 
 
