@@ -13,8 +13,6 @@ Both keep STATIC input buffers (image batch, packed ground truth, image ids); a 
 captured code obeys: no host<->device copies, no `.item()`, every accumulator is zeroed inside the graph, learning rates live in device
 memory (FusedSGD.device_lr), and after a replay the versions of the updated parameters are bumped so that eager code (evaluation,
 checkpoints) rebuilds its packed weights."""
-import os
-
 import torch
 
 from . import functional as AF
@@ -55,9 +53,6 @@ def _plain(data, dev):
             return d[0] if isinstance(d, list) and len(d) == 1 else d
         return x
     return {k: un(v) for k, v in data.items()}
-
-
-MEH_OVERLAP = os.environ.get('AOD_MEH_OVERLAP', '0') == '1'      # (experimental) the MEH step on a second stream beside the main backward pass
 
 
 class GraphedTrainStep:
@@ -141,21 +136,7 @@ class GraphedTrainStep:
             out, head_out, feat_out, prev = self.module.train_step(data, **self.kw)
         self.opt.zero_grad()
         self.cur['live'] = (out, head_out, feat_out, prev)
-        self.cur['b_done'] = False
-        if MEH_OVERLAP and not cuts:
-            # the MEH step only reads detached features / loss rows and its own parameters (see _seg_b): enqueued on a second stream BEFORE the main
-            # backward pass, its launches run beside that pass's latency-bound backbone layers instead of after them
-            main = torch.cuda.current_stream()
-            side = self.cur.get('side') or torch.cuda.Stream()
-            self.cur['side'] = side
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._seg_b()
-            self.cur['b_done'] = True
-            out['loss'].backward()
-            main.wait_stream(side)
-        else:
-            out['loss'].backward()          # (with cuts: segment 0 -- heads and neck; it ends at the cut copies)
+        out['loss'].backward()          # (with cuts: segment 0 -- heads and neck; it ends at the cut copies)
         # every 0-dim value the caller gets back, packed into ONE static vector inside the graph: a step then hands out copies with one
         # device copy per segment instead of one per log entry (~60 launches of 4 us each, serialised behind the replay)
         self.cur['pack'] = torch.stack([out['loss'].detach().float().reshape(())] + [v.detach().float().reshape(()) for v in out['log_vars'].values()])
@@ -172,9 +153,6 @@ class GraphedTrainStep:
     def _seg_b(self):
         # the MEH step only reads detached features / losses and its own parameters, so the main update (segment C) may follow it:
         # with data parallelism the main gradients' last all-reduce buckets then run under this whole segment
-        if self.cur.get('b_done'):
-            self.cur['b_done'] = False
-            return
         out, head_out, feat_out, prev = self.cur['live']
         loss_L = self.module.train_step_L(prev, head_out, feat_out, **self.kw)
         self.opt_L.zero_grad()
