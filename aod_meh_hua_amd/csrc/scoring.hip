@@ -474,9 +474,11 @@ constexpr int TR = 1024;  // tranche of candidates sorted at a time (max_num <= 
 __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n, int C, float score_thr,
                                                  float iou_thr, int max_num, float* __restrict__ dets, long long* __restrict__ det_labels,
                                                  long long* __restrict__ keep, int* __restrict__ num_det, int* __restrict__ ws_vflat, int kcache_n) {
-  // sort keys of the first kcache_n valid entries, built while they are compacted: the radix-select passes and the gathers then read LDS
-  // instead of two dependent global loads per key (vflat -> score); entries beyond the cache take the global path
-  extern __shared__ unsigned long long kcache[];
+  // score bits of the first kcache_n valid entries, kept while they are compacted (the low word of a sort key is a function of the entry's
+  // position): the radix-select passes and the gathers then read LDS instead of two dependent global loads per key (vflat -> score);
+  // entries beyond the cache take the global path.  (As 64-bit keys only 12 288 entries fitted and half of the bench pool's 25 k valid
+  // entries per image took the global path: radix select 38 -> 25 us.)
+  extern __shared__ unsigned scache[];
   __shared__ int hist[264];
   __shared__ int s_warp[TB / 64];
   __shared__ unsigned long long keys[TR];
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
         for (int cl = 0; cl < 24; ++cl)
           if ((vm >> cl) & 1u) {
             vflat[pos] = cand * C + cl;
-            if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(sv[cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+            if (pos < kcache_n) scache[pos] = __float_as_uint(sv[cl]);
             ++pos;
           }
       } else {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
           const float v = srow[cl];
           if (v > score_thr) {
             vflat[pos] = cand * C + cl;
-            if (pos < kcache_n) kcache[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pos);
+            if (pos < kcache_n) scache[pos] = __float_as_uint(v);
             ++pos;
           }
         }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(TB) void nms_kernel(const float* __restrict__ boxes
   // boxes are clipped to >= 0 so the int ordering of the float bits is valid; guard the (never expected) negative case
   const float off_unit = s_maxc + 1.f;
   auto key = [&](long long pidx) {
-    if (pidx < kcache_n) return kcache[pidx];
+    if (pidx < kcache_n) return ((unsigned long long)scache[pidx] << 32) | (unsigned long long)(0xffffffffu - (unsigned)pidx);
     const int f = vflat[pidx];
     const int cand = f / C, cl = f - cand * C;
     return ((unsigned long long)__float_as_uint(sc[(long long)cand * (C + 1) + cl]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)pidx);
@@ -676,14 +678,14 @@ extern "C" int aod_multiclass_nms(const float* boxes, const float* scores, int B
   if (B == 0) return 0;
   AOD_CHECK_ARG(boxes && scores && dets && det_labels && keep && num_det && ws, "nms: null pointer");
   AOD_CHECK_ARG(max_num >= 1 && max_num <= 256 && C >= 1, "nms: max_num must be in 1..256");
-  // key cache: up to 12 288 valid (candidate, class) entries per image (96 KB of LDS beside the 16 KB of static arrays)
+  // score cache: up to 28 672 valid (candidate, class) entries per image (112 KB of LDS beside the 36 KB of static arrays)
   const long long nc = (long long)n * C;
-  const int kcache_n = (int)(nc < 12288 ? nc : 12288);
+  const int kcache_n = (int)(nc < 28672 ? nc : 28672);
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 28672 * 4);
   }
-  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), (size_t)kcache_n * 8, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(TB), (size_t)kcache_n * 4, (hipStream_t)stream, boxes, scores, n, C, score_thr, iou_thr, max_num, dets,
                      (long long*)det_labels, (long long*)keep, num_det, (int*)ws, kcache_n);
   AOD_LAUNCH_CHECK();
   return 0;

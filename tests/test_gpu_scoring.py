@@ -257,3 +257,47 @@ def test_merged_level_launches_equal_the_per_level_chain(monkeypatch, B, H, W, h
     for x, y in zip(a.rowmax, b.rowmax):
         assert torch.equal(x, y)
     assert torch.equal(a.max_conf(), b.max_conf())
+
+
+@pytest.mark.parametrize('C,max_num', [(20, 100), (3, 100), (1, 200), (80, 100)])
+def test_nms_stress_images_vs_oracle(run, C, max_num):
+    """nms_kernel (tranches of 1 024 sorted candidates, greedy scan 64 candidates per round, stop at max_num) against the oracle's statement of
+    mmcv's sequential rule (bbox_nms.py:7-93 -> batched_nms) on images that stress it: heavy overlap (several sort tranches, the cut in the
+    middle of one), no overlap at all (the first max_num by score), fewer valid entries than max_num, one class keeping more than 64
+    candidates, exact score ties, tight clusters; 1 / 3 / 20 / 80 classes (the 80-class image has 112 000 entries, 4x the LDS score cache)."""
+    sc = run['scoring']
+    g = synth.gen(1234 + C)
+    n = 1400
+    imgs = []
+    for kind in ('dense', 'sparse', 'few', 'oneclass', 'ties', 'clusters'):
+        if kind == 'dense':
+            xy = torch.rand(n, 2, generator=g) * 40
+            wh = torch.rand(n, 2, generator=g) * 30 + 10
+        elif kind == 'clusters':
+            ctr = torch.rand(12, 2, generator=g) * 400
+            xy = ctr[torch.randint(0, 12, (n,), generator=g)] + torch.rand(n, 2, generator=g) * 6
+            wh = torch.rand(n, 2, generator=g) * 4 + 20
+        else:
+            xy = torch.rand(n, 2, generator=g) * 4000
+            wh = torch.rand(n, 2, generator=g) * 10 + 2
+        boxes = torch.cat([xy, xy + wh], -1)
+        scores = torch.rand(n, C + 1, generator=g) * 0.9 + 0.051
+        if kind == 'few':
+            scores = scores * 0.01
+            scores[torch.randint(0, n, (37,), generator=g), torch.randint(0, C, (37,), generator=g)] = 0.5
+        if kind == 'oneclass':
+            scores[:, 1:] = 0.01
+        if kind == 'ties':
+            scores = (scores * 8).round() / 8 + 0.06
+        scores[:, -1] = 0
+        imgs.append((boxes, scores))
+    boxes = torch.stack([b for b, _ in imgs]); scores = torch.stack([s for _, s in imgs])
+    d, lab, keep, num = sc.multiclass_nms_batch(boxes.cuda(), scores.cuda(), 0.05, 0.5, max_num)
+    for i, (b, s) in enumerate(imgs):
+        od, olab, okeep, _ = odetect.multiclass_nms(b, s, max_num=max_num)
+        nn = int(num[i])
+        assert nn == len(okeep), (i, nn, len(okeep))
+        assert np.array_equal(keep[i, :nn].cpu().numpy(), okeep.numpy()), i
+        assert np.array_equal(lab[i, :nn].cpu().numpy(), olab.numpy()), i
+        assert torch.equal(d[i, :nn].cpu(), od), i
+        assert bool((keep[i, nn:] == -1).all()) and bool((d[i, nn:] == 0).all())
