@@ -1281,7 +1281,11 @@ def dense_concat(tensors):
     end = t0.data_ptr()
     rows = 0
     for t in tensors:
-        if not t.is_contiguous() or t.dtype != t0.dtype or tuple(t.shape[1:]) != tail or t.data_ptr() != end:
+        if t.dtype != t0.dtype or tuple(t.shape[1:]) != tail:
+            return None
+        if t.numel() == 0:               # (an empty level occupies no rows wherever it points)
+            continue
+        if not t.is_contiguous() or t.data_ptr() != end:
             return None
         end += t.numel() * t.element_size()
         rows += t.shape[0]

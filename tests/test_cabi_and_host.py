@@ -248,3 +248,56 @@ def test_head_tail_rounding_is_monotone_and_idempotent():
         assert bool((v[1:] >= v[:-1]).all())
         assert bool((f(v) == v).all())
         assert float(((v - u).abs() / u.abs()).max()) < 2 ** -16
+
+
+def test_dense_concat_recognises_adjacent_pyramid_levels_only():
+    """functional.dense_concat: the level-fused loss launches take the pyramid levels as ONE row range -- legal only when each level starts
+    where the previous one ends in the same buffer."""
+    import torch
+    from aod_meh_hua_amd import functional as AF
+    buf = torch.arange(40 * 6, dtype=torch.float32).view(40, 6)
+    lv = [buf[0:16], buf[16:16], buf[16:28], buf[28:40]]                      # (an empty level in the middle)
+    d = AF.dense_concat(lv)
+    assert d is not None and d.shape == (40, 6) and d.data_ptr() == buf.data_ptr() and torch.equal(d, buf)
+    d = AF.dense_concat([buf[4:16], buf[16:28]])                               # does not start at the buffer's first row
+    assert d.shape == (24, 6) and torch.equal(d, buf[4:28])
+    assert AF.dense_concat([buf[0:16], buf[20:28]]) is None                    # a gap
+    assert AF.dense_concat([buf[16:28], buf[0:16]]) is None                    # wrong order
+    assert AF.dense_concat([buf[0:16], buf[16:28].clone()]) is None            # another buffer
+    assert AF.dense_concat([buf[0:16], buf[16:28].double()]) is None           # another dtype
+    assert AF.dense_concat([buf[0:16, :3], buf[16:28, :3]]) is None            # not contiguous
+    flat = torch.arange(30)
+    assert torch.equal(AF.dense_concat([flat[0:10], flat[10:30]]), flat)
+
+
+def test_parse_losses_sums_a_shared_term_matrix_once():
+    """SSL_Lambda._parse_losses (SSL_Lambda.py:126-154) on functional.PackedLosses that are the rows of ONE [3, L] matrix (what the
+    level-fused loss launch returns): log_vars = the row sums, loss = their sum, gradient of every entry = 1; a loss outside the group or a
+    non-loss key falls back to the per-name sums."""
+    import torch
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.models.detectors.SSL_Lambda import SSLBase_L_Detector
+    parse = SSLBase_L_Detector._parse_losses
+    Q = torch.rand(3, 5, dtype=torch.float64, requires_grad=True)
+    mk = lambda: dict(loss_cls=AF.PackedLosses(Q[0].unbind(0), Q[0], group=(Q, 0)), loss_bbox=AF.PackedLosses(Q[1].unbind(0), Q[1], group=(Q, 1)),
+                      loss_noR=AF.PackedLosses([torch.zeros(7)] * 5, Q[2], group=(Q, 2)))
+    loss, lv = parse(None, mk())
+    assert list(lv) == ['loss_cls', 'loss_bbox', 'loss_noR']
+    assert torch.allclose(loss, Q.sum()) and all(torch.allclose(lv[k], Q[i].sum()) for i, k in enumerate(lv))
+    loss.backward()
+    assert torch.equal(Q.grad, torch.ones_like(Q))
+    assert not any(v.requires_grad for v in lv.values())
+    # a fourth loss outside the matrix, and an 'acc' entry that is not a loss term
+    Q.grad = None
+    extra = torch.tensor(2.5, dtype=torch.float64, requires_grad=True)
+    losses = mk()
+    losses['loss_L'] = [extra * 1.0, extra * 2.0]
+    losses['acc'] = torch.tensor([1.0, 3.0], dtype=torch.float64)
+    loss, lv = parse(None, losses)
+    assert torch.allclose(loss, Q.sum() + 3.0 * extra) and float(lv['acc']) == 2.0
+    loss.backward()
+    assert torch.equal(Q.grad, torch.ones_like(Q)) and float(extra.grad) == 3.0
+    # ungrouped PackedLosses keep the per-name sum
+    P = torch.rand(4, dtype=torch.float64, requires_grad=True)
+    loss, lv = parse(None, dict(loss_L=AF.PackedLosses(P.unbind(0), P)))
+    assert torch.allclose(loss, P.sum())
