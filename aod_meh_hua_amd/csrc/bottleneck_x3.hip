@@ -33,6 +33,7 @@ struct Bnx3Args {
   const bf16_t* wd; const float* sd; const float* bd;      // DS form: X filter [256][128] and folded BN of the downsample conv
   bf16_t* y;             // X rows [B*H*W][512]
   int B, H, W, CP, tiles_y, tiles_x;      // CP = 2 * Cin: physical width of x
+  int st3;                                // phase 1 on three stages (AOD_B64X3_ST3=0: two)
 };
 
 constexpr int TH = 8, TW = 16, HW_ = 18, HPIX = (TH + 2) * HW_;      // 180 halo pixels
@@ -136,15 +137,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   unsigned w1off = (unsigned)(((8 * uw + drow) * p.CP + kcw * 8) * 2);
   const int nk1 = p.CP >> 6;
+  // THREE stages in flight (a K-step is 36 MFMAs per SIMD, a quarter of a memory round trip: with two stages every step waited for its
+  // loads): stages 0 and 1 where they always were, stage 2 in the t1 region, which is written only after the last K-step
+  auto xstage = [&](int buf) -> char* { return smem + (buf < 2 ? buf * XBUF : OFF_T1); };
+  auto wstage = [&](int buf) -> char* { return smem + (buf < 2 ? OFF_W1 + buf * 8192 : OFF_T1 + XBUF); };
+  static_assert(OFF_T1 + XBUF + 8192 <= OFF_VEC, "third phase-1 stage inside the t1 region");
   auto issue1 = [&](int buf) {          // 3 x-halo instructions + 1 filter instruction per wave and stage
-    char* xs = smem + buf * XBUF;
+    char* xs = xstage(buf);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const unsigned off = xoff[i];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(xs + (uw + 8 * i) * 1024), 16, off, 0, 0, 0);
       xoff[i] += 128;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(smem + OFF_W1 + buf * 8192 + uw * 1024), 16, w1off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(wstage(buf) + uw * 1024), 16, w1off, 0, 0, 0);
     w1off += 128;
   };
   const bool two = uw < 4;                // 12 pixel blocks over 8 waves: waves 0-3 own blocks uw and uw + 8, waves 4-7 block uw
@@ -153,15 +159,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nst = p.st3 ? 3 : 2;
   issue1(0);
   if (nk1 > 1) issue1(1);
+  if (nst > 2 && nk1 > 2) issue1(2);
+  int buf = 0;
   for (int kt = 0; kt < nk1; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk1) wait_vm<4>(); else wait_vm<0>();
+    // younger stages of this wave that may stay in flight (4 instructions each)
+    const int young = min(nk1 - 1 - kt, nst - 1);
+    if (young >= 2) wait_vm<8>(); else if (young == 1) wait_vm<4>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                 // every wave's part of stage kt has landed
     __builtin_amdgcn_sched_barrier(0);
-    const char* xs = smem + buf * XBUF;
-    const char* ws = smem + OFF_W1 + buf * 8192;
+    const char* xs = xstage(buf);
+    const char* ws = wstage(buf);
     bf16x8 wh[4], wl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -185,7 +195,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // every wave is done reading stage kt: its buffer can be refilled
-    if (kt + 2 < nk1) issue1(buf);
+    if (kt + nst < nk1) issue1(buf);
+    buf = buf == nst - 1 ? 0 : buf + 1;
   }
   // the stages are dead: conv2's first eight filter steps stream into the ring under epilogue 1 (step s = tap * 2 + channel group)
   const unsigned w2lane = (unsigned)(((8 * uw + drow) * (9 * 128) + kcw * 8) * 2);
@@ -430,6 +441,7 @@ static int launch_bnx3(const void* x, int Cin, int B, int H, int W, const void* 
   a.wd = (const bf16_t*)wd; a.sd = sd; a.bd = bd;
   a.B = B; a.H = H; a.W = W; a.CP = 2 * Cin;
   a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
+  { const char* e = getenv("AOD_B64X3_ST3"); a.st3 = (e && e[0] == '0') ? 0 : 1; }      // (read per call: tests switch it in-process)
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64x3_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -336,6 +336,14 @@ def test_x3_fused_bottleneck64_equals_the_three_launch_block(shape):
         f1 = _f(AF.as_rows(y1), B, H, W, 256)
         assert _err(f1, ref) < 1e-4, (cin, _err(f1, ref))
         assert torch.equal(y1, y0), (cin, float((AF.as_rows(y1).float() - AF.as_rows(y0).float()).abs().max()))
+        # phase 1 on two LDS stages instead of three (AOD_B64X3_ST3=0): the same K order, the same bits
+        os.environ['AOD_B64X3_ST3'] = '0'
+        try:
+            with torch.no_grad():
+                y3 = blk(xx)
+        finally:
+            os.environ.pop('AOD_B64X3_ST3', None)
+        assert torch.equal(y1, y3)
         if ds is not None:
             # the first block's downsample branch rides in the launch (aod_bottleneck64x3_ds_fwd); as a launch of its own: the same bits again
             assert AF.bottleneck64_ds_fused(blk, xx)
