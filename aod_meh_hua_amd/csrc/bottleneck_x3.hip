@@ -51,6 +51,12 @@ constexpr int W3SUB = 256 * 128;                       // conv3 filter: 2 sub-im
 static_assert(OFF_W1 + 2 * 8192 <= OFF_T1 && 8 * SLOT <= OFF_T1 && 2 * W3SUB <= OFF_T1 && 2 * T2SUB <= 2 * T1SUB && LDS_BYTES_DS <= 160 * 1024, "LDS map");
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#ifdef AOD_TILE_TIMING
+__device__ unsigned long long* g_b64_stamps = nullptr;      // debug build (tools/dbg/b64x3_timing.py): phase stamps of every tile, 100 MHz wall clock
+#define BSTAMP(k) do { if (g_b64_stamps && threadIdx.x == 0) g_b64_stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define BSTAMP(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const int t = threadIdx.x, lane = t & 63;
+  BSTAMP(0);
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int ntile = p.tiles_y * p.tiles_x;
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kt + nst < nk1) issue1(buf);
     buf = buf == nst - 1 ? 0 : buf + 1;
   }
+  BSTAMP(1);
   // the stages are dead: conv2's first eight filter steps stream into the ring under epilogue 1 (step s = tap * 2 + channel group)
   const unsigned w2lane = (unsigned)(((8 * uw + drow) * (9 * 128) + kcw * 8) * 2);
   auto issue2 = [&](int s) {              // one instruction per wave: rows 8 uw .. + 7 of the [64][128 B] slice of step s
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
+  BSTAMP(2);
   // ------------------------------------------------------------------ phase 2: t2 = relu(bn2(conv2(t1))); wave uw = output row uw of the tile
   f32x4 acc2[4];
 #pragma unroll
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else if (G == 3) issue3(1);                 // slots 4-7 (group 3 consumed): second channel group of the conv3 filter
     else issue3(0);                               // slots 0-3
   }
+  BSTAMP(3);
   // (issue order per wave: g2 x4 | g3 x4 | g4 x2 | w3[1] x4 | w3[0] x4 behind the prologue's g0 x4, g1 x4 -- the waits above count the
   // instructions younger than the group being consumed)
   {
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // t2 and the conv3 filter complete
   __builtin_amdgcn_sched_barrier(0);
+  BSTAMP(4);
 
   // ------------------------------------------------------------------ phase 3: y = relu(bn3(conv3(t2)) + res), 2 x 128 output channels
 #pragma unroll
@@ -423,10 +434,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), rsrc_y, (int)(prow + col + 64u), 0, 0);
     }
     if (half == 0) { if constexpr (DS) { __builtin_amdgcn_sched_barrier(0); load_xf(); } else load_res(1); }
+    BSTAMP(5 + half);
   }
+#ifdef AOD_TILE_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BSTAMP(7);
+#endif
 }
 
 }  // namespace
+
+#ifdef AOD_TILE_TIMING
+extern "C" int aod_dbg_set_b64_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_b64_stamps), &buf, sizeof(buf)); }
+#endif
 
 static int launch_bnx3(const void* x, int Cin, int B, int H, int W, const void* w1, const float* s1, const float* b1, const void* w2,
                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3, const void* res, const void* wd,
