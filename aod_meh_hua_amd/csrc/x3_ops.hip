@@ -306,10 +306,70 @@ __global__ __launch_bounds__(256) void x3_pad_cast_colsum_kernel(const float* __
     }
   }
 }
+// ... the same with 8 columns per thread (N % 4 == 0: the fp32 rows are 16-B aligned): two 16-B loads, a 16-B head and a 16-B tail store per
+// thread and row instead of eight 4-B loads and sixteen 2-B stores (retina_cls, 180 columns at 16 x 512^2: 80 -> 35 us).  Chunk c8 = columns
+// 8 c8 .. + 7 of a band of 32; a chunk that straddles N (176 .. 183 of 180) reads its valid half only.
+__global__ __launch_bounds__(256) void x3_pad_cast_colsum_v8_kernel(const float* __restrict__ g, const float* __restrict__ a, bf16_t* __restrict__ dz,
+                                                                    float* __restrict__ colsum, long long M, int N, int Np, int rows_per_block, int TC8,
+                                                                    float* __restrict__ cs_ws) {
+  __shared__ float red[256][9];
+  const int RP = 256 / TC8;
+  const int c8 = threadIdx.x % TC8, rl = threadIdx.x / TC8;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  const int c = c8 * 8;
+  const int col = ((c >> 5) << 6) + (c & 31);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < Np) {
+    const bool lo = c + 4 <= N, hi = c + 8 <= N;          // (N % 4 == 0: a half chunk is all valid or all pad)
+    for (long long m = r0 + rl; m < r1; m += RP) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (lo) v0 = *reinterpret_cast<const f32x4*>(g + m * N + c);
+      if (hi) v1 = *reinterpret_cast<const f32x4*>(g + m * N + c + 4);
+      if (a) {
+        if (lo) { const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + m * N + c);
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) if (!(a0[j] > 0.f)) v0[j] = 0.f; }
+        if (hi) { const f32x4 a1 = *reinterpret_cast<const f32x4*>(a + m * N + c + 4);
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) if (!(a1[j] > 0.f)) v1[j] = 0.f; }
+      }
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+      xstore(dz + m * 2 * Np + col, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int cc = threadIdx.x, q8 = cc >> 3, j = cc & 7;
+    float tsum = 0.f;
+    for (int r = 0; r < RP; ++r) tsum += red[r * TC8 + q8][j];
+    if (cs_ws) cs_ws[(long long)blockIdx.x * N + cc] = tsum;
+    else atomicAdd(colsum + cc, tsum);
+  }
+}
+
 extern "C" int aod_x3_pad_cast_colsum(const float* g, const float* relu_out_f32, void* dz, float* colsum, int64_t M, int N, aod_stream_t stream) {
   if (M == 0) return 0;
   AOD_CHECK_ARG(g && dz && colsum && N >= 1, "x3_pad_cast_colsum: bad args");
   const int Np = (N + 31) / 32 * 32;
+  if ((N & 3) == 0 && Np <= 256 && (((size_t)g | (size_t)(relu_out_f32 ? relu_out_f32 : g)) & 15) == 0) {
+    int tc8 = 4;                                   // chunks per row, a power of two (idle lanes past Np / 8)
+    while (tc8 * 8 < Np) tc8 <<= 1;
+    int rpb = (int)((M + 1023) / 1024);
+    if (rpb < 64) rpb = 64;
+    const int nb = (int)((M + rpb - 1) / rpb);
+    float* const cs_ws = aod_det_scratch((size_t)nb * N);
+    hipLaunchKernelGGL(x3_pad_cast_colsum_v8_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, relu_out_f32, (bf16_t*)dz, colsum, (long long)M, N, Np,
+                       rpb, tc8, cs_ws);
+    AOD_LAUNCH_CHECK();
+    if (cs_ws) return aod_colsum_finalize(cs_ws, nb, N, N, colsum, nullptr, 0, (hipStream_t)stream);
+    return 0;
+  }
   int rpb = (int)((M + 1023) / 1024);
   if (rpb < 16) rpb = 16;
   int tc = 32;

@@ -164,6 +164,13 @@ def test_x3_row_kernels_against_fp32():
         assert _err(ho.x3_merge(dzp, N), refg) < 2e-5 and _err(cs[:N], refg.sum(0)) < 1e-5
         if N % 32:
             assert float(ho.x3_merge(dzp)[:, N:].abs().max()) == 0.0
+    # the 8-columns-per-thread form (N % 4 == 0) over many blocks, with the ReLU mask: heads / tails are the roundings of x3_split, bit for bit
+    for N in (180, 36, 64):
+        gg, ro = rnd(70001, N), rnd(70001, N)
+        dzp, cs = ho.pad_cast_colsum(gg, ho.xw(N), ro)
+        refg = gg * (ro > 0)
+        assert torch.equal(dzp[:, :ho.xw(N)].contiguous(), ho.x3_split(torch.nn.functional.pad(refg, (0, ho.xw(N) // 2 - N))))
+        assert _err(cs[:N], refg.sum(0)) < 1e-5
     # fan-in add
     y = rnd(B, C, H, W)
     assert _err(ho.x3_merge(ho.x3_add(_x(x), _x(y)), C), (x + y).permute(0, 2, 3, 1).reshape(-1, C)) < 2e-5
