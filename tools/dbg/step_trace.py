@@ -27,6 +27,15 @@ for s, e in iv[1:]:
         ce = max(ce, e)
 busy += ce - cs
 print(f'busy {busy / 1e6:.3f} ms, idle {idle / 1e6:.3f} ms')
+CONV = ('conv_igemm', 'conv_wgrad', 'bottleneck', 'stem_pool', 'splitk', 'unpack_wgrad', 'halo_x3')
+t_conv = sum(E[i] - S[i] for i in range(a, b) if any(x in names[i] for x in CONV))
+t_else = sum(E[i] - S[i] for i in range(a, b)) - t_conv
+print(f'conv-class kernels (igemm, wgrad, fused blocks, stem, halo, split-K finalize, unpack) {t_conv / 1e6:.3f} ms, everything else {t_else / 1e6:.3f} ms')
+other = collections.Counter()
+for i in range(a, b):
+    if not any(x in names[i] for x in CONV):
+        other[names[i].split('(')[0][:70]] += E[i] - S[i]
+print('everything else, by kernel: ' + ', '.join(f'{n} {v / 1e3:.0f} us' for n, v in other.most_common(12)))
 tiny = [i for i in range(a, b) if E[i] - S[i] < 8000]
 print(len(tiny), 'kernels < 8 us:', sum(E[i] - S[i] for i in tiny) / 1e3, 'us')
 for n, c in collections.Counter(names[i][:90] for i in tiny).most_common(40):
