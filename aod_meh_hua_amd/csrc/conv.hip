@@ -723,6 +723,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(BM >= 192 ? 
       }
     }
     }
+  } else if (p.out_f32 && !p.res && !g_mask && !p.zraw && !p.post_scale && !p.pre_scale && (p.N & 3) == 0) {
+    // fp32 destinations of the prediction convs (bias, optional ReLU, no other operand; N = 180 / 36 / 720 ...): rows and 4-column halves are
+    // the only predicates -- the general loop below spends ~500 instructions per 16-B store on operands these launches do not have.
+    // (v * 1 + bias of the general loop = v + bias: the same bits)
+    const int n = n0 + ec * 8;
+    if (ecok && n < p.N) {
+      const bool hi = n + 8 <= p.N;                 // else columns n .. n + 3 only (N % 4 == 0)
+      float* const yo = reinterpret_cast<float*>(g_y) + n;
+#pragma unroll
+      for (int it = 0; it < E_IT; ++it) {
+        const int row = er + it * (NT / NCHT);
+        if (m0 + r0e + row >= p.M) continue;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(sc + row * CP + ec * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = v0[j] * 1.0f + cb1[j]; v1[j] = v1[j] * 1.0f + cb1[4 + j]; }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { csum[j] += v0[j]; if (hi) csum[4 + j] += v1[j]; }
+        float* const o = yo + s_drow[r0e + row] * p.N;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        if (hi) *reinterpret_cast<f32x4*>(o + 4) = v1;
+      }
+    }
   } else
 #pragma unroll
   for (int it = 0; it < E_IT; ++it) {
