@@ -40,21 +40,27 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {      // n is wave-uniform
   switch (n) {
     AOD_VMCASE(0) AOD_VMCASE(1) AOD_VMCASE(2) AOD_VMCASE(3) AOD_VMCASE(4) AOD_VMCASE(5) AOD_VMCASE(6) AOD_VMCASE(7) AOD_VMCASE(8)
     AOD_VMCASE(9) AOD_VMCASE(10) AOD_VMCASE(11) AOD_VMCASE(12) AOD_VMCASE(13) AOD_VMCASE(14) AOD_VMCASE(15) AOD_VMCASE(16)
-    AOD_VMCASE(17) AOD_VMCASE(18) AOD_VMCASE(19) AOD_VMCASE(20)
+    AOD_VMCASE(17) AOD_VMCASE(18) AOD_VMCASE(19) AOD_VMCASE(20) AOD_VMCASE(21) AOD_VMCASE(22) AOD_VMCASE(23) AOD_VMCASE(24)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 #undef AOD_VMCASE
 
-// NB: 16-channel output blocks (N <= 16 NB); S: stages (chunks resident / in flight)
-template <int NB, int S>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_x3_kernel(const Hx3Args p) {
+// NB: 16-channel output blocks (N <= 16 NB); S: stages (chunks resident / in flight); RW: output pixel rows per wave (8 / RW waves).
+// RW = 1: every wave reads all of a chunk's filter fragments for its one row -- 72 ds_read_b128 per 81 MFMAs at NB = 3: the LDS pipe, not the
+// matrix pipe, bounds the chunk (4 600 vs 2 600 cycles per CU).  RW = 2 (four waves): a wave reads the filter fragments once for two rows and
+// the halo fragments of its four halo rows once per chunk (a tap (dy, dx) of row r is halo row r + dy: 12 fragments instead of 18), 78 reads
+// per 162 MFMAs.  Same (chunk, tap, product) order per accumulator: identical bits.
+template <int NB, int S, int RW>
+__global__ __launch_bounds__(512 / RW) __attribute__((amdgpu_waves_per_eu(1, 2))) void halo_x3_kernel(const Hx3Args p) {
+  constexpr int NWV = 8 / RW;                                             // waves
   constexpr int WROWS = 16 * NB, WPIECES = 9 * WROWS / 8;                 // filter rows per tap; LDS-DMA pieces per chunk (all nine taps)
-  constexpr int NPI = (PPIECES + 7) / 8, NWI = (WPIECES + 7) / 8;         // piece slots per wave
+  constexpr int NPI = (PPIECES + NWV - 1) / NWV, NWI = (WPIECES + NWV - 1) / NWV;         // piece slots per wave
   constexpr int STAGE = PSLOT + 9 * WROWS * 128;
   constexpr int OFF_VEC = S * STAGE;
+  static_assert(RW == 1 || RW == 2, "rows per wave");
   static_assert(OFF_VEC + 64 * 4 <= 160 * 1024, "LDS map");
-  static_assert((S - 1) * (NPI + NWI) <= 20, "wait_vm_dyn range");
+  static_assert((S - 1) * (NPI + NWI) <= 24, "wait_vm_dyn range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -80,19 +86,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (t < 64) vec[t] = (p.shift && t < p.N) ? p.shift[t] : 0.f;
 
   // LDS-DMA lane roles: one wave-instruction fills 8 rows x 8 slots; lane -> row (lane >> 3) of its piece, slot lane & 7, source chunk
-  // slot ^ key(row); a wave moves the pieces uw + 8 i of an image, for which the key is the same
+  // slot ^ key(row); a wave moves the pieces uw + NWV i of an image, for which the key is the same (NWV is even)
   const int drow = lane >> 3;
   const int kcl = (lane & 7) ^ ((4 * (uw & 1) + (lane >> 4)) & 7);
   const int nsub = p.C >> 6;                                              // 32-channel chunks
   int n_w = 0;                                                            // pieces THIS wave moves per chunk (wave-uniform)
 #pragma unroll
-  for (int i = 0; i < NPI; ++i) n_w += (uw + 8 * i < PPIECES) ? 1 : 0;
+  for (int i = 0; i < NPI; ++i) n_w += (uw + NWV * i < PPIECES) ? 1 : 0;
 #pragma unroll
-  for (int i = 0; i < NWI; ++i) n_w += (uw + 8 * i < WPIECES) ? 1 : 0;
+  for (int i = 0; i < NWI; ++i) n_w += (uw + NWV * i < WPIECES) ? 1 : 0;
   unsigned poff[NPI], woff[NWI];
 #pragma unroll
   for (int i = 0; i < NPI; ++i) {
-    const int row = 8 * (uw + 8 * i) + drow;
+    const int row = 8 * (uw + NWV * i) + drow;
     const int hy = row / PW_, hx = row - hy * PW_;
     const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
     const bool ok = row < PPIX && (unsigned)y < (unsigned)sH && (unsigned)x < (unsigned)sW;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 #pragma unroll
   for (int i = 0; i < NWI; ++i) {
-    const int pi = uw + 8 * i;                                            // piece of the chunk's filter image [9][WROWS][128 B]
+    const int pi = uw + NWV * i;                                          // piece of the chunk's filter image [9][WROWS][128 B]
     const int tap = pi / (WROWS / 8), n = (pi - tap * (WROWS / 8)) * 8 + drow;
     woff[i] = (pi < WPIECES && n < p.N) ? (unsigned)((((long long)n * 9 + tap) * p.C) * 2 + kcl * 16) : OOB;
   }
@@ -108,28 +114,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* st = smem + slot * STAGE;
 #pragma unroll
     for (int i = 0; i < NPI; ++i)
-      if (uw + 8 * i < PPIECES) {
+      if (uw + NWV * i < PPIECES) {
         const unsigned off = poff[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(st + (uw + 8 * i) * 1024), 16, off, kc * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(st + (uw + NWV * i) * 1024), 16, off, kc * 128, 0, 0);
       }
 #pragma unroll
     for (int i = 0; i < NWI; ++i)
-      if (uw + 8 * i < WPIECES) {
+      if (uw + NWV * i < WPIECES) {
         const unsigned off = woff[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(st + PSLOT + (uw + 8 * i) * 1024), 16, off, kc * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(st + PSLOT + (uw + NWV * i) * 1024), 16, off, kc * 128, 0, 0);
       }
   };
-  // per-lane fragment addresses inside a stage (heads; the tails sit at slot ^ 4 = 64 B further)
-  unsigned afrag[9], wfrag[NB];
+  // per-lane fragment addresses inside a stage (heads; the tails sit at slot ^ 4 = 64 B further): halo row RW uw + hr, pixel lr + dx
+  unsigned afrag[RW + 2][3], wfrag[NB];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) afrag[tap] = (unsigned)swz((uw + tap / 3) * PW_ + lr + tap % 3, lq);
+  for (int hr = 0; hr < RW + 2; ++hr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) afrag[hr][dx] = (unsigned)swz((RW * uw + hr) * PW_ + lr + dx, lq);
 #pragma unroll
   for (int j = 0; j < NB; ++j) wfrag[j] = (unsigned)(PSLOT + swz(j * 16 + lr, lq));
   auto lds16 = [&](unsigned a) { return *reinterpret_cast<const bf16x8*>(smem + a); };
 
-  f32x4 acc[NB];
+  f32x4 acc[RW][NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[rr][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < S; ++s)
     if (s < nsub) issue(s, s);
@@ -145,57 +155,89 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kc >= 1 && kc - 1 + S < nsub) issue(kc - 1 + S, slot == 0 ? S - 1 : slot - 1);      // into the stage chunk kc - 1 was read from
     __builtin_amdgcn_sched_barrier(0);
     const unsigned base = (unsigned)(slot * STAGE);
+    if constexpr (RW == 1) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const bf16x8 ah = lds16(base + afrag[tap]), al = lds16(base + (afrag[tap] ^ 64u));
-      bf16x8 wh[NB], wl[NB];
+      for (int tap = 0; tap < 9; ++tap) {
+        const unsigned af = afrag[tap / 3][tap % 3];
+        const bf16x8 ah = lds16(base + af), al = lds16(base + (af ^ 64u));
+        bf16x8 wh[NB], wl[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        wh[j] = lds16(base + tap * (WROWS * 128) + wfrag[j]);
-        wl[j] = lds16(base + tap * (WROWS * 128) + (wfrag[j] ^ 64u));
+        for (int j = 0; j < NB; ++j) {
+          wh[j] = lds16(base + tap * (WROWS * 128) + wfrag[j]);
+          wl[j] = lds16(base + tap * (WROWS * 128) + (wfrag[j] ^ 64u));
+        }
+        // (per accumulator the order of conv_igemm_kernel<X3>: heads x heads, activation tails x filter heads, activation heads x filter tails)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc[0][j], 0, 0, 0);
       }
-      // (per accumulator the order of conv_igemm_kernel<X3>: heads x heads, activation tails x filter heads, activation heads x filter tails)
+    } else {
+      // the chunk's halo fragments of this wave's RW + 2 halo rows, once
+      bf16x8 ah[RW + 2][3], al[RW + 2][3];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah, acc[j], 0, 0, 0);
+      for (int hr = 0; hr < RW + 2; ++hr)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al, acc[j], 0, 0, 0);
+        for (int dx = 0; dx < 3; ++dx) { ah[hr][dx] = lds16(base + afrag[hr][dx]); al[hr][dx] = lds16(base + (afrag[hr][dx] ^ 64u)); }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah, acc[j], 0, 0, 0);
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        bf16x8 wh[NB], wl[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          wh[j] = lds16(base + tap * (WROWS * 128) + wfrag[j]);
+          wl[j] = lds16(base + tap * (WROWS * 128) + (wfrag[j] ^ 64u));
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], ah[rr + dy][dx], acc[rr][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[rr + dy][dx], acc[rr][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], ah[rr + dy][dx], acc[rr][j], 0, 0, 0);
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     slot = slot == S - 1 ? 0 : slot + 1;
   }
 
-  // ---- epilogue straight from the accumulators: lane (lr, lq) holds channels 16 j + 4 lq .. + 3 of pixel (ty0 + uw, tx0 + lr)
-  const int y = ty0 + uw, x = tx0 + lr;
-  if (y < sH && x < sW) {
-    float* o = p.y + (sdst + ((long long)b * sH + y) * sW + x) * p.N;
+  // ---- epilogue straight from the accumulators: lane (lr, lq) holds channels 16 j + 4 lq .. + 3 of pixel (ty0 + RW uw + rr, tx0 + lr)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int ch0 = j * 16 + lq * 4;
-      float v[4];
+  for (int rr = 0; rr < RW; ++rr) {
+    const int y = ty0 + RW * uw + rr, x = tx0 + lr;
+    if (y < sH && x < sW) {
+      float* o = p.y + (sdst + ((long long)b * sH + y) * sW + x) * p.N;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[j][r] * 1.0f + vec[(ch0 + r) & 63];              // (the general kernel's epilogue: v * scale + shift with scale = 1)
-        if (p.relu) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (ch0 + 4 <= p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4*>(o + ch0) = (f32x4){v[0], v[1], v[2], v[3]};
-      else {
+      for (int j = 0; j < NB; ++j) {
+        const int ch0 = j * 16 + lq * 4;
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ch0 + r < p.N) o[ch0 + r] = v[r];
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[rr][j][r] * 1.0f + vec[(ch0 + r) & 63];          // (the general kernel's epilogue: v * scale + shift with scale = 1)
+          if (p.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (ch0 + 4 <= p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4*>(o + ch0) = (f32x4){v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ch0 + r < p.N) o[ch0 + r] = v[r];
+        }
       }
     }
   }
 }
 
-template <int NB, int S>
+template <int NB, int S, int RW>
 int launch_hx3(const Hx3Args& a, hipStream_t st) {
   constexpr int LDS = S * (PSLOT + 9 * 16 * NB * 128) + 256;
   static unsigned long long attr_done = 0;
   if (aod_first_on_device(&attr_done))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&halo_x3_kernel<NB, S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  hipLaunchKernelGGL((halo_x3_kernel<NB, S>), dim3(a.ntiles), dim3(512), LDS, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&halo_x3_kernel<NB, S, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  hipLaunchKernelGGL((halo_x3_kernel<NB, S, RW>), dim3(a.ntiles), dim3(512 / RW), LDS, st, a);
   return 0;
 }
 
@@ -239,8 +281,10 @@ extern "C" int aod_halo_conv3x3_x3(const aod_conv_desc_t* d, const void* src, co
   a.w_bytes = (long long)a.N * 9 * a.C * 2;
   AOD_CHECK_ARG(a.x_bytes < 0xe0000000ll && a.w_bytes < 0xe0000000ll, "halo_conv_x3: operand larger than 3.5 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  if (a.N <= 16) launch_hx3<1, 3>(a, st);           // retina_L: 41 KB per chunk, three stages
-  else launch_hx3<3, 2>(a, st);                     // retina_reg: 77 KB per chunk, two stages
+  const char* e = getenv("AOD_HALO_X3_RW");          // (read per call: tests switch it in-process) 1 = one pixel row per wave, eight waves
+  const bool rw2 = !(e && e[0] == '1');
+  if (a.N <= 16) { if (rw2) launch_hx3<1, 3, 2>(a, st); else launch_hx3<1, 3, 1>(a, st); }      // retina_L: 41 KB per chunk, three stages
+  else { if (rw2) launch_hx3<3, 2, 2>(a, st); else launch_hx3<3, 2, 1>(a, st); }                // retina_reg: 77 KB per chunk, two stages
   AOD_LAUNCH_CHECK();
   return 0;
 }
