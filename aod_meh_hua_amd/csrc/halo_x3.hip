@@ -47,10 +47,10 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {      // n is wave-uniform
 #undef AOD_VMCASE
 
 // NB: 16-channel output blocks (N <= 16 NB); S: stages (chunks resident / in flight); RW: output pixel rows per wave (8 / RW waves).
-// RW = 1: every wave reads all of a chunk's filter fragments for its one row -- 72 ds_read_b128 per 81 MFMAs at NB = 3: the LDS pipe, not the
-// matrix pipe, bounds the chunk (4 600 vs 2 600 cycles per CU).  RW = 2 (four waves): a wave reads the filter fragments once for two rows and
-// the halo fragments of its four halo rows once per chunk (a tap (dy, dx) of row r is halo row r + dy: 12 fragments instead of 18), 78 reads
-// per 162 MFMAs.  Same (chunk, tap, product) order per accumulator: identical bits.
+// RW = 1 (default): every wave reads all of a chunk's filter fragments for its one row -- 72 ds_read_b128 per 81 MFMAs at NB = 3.  RW = 2 (four
+// waves): a wave reads the filter fragments once for two rows and the halo fragments of its four halo rows once per chunk (a tap (dy, dx) of
+// row r is halo row r + dy: 12 fragments instead of 18), 78 reads per 162 MFMAs.  Same (chunk, tap, product) order per accumulator: identical
+// bits -- and the same time: what bounds the kernel is the arrival of its chunks (77 KB each at NB = 3, one ahead of the one in use), not the LDS pipe.
 template <int NB, int S, int RW>
 __global__ __launch_bounds__(512 / RW) __attribute__((amdgpu_waves_per_eu(1, 2))) void halo_x3_kernel(const Hx3Args p) {
   constexpr int NWV = 8 / RW;                                             // waves
@@ -281,8 +281,10 @@ extern "C" int aod_halo_conv3x3_x3(const aod_conv_desc_t* d, const void* src, co
   a.w_bytes = (long long)a.N * 9 * a.C * 2;
   AOD_CHECK_ARG(a.x_bytes < 0xe0000000ll && a.w_bytes < 0xe0000000ll, "halo_conv_x3: operand larger than 3.5 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  const char* e = getenv("AOD_HALO_X3_RW");          // (read per call: tests switch it in-process) 1 = one pixel row per wave, eight waves
-  const bool rw2 = !(e && e[0] == '1');
+  // (read per call: tests switch it in-process) AOD_HALO_X3_RW=2: two pixel rows per wave, four waves -- half the LDS fragment reads, the same
+  // time (84 / 48 us either way, profiles/r05_x3_tile_ab.txt): the kernel waits for its chunks, one or two of which fit the LDS ahead of the one in use
+  const char* e = getenv("AOD_HALO_X3_RW");
+  const bool rw2 = e && e[0] == '2';
   if (a.N <= 16) { if (rw2) launch_hx3<1, 3, 2>(a, st); else launch_hx3<1, 3, 1>(a, st); }      // retina_L: 41 KB per chunk, three stages
   else { if (rw2) launch_hx3<3, 2, 2>(a, st); else launch_hx3<3, 2, 1>(a, st); }                // retina_reg: 77 KB per chunk, two stages
   AOD_LAUNCH_CHECK();

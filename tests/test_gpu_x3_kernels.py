@@ -510,13 +510,13 @@ def test_x3_narrow_prediction_convs_on_the_halo_kernel_equal_the_general_kernel(
             with torch.no_grad():
                 outs[mode] = [o.clone() for o in conv(list(feats), out_f32=True, relu=relu)]
             assert ('aod_halo_conv3x3_x3' in calls) == (mode == '1'), calls
-        # the one-row-per-wave form of the kernel (AOD_HALO_X3_RW=1; the default gives a wave two pixel rows): the same bits again
-        monkeypatch.setenv('AOD_HALO_X3', '1'); monkeypatch.setenv('AOD_HALO_X3_RW', '1')
+        # the two-rows-per-wave form of the kernel (AOD_HALO_X3_RW=2, four waves): the same bits again
+        monkeypatch.setenv('AOD_HALO_X3', '1'); monkeypatch.setenv('AOD_HALO_X3_RW', '2')
         with torch.no_grad():
-            outs['rw1'] = [o.clone() for o in conv(list(feats), out_f32=True, relu=relu)]
+            outs['rw2'] = [o.clone() for o in conv(list(feats), out_f32=True, relu=relu)]
         monkeypatch.undo()
         torch.cuda.synchronize()
-        assert all(torch.equal(a, c) for a, c in zip(outs['1'], outs['rw1']))
+        assert all(torch.equal(a, c) for a, c in zip(outs['1'], outs['rw2']))
         for x, a, b_ in zip(xs, outs['1'], outs['0']):
             ref = F.conv2d(x, conv.weight, conv.bias, 1, 1)
             ref = torch.relu(ref) if relu else ref

@@ -13,19 +13,22 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, int DEPTH>
-__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, unsigned win, int iters, unsigned long long* out, unsigned* sink) {
+__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, unsigned win, int iters, unsigned long long* out, unsigned* sink, int bcast, unsigned rstride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];      // DEPTH x 64 KB
   const int t = threadIdx.x, lane = t & 63;
   const int uw = __builtin_amdgcn_readfirstlane(t >> 6);
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)win, 0x00020000);
   // tile k of this workgroup starts at ((blockIdx * 7 + k) * 64 KB) mod win; a wave moves 8 x 1 KB pieces of it
-  unsigned base = (unsigned)(((unsigned long long)blockIdx.x * 7u * 65536u) % win);
+  // bcast: every workgroup walks the SAME tiles (a filter: all CUs read the same lines at about the same time);
+  // rstride: a 1 KB piece is 8 rows of 128 B `rstride` bytes apart (a [N][K] filter matrix read 64 columns at a time) instead of 1 KB contiguous
+  unsigned base = bcast ? 0u : (unsigned)(((unsigned long long)blockIdx.x * 7u * 65536u) % win);
   u32x4 fold = {0, 0, 0, 0};
   auto issue = [&](int k, int slot, u32x4 (&r)[8]) {
     const unsigned off0 = (unsigned)(((unsigned long long)base + (unsigned long long)k * 65536u) % win);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const unsigned off = off0 + (unsigned)((uw * 8 + i) * 1024 + lane * 16);
+      const unsigned off = rstride ? (unsigned)(((unsigned long long)off0 / 65536u * 128u + (unsigned long long)((uw * 8 + i) * 8 + (lane >> 3)) * rstride + (lane & 7) * 16) % win)
+                                   : off0 + (unsigned)((uw * 8 + i) * 1024 + lane * 16);
       if (MODE == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + slot * 65536 + (uw * 8 + i) * 1024), 16, off, 0, 0, 0);
       else r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
     }
@@ -62,10 +65,10 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, unsig
 }
 
 template <int MODE, int DEPTH>
-static void run(const char* name, const char* src, unsigned win, int wgs, int iters, unsigned long long* out, unsigned* sink) {
+static void run(const char* name, const char* src, unsigned win, int wgs, int iters, unsigned long long* out, unsigned* sink, int bcast = 0, unsigned rstride = 0) {
   const size_t lds = (size_t)DEPTH * 65536;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, win, iters, out, sink);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(wgs), dim3(512), lds, 0, src, win, iters, out, sink, bcast, rstride);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(2 * wgs);
   hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
@@ -73,7 +76,7 @@ static void run(const char* name, const char* src, unsigned win, int wgs, int it
   for (int i = 0; i < wgs; ++i) { cyc += (double)h[2 * i]; tick += (double)h[2 * i + 1]; }
   cyc /= wgs; tick /= wgs;
   const double bytes = (double)(iters + DEPTH) * 65536.0;
-  printf("  %-18s depth %d  window %6.1f MB  %4d wgs: %6.1f B/clk/CU  %6.1f GB/s/CU  (clock %.2f GHz)  aggregate %5.2f TB/s\n", name, DEPTH, win / 1048576.0, wgs,
+  printf("  %-18s %s%s depth %d  window %6.1f MB  %4d wgs: %6.1f B/clk/CU  %6.1f GB/s/CU  (clock %.2f GHz)  aggregate %5.2f TB/s\n", name, bcast ? "[same tiles in every CU] " : "", rstride ? "[rows 9216 B apart] " : "", DEPTH, win / 1048576.0, wgs,
          bytes / cyc, bytes / (tick * 10.0), cyc / (tick * 10.0), bytes / (tick * 10.0) * wgs / 1000.0);
 }
 
@@ -95,5 +98,11 @@ int main() {
       }
     }
   }
+  printf("filter-like access (LDS-DMA, two tiles in flight), 256 workgroups:\n");
+  run<0, 2>("LDS-DMA", src, 4u << 20, 256, iters, out, sink, 1, 0);
+  run<0, 2>("LDS-DMA", src, 4u << 20, 256, iters, out, sink, 0, 9216);
+  run<0, 2>("LDS-DMA", src, 4u << 20, 256, iters, out, sink, 1, 9216);
+  run<0, 2>("LDS-DMA", src, 4u << 20, 256, iters, out, sink, 1, 9216 + 128);
+  run<0, 2>("LDS-DMA", src, 4u << 20, 256, iters, out, sink, 1, 1024);
   return 0;
 }
