@@ -43,6 +43,25 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert b'multiple of 8' in lib.aod_last_error()
     lib.aod_loss_partials_len.restype = ctypes.c_size_t
     assert lib.aod_loss_partials_len(ctypes.c_int64(1000)) == 48      # 3 per block of 64 rows (the 4-lanes-per-row form for > 24 classes)
+    # the level-fused loss entry points: 1 .. 8 levels, and their workspace is the per-level sum (a level's last block is its own)
+    rows = (ctypes.c_int64 * 3)(1000, 10, 0)
+    lib.aod_loss_levels_partials_len.restype = ctypes.c_size_t
+    assert lib.aod_loss_levels_partials_len(3, rows) == 48 + 3 + 0
+    one = ctypes.c_void_p(16)
+    for nlev in (0, 9):
+        rc = lib.aod_edl_focal_l1_levels_fwd(one, one, one, None, None, None, nlev, rows, 20, ctypes.c_float(2.0), ctypes.c_float(0.25), one, one, one,
+                                             None, 0, None, None, None)
+        assert rc == -1 and b'1..8 levels' in lib.aod_last_error()
+        rc = lib.aod_meh_loss_levels_bwd(one, one, one, nlev, rows, one, one, 0, 9, 9, None)
+        assert rc == -1 and b'1..8 levels' in lib.aod_last_error()
+    # (num_pos without a divisor buffer)
+    rc = lib.aod_edl_focal_l1_levels_fwd(one, one, one, None, None, None, 3, rows, 20, ctypes.c_float(2.0), ctypes.c_float(0.25), one, one, one,
+                                         one, 16, None, None, None)
+    assert rc == -1 and b'divisor' in lib.aod_last_error()
+    # the x3 halo kernel says no to anything but a narrow fp32-destination 3 x 3 / stride-1 forward conv of the reference-precision mode
+    from aod_meh_hua_amd._C import ConvDesc
+    dd = ConvDesc()
+    assert lib.aod_halo_conv3x3_x3_applies(ctypes.byref(dd)) == 0
 
 
 def test_product_refuses_cpu_tensors():
