@@ -6,8 +6,6 @@ The fork rounds UP to two decimals in three places -- cumulative recall and prec
 precision of the VOC07 11-point AP (:49-50) -- which shifts mAP by up to ~1 point against stock mmdet; those quirks are part of the
 number the paper reports and are kept.  Host-side numpy (the metric is a sequential greedy match over a few thousand boxes, not a GPU
 workload); one process instead of the reference's multiprocessing.Pool (same arithmetic, deterministic order)."""
-import math
-
 import numpy as np
 
 
@@ -29,80 +27,86 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', eps=1e-6):
     return (overlap / np.maximum(union, np.float32(eps))).astype(np.float32)
 
 
+def _running_max_from_the_right(p):
+    return np.maximum.accumulate(p[..., ::-1], axis=-1)[..., ::-1]
+
+
 def average_precision(recalls, precisions, mode='area'):
-    """mean_ap.py:12-57; '11points' adds ceil(prec*100)/100 per recall threshold (:49-50)."""
-    no_scale = recalls.ndim == 1
-    if no_scale:
-        recalls, precisions = recalls[np.newaxis, :], precisions[np.newaxis, :]
-    assert recalls.shape == precisions.shape and recalls.ndim == 2
-    num_scales = recalls.shape[0]
-    ap = np.zeros(num_scales, dtype=np.float32)
+    """Behaviour of mean_ap.py:12-57.  'area': area under the monotone precision envelope, summed over the recall steps; '11points':
+    mean over recall thresholds 0, 0.1, ..., 1 of the best precision at recall >= threshold, each sample rounded UP to two decimals
+    (the fork's quirk, :49-50).  One curve ([n]) or one per scale ([scales, n]); float32 result like the reference's accumulator."""
+    single = recalls.ndim == 1
+    rec, prec = np.atleast_2d(recalls), np.atleast_2d(precisions)
+    assert rec.shape == prec.shape and rec.ndim == 2
+    n_curves = rec.shape[0]
+    out = np.zeros(n_curves, dtype=np.float32)
     if mode == 'area':
-        zeros, ones = np.zeros((num_scales, 1), dtype=recalls.dtype), np.ones((num_scales, 1), dtype=recalls.dtype)
-        mrec, mpre = np.hstack((zeros, recalls, ones)), np.hstack((zeros, precisions, zeros))
-        for i in range(mpre.shape[1] - 1, 0, -1):
-            mpre[:, i - 1] = np.maximum(mpre[:, i - 1], mpre[:, i])
-        for i in range(num_scales):
-            ind = np.where(mrec[i, 1:] != mrec[i, :-1])[0]
-            ap[i] = np.sum((mrec[i, ind + 1] - mrec[i, ind]) * mpre[i, ind + 1])
+        pad0, pad1 = np.zeros((n_curves, 1), rec.dtype), np.ones((n_curves, 1), rec.dtype)
+        r = np.concatenate((pad0, rec, pad1), axis=1)                         # recall axis closed at 0 and 1
+        envelope = _running_max_from_the_right(np.concatenate((pad0, prec, pad0), axis=1))
+        width = r[:, 1:] - r[:, :-1]
+        for c in range(n_curves):
+            step = r[c, 1:] != r[c, :-1]                                       # only the columns where recall moves contribute
+            out[c] = np.sum(width[c, step] * envelope[c, 1:][step])
     elif mode == '11points':
-        for i in range(num_scales):
-            for thr in np.arange(0, 1 + 1e-3, 0.1):
-                precs = precisions[i, recalls[i, :] >= thr]
-                prec = precs.max() if precs.size > 0 else 0
-                ap[i] += math.ceil(prec * 100) / 100
-        ap /= 11
+        thresholds = np.arange(0, 1 + 1e-3, 0.1)
+        reached = rec[:, None, :] >= thresholds[None, :, None]                # [curve, threshold, point]
+        best = np.where(reached, prec[:, None, :], -np.inf).max(axis=2, initial=-np.inf)
+        best = np.where(reached.any(axis=2), best, 0).astype(prec.dtype)      # no point reaches the threshold: 0
+        samples = np.ceil(best * 100).astype(np.float64) / 100                 # rounded UP, in the curve's own dtype
+        for c in range(n_curves):
+            acc = np.float32(0)
+            for v in samples[c]:                                               # float32 running sum, threshold by threshold
+                acc = np.float32(acc + np.float32(v))
+            out[c] = acc
+        out /= 11
     else:
         raise ValueError('Unrecognized mode, only "area" and "11points" are supported')
-    return ap[0] if no_scale else ap
+    return out[0] if single else out
+
+
+def _box_areas(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 
 
 def tpfp_default(det_bboxes, gt_bboxes, gt_bboxes_ignore=None, iou_thr=0.5, area_ranges=None):
-    """mean_ap.py:154-239: greedy matching in descending score order; a det whose best gt is ignored counts as neither."""
-    if gt_bboxes_ignore is None:
-        gt_bboxes_ignore = np.empty((0, 4), dtype=np.float32)
-    gt_ignore_inds = np.concatenate((np.zeros(gt_bboxes.shape[0], dtype=bool), np.ones(gt_bboxes_ignore.shape[0], dtype=bool)))
-    gt_bboxes = np.vstack((gt_bboxes, gt_bboxes_ignore))
-    num_dets, num_gts = det_bboxes.shape[0], gt_bboxes.shape[0]
-    if area_ranges is None:
-        area_ranges = [(None, None)]
-    num_scales = len(area_ranges)
-    tp = np.zeros((num_scales, num_dets), dtype=np.float32)
-    fp = np.zeros((num_scales, num_dets), dtype=np.float32)
-    if num_gts == 0:
-        if area_ranges == [(None, None)]:
-            fp[...] = 1
-        else:
-            det_areas = (det_bboxes[:, 2] - det_bboxes[:, 0]) * (det_bboxes[:, 3] - det_bboxes[:, 1])
-            for i, (min_area, max_area) in enumerate(area_ranges):
-                fp[i, (det_areas >= min_area) & (det_areas < max_area)] = 1
+    """Behaviour of mean_ap.py:154-239, vectorised.  Every detection points at its best-IoU gt; among the detections that reach
+    `iou_thr` on a countable gt, the highest-scoring one is the true positive and the others are false positives; a detection whose
+    best gt is an ignored one (or outside the area range) is neither; a detection below the threshold is a false positive when its own
+    area lies in the range.  Returns (tp, fp), each [scales, num_dets] float32 in the detections' input order."""
+    n_real = gt_bboxes.shape[0]
+    if gt_bboxes_ignore is not None and gt_bboxes_ignore.shape[0]:
+        gt_bboxes = np.vstack((gt_bboxes, gt_bboxes_ignore))
+    n_det, n_gt = det_bboxes.shape[0], gt_bboxes.shape[0]
+    flagged_ignore = np.arange(n_gt) >= n_real
+    ranges = [(None, None)] if area_ranges is None else list(area_ranges)
+    tp = np.zeros((len(ranges), n_det), dtype=np.float32)
+    fp = np.zeros((len(ranges), n_det), dtype=np.float32)
+    det_area = _box_areas(det_bboxes[:, :4]) if n_det else np.zeros(0, det_bboxes.dtype)
+
+    def det_in_range(lo, hi):
+        return np.ones(n_det, bool) if lo is None else (det_area >= lo) & (det_area < hi)
+
+    if n_gt == 0:
+        for k, (lo, hi) in enumerate(ranges):
+            fp[k, det_in_range(lo, hi)] = 1
         return tp, fp
-    ious = bbox_overlaps(det_bboxes, gt_bboxes)
-    ious_max, ious_argmax = ious.max(axis=1), ious.argmax(axis=1)
-    sort_inds = np.argsort(-det_bboxes[:, -1])
-    for k, (min_area, max_area) in enumerate(area_ranges):
-        gt_covered = np.zeros(num_gts, dtype=bool)
-        if min_area is None:
-            gt_area_ignore = np.zeros_like(gt_ignore_inds, dtype=bool)
-        else:
-            gt_areas = (gt_bboxes[:, 2] - gt_bboxes[:, 0]) * (gt_bboxes[:, 3] - gt_bboxes[:, 1])
-            gt_area_ignore = (gt_areas < min_area) | (gt_areas >= max_area)
-        for i in sort_inds:
-            if ious_max[i] >= iou_thr:
-                m = ious_argmax[i]
-                if not (gt_ignore_inds[m] or gt_area_ignore[m]):
-                    if not gt_covered[m]:
-                        gt_covered[m] = True
-                        tp[k, i] = 1
-                    else:
-                        fp[k, i] = 1
-            elif min_area is None:
-                fp[k, i] = 1
-            else:
-                bbox = det_bboxes[i, :4]
-                area = (bbox[2] - bbox[0]) * (bbox[3] - bbox[1])
-                if min_area <= area < max_area:
-                    fp[k, i] = 1
+    iou = bbox_overlaps(det_bboxes, gt_bboxes)
+    best_gt, best_iou = iou.argmax(axis=1), iou.max(axis=1)
+    reaches = best_iou >= iou_thr
+    order = np.argsort(-det_bboxes[:, -1])                                    # the reference's tie order is this call's
+    rank = np.empty(n_det, dtype=np.int64)
+    rank[order] = np.arange(n_det)
+    gt_area = _box_areas(gt_bboxes)
+    for k, (lo, hi) in enumerate(ranges):
+        uncounted = flagged_ignore if lo is None else flagged_ignore | (gt_area < lo) | (gt_area >= hi)
+        claim = np.flatnonzero(reaches & ~uncounted[best_gt])                  # detections competing for a countable gt
+        first = np.full(n_gt, n_det, dtype=np.int64)
+        np.minimum.at(first, best_gt[claim], rank[claim])                      # best-ranked claimant per gt
+        won = rank[claim] == first[best_gt[claim]]
+        tp[k, claim[won]] = 1
+        fp[k, claim[~won]] = 1
+        fp[k, ~reaches & det_in_range(lo, hi)] = 1
     return tp, fp
 
 

@@ -11,6 +11,7 @@ import math
 import os
 import os.path as osp
 import time
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -273,16 +274,66 @@ def _init_one(m, cfg):
             b.fill_(bias)
 
 
+# mmcv resolves `torchvision://NAME` through torchvision's model_urls and `open-mmlab://NAME` through its open_mmlab.json and
+# downloads into $TORCH_HOME/hub/checkpoints (mmcv/runner/checkpoint.py load_from_torchvision / load_from_openmmlab).  There is no
+# network here, so the same names are resolved against local directories -- and an unresolvable one is LOUD, never a silent skip.
+_PRETRAINED_ALIASES = {'vgg16_caffe': ('vgg16_caffe-292e1171.pth',), 'resnet50': ('resnet50-0676ba61.pth', 'resnet50-19c8e357.pth'),
+                       'resnet101': ('resnet101-63fe2227.pth', 'resnet101-5d3b4d8f.pth')}
+_pretrained_warned = set()
+
+
+def pretrained_search_dirs():
+    dirs = []
+    if os.environ.get('AOD_PRETRAINED_DIR'):
+        dirs.append(os.environ['AOD_PRETRAINED_DIR'])
+    home = os.environ.get('TORCH_HOME') or osp.join(os.environ.get('XDG_CACHE_HOME', osp.expanduser('~/.cache')), 'torch')
+    dirs += [osp.join(home, 'hub', 'checkpoints'), osp.join(home, 'checkpoints')]
+    return dirs
+
+
+def resolve_pretrained(uri):
+    """Local file for a `Pretrained` checkpoint string, or None.  A plain path is returned if it exists; `torchvision://NAME`,
+    `open-mmlab://NAME` and http(s) URLs are looked up by file name (the hashed names mmcv would have downloaded, `NAME.pth`, or
+    `NAME-*.pth`) in $AOD_PRETRAINED_DIR, then $TORCH_HOME/hub/checkpoints (default ~/.cache/torch/hub/checkpoints)."""
+    import glob
+    if not uri:
+        return None
+    if '://' not in uri:
+        return uri if osp.isfile(uri) else None
+    scheme, name = uri.split('://', 1)
+    if scheme in ('http', 'https'):
+        names = [osp.basename(name)]
+    else:
+        base = osp.basename(name)
+        names = list(_PRETRAINED_ALIASES.get(base, ())) + [base + '.pth', base + '-*.pth']
+    for d in pretrained_search_dirs():
+        for n in names:
+            hits = sorted(glob.glob(osp.join(d, n)))
+            if hits:
+                return hits[0]
+    return None
+
+
 def initialize(module, init_cfg):
-    """mmcv.cnn.utils.weight_init.initialize subset: {type, layer, override}; Pretrained is a no-op
-    here (no network: synthetic benchmarks use seeded weights; load real checkpoints via load_checkpoint)."""
+    """mmcv.cnn.utils.weight_init.initialize subset: {type, layer, override} + Pretrained (mmcv PretrainedInit: load_checkpoint with
+    strict=False into THIS module; configs/_base_/Config_RetinaNet.py:33 `torchvision://resnet50`, Config_SSD.py:32
+    `open-mmlab://vgg16_caffe`).  A checkpoint that cannot be found warns once per string and leaves the module at its constructor
+    initialisation -- the synthetic benchmarks and the parity tests load seeded weights afterwards."""
     cfgs = init_cfg if isinstance(init_cfg, list) else [init_cfg]
     for cfg in cfgs:
         cfg = dict(cfg)
         if cfg['type'] == 'Pretrained':
-            ck = cfg.get('checkpoint', '')
-            if osp.isfile(ck):
-                load_checkpoint(module, ck, strict=False)
+            uri = cfg.get('checkpoint', '')
+            ck = resolve_pretrained(uri)
+            if ck is None:
+                if uri not in _pretrained_warned:
+                    _pretrained_warned.add(uri)
+                    warnings.warn(f"init_cfg=dict(type='Pretrained', checkpoint={uri!r}) of {type(module).__name__}: no such file in "
+                                  f"{pretrained_search_dirs()} (there is no network to download it) -- {type(module).__name__} keeps its "
+                                  f"RANDOM constructor initialisation.  Put the checkpoint there (or set AOD_PRETRAINED_DIR), or remove "
+                                  f"init_cfg from the config to silence this.", RuntimeWarning, stacklevel=2)
+                continue
+            load_checkpoint(module, ck, strict=False, prefix=cfg.get('prefix'))
             continue
         override = cfg.pop('override', None)
         layers = cfg.pop('layer', None)
@@ -442,12 +493,29 @@ class MMDataParallel(nn.Module):
 
 
 # ------------------------------------------------------------------------------ checkpoints / logging
-def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None):
+def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, prefix=None):
+    """mmcv.runner.load_checkpoint: `state_dict` wrapper and `module.` prefixes stripped, optional `prefix` sub-dict selection
+    (PretrainedInit's `prefix=`); with strict=False the keys that did not land are reported (mmcv logs them), and a file none of
+    whose keys match the module raises -- that is a wrong file, not a partial load."""
     ck = torch.load(filename, map_location=map_location)
     sd = ck.get('state_dict', ck) if isinstance(ck, dict) else ck
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+    if prefix:
+        prefix = prefix if prefix.endswith('.') else prefix + '.'
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     tgt = model.module if hasattr(model, 'module') else model
-    tgt.load_state_dict(sd, strict=strict)
+    res = tgt.load_state_dict(sd, strict=strict)
+    if not strict:
+        own = tgt.state_dict()
+        if sd and not any(k in own for k in sd):
+            raise RuntimeError(f'{filename}: none of its {len(sd)} keys (e.g. {next(iter(sd))!r}) names a tensor of '
+                               f'{type(tgt).__name__} (e.g. {next(iter(own), None)!r})')
+        miss = [k for k in res.missing_keys if not k.endswith('num_batches_tracked')]
+        if miss or res.unexpected_keys:
+            msg = (f'{osp.basename(filename)} -> {type(tgt).__name__}: {len(sd) - len(res.unexpected_keys)} tensors loaded; '
+                   f'missing in file: {miss[:6]}{" ..." if len(miss) > 6 else ""}; '
+                   f'unexpected in file: {res.unexpected_keys[:6]}{" ..." if len(res.unexpected_keys) > 6 else ""}')
+            (logger.warning if logger is not None else print)(msg)
     return ck
 
 

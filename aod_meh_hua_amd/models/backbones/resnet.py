@@ -93,6 +93,11 @@ class ResNet(BaseModule):
             raise KeyError(f'invalid depth {depth} for resnet')
         assert not deep_stem and not avg_down and dcn is None and plugins is None
         assert norm_eval, 'the MEH/HUA configs run BN in eval mode (norm_eval=True); train-mode BN is out of scope'
+        assert not (init_cfg and pretrained), 'init_cfg and pretrained cannot be setting at the same time'
+        if isinstance(pretrained, str):            # resnet.py:399-402 (deprecated spelling of init_cfg=Pretrained)
+            self.init_cfg = dict(type='Pretrained', checkpoint=pretrained)
+        elif pretrained is not None:
+            raise TypeError('pretrained must be a str or None')
         if init_cfg is None and pretrained is None:
             self.init_cfg = [dict(type='Kaiming', layer='Conv2d'), dict(type='Constant', val=1, layer=['_BatchNorm', 'GroupNorm'])]
         self.zero_init_residual = zero_init_residual and init_cfg is None and pretrained is None

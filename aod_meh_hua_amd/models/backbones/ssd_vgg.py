@@ -17,6 +17,11 @@ class SSDVGG(BaseModule):
 
     def __init__(self, depth, with_last_pool=False, ceil_mode=True, out_indices=(3, 4), out_feature_indices=(22, 34), pretrained=None,
                  init_cfg=None, input_size=None, l2_norm_scale=None):
+        assert not (init_cfg and pretrained), 'init_cfg and pretrained cannot be setting at the same time'
+        if init_cfg is None and isinstance(pretrained, str):     # ssd_vgg.py:84-87 (deprecated spelling of init_cfg=Pretrained)
+            init_cfg = dict(type='Pretrained', checkpoint=pretrained)
+        elif pretrained is not None and not isinstance(pretrained, str):
+            raise TypeError('pretrained must be a str or None')
         super().__init__(init_cfg if init_cfg is not None else [dict(type='Kaiming', layer='Conv2d')])
         layers, inpl = [], 3
         for i, nb in enumerate(self.arch_settings[depth]):

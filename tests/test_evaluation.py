@@ -64,3 +64,40 @@ def test_bbox2result_and_voc_evaluate():
     out07 = ev.evaluate_voc(dets, anns, year=2007, logger='silent')
     out12 = ev.evaluate_voc(dets, anns, year=2012, logger='silent')
     assert out07['mAP'] == float(G['a_voc07_map']) and out12['mAP'] == float(G['a_area_map']) and out07['AP50'] == round(out07['mAP'], 3)
+
+
+def test_vectorised_matching_equals_a_sequential_greedy_walk():
+    """tpfp_default is a vectorised first-claim match; here it is checked against the literal sequential definition (walk the detections
+    in descending score, a gt can be claimed once) on random crowded scenes with ignored gts, area ranges and tied scores."""
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        nd, ng, ni = int(rng.integers(0, 40)), int(rng.integers(0, 6)), int(rng.integers(0, 3))
+        def boxes(n):
+            xy = rng.uniform(0, 60, (n, 2)).astype(np.float32)
+            wh = rng.uniform(4, 50, (n, 2)).astype(np.float32)
+            return np.hstack((xy, xy + wh)).astype(np.float32)
+        sc = np.round(rng.uniform(0, 1, (nd, 1)), 1 if trial % 2 else 6).astype(np.float32)      # odd trials: many tied scores
+        det, gt, ign = np.hstack((boxes(nd), sc)), boxes(ng), boxes(ni)
+        for ranges in (None, [(0, 900), (900, 1e5)]):
+            for thr in (0.3, 0.5):
+                tp, fp = ev.tpfp_default(det, gt, ign, thr, ranges)
+                allgt = np.vstack((gt, ign))
+                iou = ev.bbox_overlaps(det, allgt)
+                for k, (lo, hi) in enumerate(ranges or [(None, None)]):
+                    taken, etp, efp = set(), np.zeros(nd), np.zeros(nd)
+                    for i in np.argsort(-det[:, -1]):
+                        area = (det[i, 2] - det[i, 0]) * (det[i, 3] - det[i, 1])
+                        inside = lo is None or lo <= area < hi
+                        if allgt.shape[0] == 0 or iou[i].max() < thr:
+                            efp[i] = inside
+                            continue
+                        m = int(iou[i].argmax())
+                        ga = (allgt[m, 2] - allgt[m, 0]) * (allgt[m, 3] - allgt[m, 1])
+                        if m >= ng or (lo is not None and not lo <= ga < hi):
+                            continue
+                        if m in taken:
+                            efp[i] = 1
+                        else:
+                            taken.add(m)
+                            etp[i] = 1
+                    assert np.array_equal(tp[k], etp) and np.array_equal(fp[k], efp), (trial, k, thr)
