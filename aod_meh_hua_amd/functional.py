@@ -508,7 +508,10 @@ class _WgradQueue:
     @classmethod
     def submit(cls, job, wid, defer):
         cls.begin_pass()
-        if wid in cls.seen or not (defer and cls.enabled):
+        # deterministic mode: every weight gradient is launched ALONE -- a job's slab count (= its fp32 summation order) must not depend on
+        # which neighbours happened to share its grouped launch, and those differ between one backward pass and the same pass cut into
+        # segments (data parallelism): the 3-iteration data-parallel run then equals its one-process emulation again
+        if wid in cls.seen or not (defer and cls.enabled) or ho.DETERMINISTIC:
             cls.flush()
             job.run_alone()
             # a second use of a weight inside one pass: the engine ADDS the two gradients -- .grad is then no longer "our tensor or a clone

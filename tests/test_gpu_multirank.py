@@ -77,13 +77,10 @@ def test_two_rank_replicas_in_the_reference_precision_mode():
     column-sum atomics) reaches the 16-bit head + tail images of activations and filters, and on the worker's 128 x 128 images -- a 4 x 4
     map in layer 4 -- a single flipped ReLU bit moves a filter's gradient by percents (tools/dbg/drift_where.py: two IDENTICAL one-process
     runs drift apart the same way from iteration 3 on; the bf16 mode rounds the difference away, which is why its runs repeat to 1e-7)."""
-    # (third case: the deterministic mode -- ordered column sums, functional.set_deterministic -- removes the noise source, and three iterations
-    # then equal the mean-gradient run to the fp32 summation order of one regrouped weight-gradient launch)
-    # (the worker's default step size lets the loss of the seeded network grow from iteration to iteration: in that regime the ONE regrouped
-    # weight-gradient launch by which the data-parallel run differs from its emulation -- 2e-8 after one iteration -- is amplified without bound,
-    # one ReLU flip at a time; the three-iteration comparison of the deterministic mode therefore runs at a tenth of the step size, and its
-    # bound is one flipped element's share of a bias gradient, not a rounding error: measured 7e-4 on the worst bias vector, 2e-8 after one step)
-    for steps, det, bound, lr in ((1, '0', 1e-5, '2e-4'), (3, '0', 5e-2, '2e-4'), (1, '1', 1e-6, '2e-4'), (3, '1', 5e-3, '2e-5')):
+    # (third / fourth case: the deterministic mode -- ordered column sums AND ungrouped weight gradients, functional.set_deterministic -- removes
+    # both noise sources: the data-parallel run and its one-process emulation then issue the same launches with the same summation orders, and
+    # three iterations at the worker's full step size agree to the rounding of the gradient mean, ADVICE r5)
+    for steps, det, bound, lr in ((1, '0', 1e-5, '2e-4'), (3, '0', 5e-2, '2e-4'), (1, '1', 1e-6, '2e-4'), (3, '1', 1e-6, '2e-4')):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', AOD_CONV_PREC='bf16x3', MULTIRANK_STEPS=str(steps), MULTIRANK_DETERMINISTIC=det,
                    MULTIRANK_LR=lr)
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
