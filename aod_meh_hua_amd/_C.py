@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
 P, I32, I64, F32, U64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 _SIGS = {
     'aod_version': (C.c_int, []),
+    'aod_conv_x3p_count': (C.c_int64, []),
     'aod_set_pointwise_mode': (C.c_int, [I32]),
     'aod_bottleneck64_fwd': (C.c_int, [P, I32, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P]),
     'aod_bottleneck64x3_fwd': (C.c_int, [P, I32, I32, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P]),

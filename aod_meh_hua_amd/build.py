@@ -19,7 +19,7 @@ def source_digest():
     tools/profile/pmc_passes.sh) to the build it was measured on -- bench.py merges such a file into its line only when the tags agree."""
     import hashlib
     h = hashlib.sha256()
-    for f in sources() + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pointwise.h'), os.path.join(HERE, '..', 'include', 'aod_hip.h')]:
+    for f in sources() + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pointwise.h'), os.path.join(CSRC, 'conv_x3p.h'), os.path.join(HERE, '..', 'include', 'aod_hip.h')]:
         if os.path.exists(f):
             h.update(os.path.basename(f).encode())
             h.update(open(f, 'rb').read())
@@ -30,7 +30,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'aod_hip.h')]
+    deps = sources() + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pointwise.h'), os.path.join(CSRC, 'conv_x3p.h'),
+                        os.path.join(HERE, '..', 'include', 'aod_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

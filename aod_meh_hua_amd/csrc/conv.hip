@@ -12,6 +12,7 @@
 //   with ds_read_b64_tr_b16 (hardware transpose); split over m across workgroups, fp32 atomics.
 #include "common.h"
 #include "pointwise.h"
+#include "conv_x3p.h"
 
 struct ConvGroup { const bf16_t* x; const bf16_t* w; void* y; const float* pre_shift; const bf16_t* mask; float* colsum; };
 struct ConvKParams {
@@ -1158,6 +1159,26 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
+  if (p.x3 && !p.out_f32 && !p.zraw && !p.post_scale && !p.perm && !p.up_w && !p.bigrows && p.R == p.S) {
+    // the persistent producer / consumer kernel (conv_x3p.hip) for the 128-column-tileable 1x1 / 3x3 layers that fill at least ~ a round of
+    // the CUs with 128 x 128 tiles and do NOT qualify for the 256 x 256 tile below (the head towers, FPN P3): identical bits, AOD_X3P=0 disables
+    const long long t256 = ntiles(256, 256);
+    const bool big = !p.res && p.N % 256 == 0 && p.K >= 2048 && t256 >= 240 && t256 * 100 >= ((t256 + 255) / 256) * 256 * 92;
+    static const char* dbg_big = getenv("AOD_X3P_OVER_256");           // (A/B: also take the launches of the 256 x 256 tile)
+    if (!big || (dbg_big && dbg_big[0] == '1')) {
+      X3PArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = p.x; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y); a.pre_scale = p.pre_scale; a.pre_shift = p.pre_shift; a.res = p.res; a.mask = p.mask;
+      a.colsum = p.colsum; a.C = p.C; a.N = p.N; a.K = p.K; a.taps = p.R * p.S; a.S = p.S; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil;
+      a.transposed = p.transposed; a.relu = p.relu; a.nseg = p.nseg; a.M = p.M; a.x_bytes = p.x_bytes; a.w_bytes = p.w_bytes;
+      a.tapin = (p.tap_inner && a.taps > 1 && p.C >= 256) ? 1 : 0;      // the general kernel's K order for this shape (see `tapin` there)
+      for (int i = 0; i < 8; ++i) {
+        a.segH[i] = p.segH[i]; a.segW[i] = p.segW[i]; a.segOH[i] = p.segOH[i]; a.segOW[i] = p.segOW[i]; a.segB[i] = p.segB[i];
+        a.seg_src0[i] = p.seg_src0[i]; a.seg_dst0[i] = p.seg_dst0[i]; a.seg_mend[i] = p.seg_mend[i];
+      }
+      if (aod_conv_x3p_wants(a, p.colsum && aod_get_deterministic())) return aod_conv_x3p_launch(a, st);
+    }
+  }
   if (p.x3) {
     // X3: the 256 x 256 tile under the same fill rule as the plain form (a K-step of the 128 x 128 tile asks the L2 -> LDS path for 64 KB
     // per 1 536 matrix-pipe cycles per CU -- more than it delivers --, the big tile for half of that), else the 4-wave forms

@@ -1,0 +1,176 @@
+"""GPU: the persistent producer / consumer x3 convolution (csrc/conv_x3p.hip; the backbone's and the neck's 1x1 / 3x3 layers,
+mmdet/models/backbones/resnet.py:262-301, necks/fpn.py:151-202) against the general implicit-GEMM kernel it replaces: the same products in the
+same order and the same fp32 epilogue -> IDENTICAL BITS for the outputs and the input gradients (forward with BN / bias / residual / ReLU at
+stride 1 and 2, dgrad with ReLU mask / deferred residual gradient), whole, ragged and multi-round tile counts, one and several segments; the
+fused column sums (bias / BN-shift gradients) are fp32 atomics in both kernels and agree to rounding; and against torch fp32."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def x3_mode():
+    from aod_meh_hua_amd import functional as AF
+    AF.set_precision('bf16x3')
+    yield
+    AF.set_precision(os.environ.get('AOD_CONV_PREC', 'bf16x3'))
+
+
+def _x(t):
+    from aod_meh_hua_amd import hipops as ho
+    B, C, H, W = t.shape
+    return ho.x3_split(t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous())
+
+
+def _f(rows, B, H, W, C):
+    from aod_meh_hua_amd import hipops as ho
+    return ho.x3_merge(rows, C).view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def _err(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-30))
+
+
+CASES = [
+    # B, C, O, H, W, R, stride, bn, res, relu      (tiles of 128 x 128: rows / 128 x O / 128)
+    dict(B=2, C=256, O=128, H=32, W=32, R=1, stride=1, bn=True, res=False, relu=True),        # 16 tiles, (tap, chunk) order irrelevant (1x1)
+    dict(B=2, C=128, O=128, H=32, W=32, R=3, stride=1, bn=True, res=False, relu=True),        # 3x3, C < 256: taps outermost
+    dict(B=2, C=256, O=256, H=32, W=32, R=3, stride=1, bn=True, res=False, relu=True),        # 3x3, C >= 256: taps innermost (layer-3 conv2)
+    dict(B=3, C=128, O=512, H=24, W=40, R=1, stride=1, bn=True, res=True, relu=True),         # expand conv with residual = head + tail; ragged last tile (2 880 rows)
+    dict(B=4, C=256, O=128, H=64, W=64, R=3, stride=2, bn=True, res=False, relu=True),        # stride-2 forward (first block's conv2): x3p forward, general dgrad
+    dict(B=2, C=512, O=256, H=32, W=32, R=1, stride=2, bn=True, res=False, relu=False),       # 1x1 / stride-2 downsample
+    dict(B=16, C=256, O=1024, H=32, W=32, R=1, stride=1, bn=True, res=True, relu=True),       # 1 024 tiles: four rounds of the persistent grid
+    dict(B=1, C=64, O=128, H=13, W=21, R=3, stride=1, bn=False, res=False, relu=False),       # one K-chunk per tap, 273 rows: three tiles, the last ragged; bias
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_x3p_forward_and_dgrad_equal_the_general_kernel(case, monkeypatch):
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import lib
+    from aod_meh_hua_amd.mmcv_lite import BatchNorm2d
+    c = case
+    B, C, O, H, W, R, st = c['B'], c['C'], c['O'], c['H'], c['W'], c['R'], c['stride']
+    pad = R // 2
+    g = torch.Generator(device='cuda').manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    x = rnd(B, C, H, W)
+    w0 = rnd(O, C, R, R) / (C * R * R) ** 0.5
+    bn, bias0 = None, None
+    if c['bn']:
+        bn = BatchNorm2d(O).cuda().eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(O, device='cuda', generator=g) + 0.5); bn.bias.copy_(rnd(O) * 0.1)
+            bn.running_mean.copy_(rnd(O) * 0.1); bn.running_var.copy_(torch.rand(O, device='cuda', generator=g) + 0.5)
+    else:
+        bias0 = rnd(O) * 0.1
+    oh, ow = ho.out_hw(H, W, R, R, st, pad, 1)
+    res = rnd(B, O, oh, ow) if c['res'] else None
+    gy = rnd(B, O, oh, ow)
+    monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setenv('AOD_X3P_1X1', '1')          # (the product sends only the 3x3 layers here; the kernel itself takes both)
+    monkeypatch.setattr(ho, 'SPLITK', False)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('AOD_X3P', mode)
+        n0 = lib.aod_conv_x3p_count()
+        w = w0.clone().requires_grad_()
+        bias = bias0.clone().requires_grad_() if bias0 is not None else None
+        if bn is not None:
+            bn.weight.grad = bn.bias.grad = None
+        xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+        rx = AF.as_nchw(_x(res), B, oh, ow) if res is not None else None
+        y = AF.conv_bn_act(xx, w, bn=bn, bias=bias, res=rx, stride=st, pad=pad, relu=c['relu'])
+        y.backward(AF.as_nchw(_x(gy), B, oh, ow))
+        torch.cuda.synchronize()
+        took = lib.aod_conv_x3p_count() - n0
+        # forward always qualifies; the dgrad at stride 1 with C % 128 == 0 only (the class-major stride-2 dgrad and 64-channel destinations
+        # stay with the general kernel)
+        assert took == (0 if mode == '0' else (2 if st == 1 and C % 128 == 0 else 1)), (mode, took)
+        out[mode] = dict(y=AF.as_rows(y).detach().clone(), gx=AF.as_rows(xx.grad).clone(), gw=w.grad.clone(),
+                         gb=(bn.bias.grad if bn is not None else bias.grad).clone())
+    a, b_ = out['1'], out['0']
+    assert torch.equal(a['y'], b_['y']), float((a['y'].float() - b_['y'].float()).abs().max())
+    assert torch.equal(a['gx'], b_['gx']), float((a['gx'].float() - b_['gx'].float()).abs().max())
+    assert torch.equal(a['gw'], b_['gw'])                       # (same wgrad kernel, fed bit-identical gradients)
+    assert _err(a['gb'], b_['gb']) < 2e-6                       # column sums: fp32 atomics, arrival order
+    # ---- and against torch fp32
+    z = F.conv2d(x, w0, bias0, st, pad)
+    if bn is not None:
+        z = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight.detach(), bn.bias.detach(), False, 0.0, bn.eps)
+    if res is not None:
+        z = z + res
+    yf = _f(a['y'], B, oh, ow, O)
+    if c['relu']:
+        z = z * (yf > 0).float()
+    assert _err(yf, z) < 1e-4, _err(yf, z)
+
+
+def test_x3p_pyramid_segments_and_mask_epilogue(monkeypatch):
+    """Several segments sharing a filter (the neck's / towers' level-batched launches, Lambda_L2.py:85-94 style) whose row counts are multiples
+    of 128 -- a tile never straddles two levels -- take the persistent kernel as ONE launch; a pyramid with a ragged inner level must not.  The
+    dgrad epilogue with a ReLU mask and column sums (functional.ActSlot protocol: conv -> ReLU -> conv, the second conv's dgrad masks) is
+    covered by chaining two convs."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import lib
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    g = torch.Generator(device='cuda').manual_seed(12)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setattr(ho, 'SPLITK', False)
+    c1, c2 = Conv2d(256, 256, 3, padding=1).cuda(), Conv2d(256, 128, 3, padding=1).cuda()
+    with torch.no_grad():
+        c1.weight.copy_(rnd(256, 256, 3, 3) / 48.0); c1.bias.copy_(rnd(256) * 0.1)
+        c2.weight.copy_(rnd(128, 256, 3, 3) / 48.0); c2.bias.copy_(rnd(128) * 0.1)
+    for B, sizes, expect in ((2, ((32, 32), (16, 16), (8, 8)), True), (2, ((32, 32), (12, 12), (8, 8)), False)):
+        xs = [rnd(B, 256, h, w) for h, w in sizes]
+        gys = [rnd(B, 128, h, w) for h, w in sizes]
+        res = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('AOD_X3P', mode)
+            n0 = lib.aod_conv_x3p_count()
+            for m in (c1, c2):
+                m.weight.grad = m.bias.grad = None
+            feats = [AF.as_nchw(_x(x), B, x.shape[2], x.shape[3]).requires_grad_() for x in xs]
+            hs = c1(list(feats), relu=True)
+            ys = c2(list(hs), relu=False)
+            torch.autograd.backward(list(ys), [AF.as_nchw(_x(gq), B, gq.shape[2], gq.shape[3]) for gq in gys])
+            torch.cuda.synchronize()
+            took = lib.aod_conv_x3p_count() - n0
+            assert (took > 0) == (mode == '1' and expect), (mode, expect, took)
+            res[mode] = ([AF.as_rows(y).detach().clone() for y in ys], [AF.as_rows(f.grad).clone() for f in feats],
+                         c1.bias.grad.clone(), c2.bias.grad.clone(), c1.weight.grad.clone())
+        for a, b_ in zip(res['1'][0] + res['1'][1], res['0'][0] + res['0'][1]):
+            assert torch.equal(a, b_), float((a.float() - b_.float()).abs().max())
+        assert _err(res['1'][2], res['0'][2]) < 2e-6 and _err(res['1'][3], res['0'][3]) < 2e-6
+        assert _err(res['1'][4], res['0'][4]) < 2e-6
+        ref = F.conv2d(torch.relu(F.conv2d(xs[0], c1.weight, c1.bias, 1, 1)), c2.weight, c2.bias, 1, 1)
+        assert _err(_f(res['1'][0][0], B, sizes[0][0], sizes[0][1], 128), ref) < 2e-4
+
+
+def test_x3p_repeated_launches_are_bit_stable(monkeypatch):
+    """race screen: the ring's waits are counted by hand -- 40 launches of a multi-round shape, back to back, must all give the first one's bits"""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    g = torch.Generator(device='cuda').manual_seed(13)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setenv('AOD_X3P', '1')
+    B, C, O, H, W = 16, 256, 256, 32, 32
+    x = AF.as_nchw(_x(rnd(B, C, H, W)), B, H, W)
+    w = rnd(O, C, 3, 3) / 48.0
+    bias = rnd(O) * 0.1
+    with torch.no_grad():
+        first = AF.as_rows(AF.conv_bn_act(x, w, bias=bias, stride=1, pad=1, relu=True)).clone()
+        junk = torch.empty(64 << 20, device='cuda', dtype=torch.uint8)
+        for i in range(40):
+            if i % 4 == 0:
+                junk.random_(0, 255)                    # (evict the operands now and then: cold and warm loads take different times)
+            y = AF.as_rows(AF.conv_bn_act(x, w, bias=bias, stride=1, pad=1, relu=True))
+            assert torch.equal(y, first), i

@@ -1,0 +1,110 @@
+"""A/B of the persistent producer / consumer x3 conv (csrc/conv_x3p.hip, AOD_X3P=1) against the general kernel (AOD_X3P=0) on the backbone /
+neck shapes of configs[1] (16 x 512^2), launches back to back on one stream, operands evicted between repetitions (cold) or not (warm).
+  gpurun -- 'python tools/dbg/x3p_micro.py'            # -> gpurun_out/x3p_micro.txt"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from aod_meh_hua_amd import functional as AF  # noqa: E402
+from aod_meh_hua_amd import hipops as ho  # noqa: E402
+from aod_meh_hua_amd._C import lib  # noqa: E402
+
+AF.set_precision('bf16x3')
+ho.SPLITK = True
+B = int(os.environ.get('B', '16'))
+SHAPES = [  # name, C, O, H, W, R, stride, res
+    ('l3 reduce 1x1 1024->256 @32', 1024, 256, 32, 32, 1, 1, False),
+    ('l3 conv2 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, False),
+    ('l3 expand 1x1 256->1024 @32 +res', 256, 1024, 32, 32, 1, 1, True),
+    ('l2 reduce 1x1 512->128 @64', 512, 128, 64, 64, 1, 1, False),
+    ('l2 conv2 3x3 128->128 @64', 128, 128, 64, 64, 3, 1, False),
+    ('l2 expand 1x1 128->512 @64 +res', 128, 512, 64, 64, 1, 1, True),
+    ('l3.0 conv2 3x3 s2 256->256 @64', 256, 256, 64, 64, 3, 2, False),
+    ('l3.0 down 1x1 s2 512->1024 @64', 512, 1024, 64, 64, 1, 2, False),
+    ('l4 reduce 1x1 2048->512 @16', 2048, 512, 16, 16, 1, 1, False),
+    ('l4 expand 1x1 512->2048 @16 +res', 512, 2048, 16, 16, 1, 1, True),
+    ('fpn lateral 1x1 512->256 @64', 512, 256, 64, 64, 1, 1, False),
+    ('fpn lateral 1x1 1024->256 @32', 1024, 256, 32, 32, 1, 1, False),
+    ('fpn 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, False),
+    ('fpn 3x3 256->256 @64 (256x256 tile today)', 256, 256, 64, 64, 3, 1, False),
+    # dgrads (stride 1): dX [M, C] = conv_T(dZ [M, O], W), with the producer's ReLU mask and column sums in the epilogue
+    ('DGRAD l3 conv2 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, 'dgrad'),
+    ('DGRAD fpn 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, 'dgrad'),
+    ('DGRAD retina_cls 3x3 256->192 pyramid', 256, 192, 0, 0, 3, 1, 'dgrad'),
+    ('DGRAD retina_reg 3x3 256->64 pyramid', 256, 64, 0, 0, 3, 1, 'dgrad'),
+    ('DGRAD retina_L 3x3 256->32 pyramid', 256, 32, 0, 0, 3, 1, 'dgrad'),
+]
+MODES = os.environ.get('MODES', '0,1').split(',')
+ONLY = os.environ.get('ONLY')
+g = torch.Generator(device='cuda').manual_seed(1)
+junk = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
+lines = []
+for name, C, O, H, W, R, st, res in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
+    pad = R // 2
+    dgrad = res == 'dgrad'
+    res = res is True
+    sizes = [(H, W)] if H else [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    segs, r0 = [], 0
+    for h_, w_ in sizes:
+        segs.append(ho.Seg(B, h_, w_, r0)); r0 += B * h_ * w_
+    Mrows = r0
+    w = torch.randn(O, C, R, R, device='cuda', generator=g) / (C * R * R) ** 0.5
+    oh, ow = (ho.out_hw(H, W, R, R, st, pad, 1) if H else (0, 0))
+    bias = torch.randn(O, device='cuda', generator=g)
+    holder = {}
+    if not dgrad:
+        x = AF.as_nchw(ho.x3_split(torch.randn(B * H * W, C, device='cuda', generator=g)), B, H, W)
+        r = AF.as_nchw(ho.x3_split(torch.randn(B * oh * ow, O, device='cuda', generator=g)), B, oh, ow) if res else None
+
+        def f():
+            with torch.no_grad():
+                holder['y'] = AF.as_rows(AF.conv_bn_act(x, w, bias=bias, res=r, stride=st, pad=pad, relu=True))
+        Mout = B * oh * ow
+    else:
+        pi = AF.PREP.get(w, None, ho.xw(C), 0.0)
+        AF.PREP.refresh_if_stale()
+        dz = ho.x3_split(torch.randn(Mrows, O, device='cuda', generator=g))
+        xmask = ho.x3_split(torch.randn(Mrows, C, device='cuda', generator=g))
+        cs = torch.zeros(C, device='cuda')
+
+        def f():
+            holder['y'] = ho.conv2d_dgrad_rows(dz, segs, segs, pi.wd, C, R, R, 1, pad, 1, mask=xmask, colsum=cs)
+        Mout, oh, ow = Mrows, 1, Mrows // B
+    flop = 2.0 * Mout * O * C * R * R
+    row = [f'{name:44s} M={Mout:6d}']
+    outs = {}
+    for mode in MODES:
+        os.environ['AOD_X3P'] = mode[0]
+        os.environ['AOD_X3P_ROT'] = mode[2:] if len(mode) > 1 else '0'
+        os.environ['AOD_X3P_MIN_TILES'] = os.environ.get('MIN_TILES', '1')
+        os.environ['AOD_X3P_1X1'] = '1'
+        for _ in range(3):
+            f()
+        n0 = lib.aod_conv_x3p_count()
+        f()
+        took = lib.aod_conv_x3p_count() - n0
+        outs[mode] = holder['y'].clone()
+        ts = {}
+        for kind in ('warm', 'cold'):
+            reps = 20
+            evs = []
+            for i in range(reps):
+                if kind == 'cold':
+                    junk.random_(0, 255)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); f(); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+            ts[kind] = t[len(t) // 2]
+        row.append(f'x3p={mode:4s}{"*" if took else " "} warm {ts["warm"]:7.1f} us ({flop / ts["warm"] * 1e-6:5.0f} TF) cold {ts["cold"]:7.1f} us')
+    row.append('bits equal' if all(torch.equal(outs[MODES[0]], o) for o in outs.values()) else 'BITS DIFFER')
+    lines.append('  '.join(row))
+    print(lines[-1], flush=True)
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+open(os.path.join(ROOT, 'gpurun_out', 'x3p_micro.txt'), 'w').write('\n'.join(lines) + '\n')
