@@ -1038,6 +1038,26 @@ __global__ __launch_bounds__(256) void conv_splitk_finalize_kernel(const ConvKPa
 // a stride-2 3x3 on the 2048-channel C5, 8 x 8 outputs per image; the 3x3 convs of the 16 x 16 backbone stage, K = 4608).  The decision and the slice boundaries depend on the PER-IMAGE
 // geometry and on K only, never on the batch size: the fp32 summation order of an output element -- and so the score of an image --
 // must not change with how the pool is batched.  Returns the number of K slices (1 = direct launch).
+// operands / geometry of a launch in the persistent kernel's terms (conv_x3p.hip)
+static void x3p_args(const ConvKParams& p, X3PArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.x = p.x; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y); a.pre_scale = p.pre_scale; a.pre_shift = p.pre_shift; a.res = p.res; a.mask = p.mask;
+  a.colsum = p.colsum; a.C = p.C; a.N = p.N; a.K = p.K; a.taps = p.R * p.S; a.S = p.S; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil;
+  a.transposed = p.transposed; a.relu = p.relu; a.nseg = p.nseg; a.M = p.M; a.x_bytes = p.x_bytes; a.w_bytes = p.w_bytes;
+  a.tapin = (p.tap_inner && a.taps > 1 && p.C >= 256) ? 1 : 0;      // the general kernel's K order for this shape (see `tapin` there)
+  for (int i = 0; i < 8; ++i) {
+    a.segH[i] = p.segH[i]; a.segW[i] = p.segW[i]; a.segOH[i] = p.segOH[i]; a.segOW[i] = p.segOW[i]; a.segB[i] = p.segB[i];
+    a.seg_src0[i] = p.seg_src0[i]; a.seg_dst0[i] = p.seg_dst0[i]; a.seg_mend[i] = p.seg_mend[i];
+  }
+  if (p.ngroups > 1) {
+    a.ngroups = p.ngroups;
+    for (int g = 0; g < p.ngroups; ++g) {
+      a.grp[g].x = p.grp[g].x; a.grp[g].w = p.grp[g].w; a.grp[g].y = reinterpret_cast<bf16_t*>(p.grp[g].y); a.grp[g].shift = p.grp[g].pre_shift;
+      a.grp[g].mask = p.grp[g].mask; a.grp[g].colsum = p.grp[g].colsum;
+    }
+  }
+}
+
 static int choose_ksplit(const ConvKParams& p) {
   const int nk = (p.K + 63) / 64;
   if (nk < 64) return 1;
@@ -1164,18 +1184,10 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     // the CUs with 128 x 128 tiles and do NOT qualify for the 256 x 256 tile below (the head towers, FPN P3): identical bits, AOD_X3P=0 disables
     const long long t256 = ntiles(256, 256);
     const bool big = !p.res && p.N % 256 == 0 && p.K >= 2048 && t256 >= 240 && t256 * 100 >= ((t256 + 255) / 256) * 256 * 92;
-    static const char* dbg_big = getenv("AOD_X3P_OVER_256");           // (A/B: also take the launches of the 256 x 256 tile)
+    const char* dbg_big = getenv("AOD_X3P_OVER_256");                  // (A/B, read per call: also take the launches of the 256 x 256 tile)
     if (!big || (dbg_big && dbg_big[0] == '1')) {
       X3PArgs a;
-      memset(&a, 0, sizeof(a));
-      a.x = p.x; a.w = p.w; a.y = reinterpret_cast<bf16_t*>(p.y); a.pre_scale = p.pre_scale; a.pre_shift = p.pre_shift; a.res = p.res; a.mask = p.mask;
-      a.colsum = p.colsum; a.C = p.C; a.N = p.N; a.K = p.K; a.taps = p.R * p.S; a.S = p.S; a.stride = p.stride; a.pad = p.pad; a.dil = p.dil;
-      a.transposed = p.transposed; a.relu = p.relu; a.nseg = p.nseg; a.M = p.M; a.x_bytes = p.x_bytes; a.w_bytes = p.w_bytes;
-      a.tapin = (p.tap_inner && a.taps > 1 && p.C >= 256) ? 1 : 0;      // the general kernel's K order for this shape (see `tapin` there)
-      for (int i = 0; i < 8; ++i) {
-        a.segH[i] = p.segH[i]; a.segW[i] = p.segW[i]; a.segOH[i] = p.segOH[i]; a.segOW[i] = p.segOW[i]; a.segB[i] = p.segB[i];
-        a.seg_src0[i] = p.seg_src0[i]; a.seg_dst0[i] = p.seg_dst0[i]; a.seg_mend[i] = p.seg_mend[i];
-      }
+      x3p_args(p, a);
       if (aod_conv_x3p_wants(a, p.colsum && aod_get_deterministic())) return aod_conv_x3p_launch(a, st);
     }
   }
@@ -1292,6 +1304,21 @@ extern "C" int aod_conv2d_grouped(const aod_conv_desc_t* desc, int ngroups, cons
   };
   static const char* dbg_t256 = getenv("AOD_TILE_256");
   const bool ok256 = !(dbg_t256 && dbg_t256[0] == '0') && p.N % 256 == 0 && p.K >= 1024;
+  if (p.x3 && p.R == p.S && !p.bigrows) {
+    // the head towers' grouped launches CAN run on the persistent producer / consumer kernel (conv_x3p.hip, 128 x 256 tiles; identical bits):
+    // AOD_X3P_GROUPED=1.  Not the default -- launch by launch the two forms are level (671 vs 689 us forward, 729 vs 725 us dgrad for three
+    // groups at 16 x 512^2, profiles/r06_x3p_micro.txt) and inside the step the 256 x 256 tile is 0.3 - 0.5 ms ahead
+    const char* dbg_g = getenv("AOD_X3P_GROUPED");                   // (read per call: tests / A-B scripts switch it in-process)
+    bool any_cs = false;
+    for (int g = 0; g < ngroups; ++g) any_cs = any_cs || p.grp[g].colsum;
+    if (dbg_g && dbg_g[0] == '1') {        // (opt-in: interleaved A/Bs put it level with the 256 x 256 tile, tools/dbg/x3p_grouped_micro.py)
+      X3PArgs a;
+      x3p_args(p, a);
+      if (ngroups == 1) { a.ngroups = 1; a.grp[0].x = p.grp[0].x; a.grp[0].w = p.grp[0].w; a.grp[0].y = reinterpret_cast<bf16_t*>(p.grp[0].y);
+                          a.grp[0].shift = p.grp[0].pre_shift; a.grp[0].mask = p.grp[0].mask; a.grp[0].colsum = p.grp[0].colsum; }
+      if (aod_conv_x3p_wants(a, any_cs && aod_get_deterministic())) return aod_conv_x3p_launch(a, st);
+    }
+  }
   if (p.x3) {          // x3 groups take the big tile (the 4-wave forms have no grouped instances)
     if (!any_mask) launch_conv<256, 256, 512, 0, true, 2, true>(p, st); else launch_conv<256, 256, 512, 1, true, 2, true>(p, st);
   } else if (ok256 && fill(256, 256, 256) * 1.12 >= fill(128, 128, 512)) {        // (the big tile is ~15 % faster per FLOP when its rounds are full)

@@ -14,7 +14,9 @@ struct X3PArgs {
   float* colsum;            // optional fp32 [N]: += column sums of the stored values (fp32 atomics)
   int C, N, K, taps, S, stride, pad, dil, transposed, relu, tapin;
   int nseg, M, tiles_m, tiles_n;
-  int rot;                  // debug (AOD_X3P_ROT): tile-dependent start chunk of the K loop
+  int rot;                  // debug (AOD_X3P_ROT): tile-dependent start chunk of the K loop / dropped operand loads (timing experiments)
+  int ngroups;              // >= 1: grp[] holds the operands (the launcher fills grp[0] from the fields above for a plain launch)
+  struct { const bf16_t* x; const bf16_t* w; bf16_t* y; const float* shift; const bf16_t* mask; float* colsum; } grp[4];
   long long x_bytes, w_bytes;
   int segH[8], segW[8], segOH[8], segOW[8], segB[8];
   long long seg_src0[8], seg_dst0[8];

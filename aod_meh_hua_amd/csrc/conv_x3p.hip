@@ -7,18 +7,21 @@
 // (one or two 4-wave workgroups per CU) nothing covers the address code and the load issue: the matrix pipe is busy 27 % of the time
 // (profiles/r05_pmc_passes.txt), although neither the L2 -> LDS path nor the LDS is near a limit.
 //
-// Structure here (one 8-wave workgroup per CU, 128 pixels x 128 channels per tile, grid = min(tiles, CUs), each workgroup walks its tiles):
+// Structure here (one 8-wave workgroup per CU, 128 pixels x 128 or 256 channels per tile, grid = min(tiles, CUs), each workgroup walks its tiles):
 //   * waves 4-7 are LOADERS: per tile they resolve 4 pixel rows per lane ONCE into one byte offset per (tap, row) -- out-of-image taps become
 //     an out-of-range offset, for which the buffer range check returns zeros -- and then only issue LDS-DMA: 8 x 1 KiB per wave and K-step,
-//     the K-step's displacement in the instruction's scalar offset.  They keep three 32-KB stages in flight in a five-slot ring (all 160 KB of
-//     the LDS) and continue into the NEXT tile while the consumers finish the current one (the ring does not know about tiles).
+//     the K-step's displacement in the instruction's scalar offset.  They keep three 32-KB stages in flight in a five-slot ring (128-column
+//     tiles; 256-column tiles: one to two 48-KB stages in a three-slot ring -- either way all but 16 KB of the LDS) and continue into the NEXT
+//     tile while the consumers finish the current one (the ring does not know about tiles).
 //   * waves 0-3 are CONSUMERS (one per SIMD, 2 x 2 over the tile): fragment reads + 48 MFMAs per K-step, nothing else.  Products are formed
 //     TRANSPOSED -- the filter is the MFMA's A operand, the pixels its B operand -- and the loaders fill the filter tile with its rows
 //     permuted, so that a lane ends up with eight consecutive channels of one pixel in two accumulators: the epilogue (BN / bias, residual =
 //     head + tail, ReLU mask, ReLU, column sums, head / tail split) runs in registers and stores 16-B pieces straight to the destination
 //     rows -- no LDS image, no barrier, and the ring keeps filling meanwhile.
-//   * one raw s_barrier per K-step.  At barrier g the loaders guarantee that stage g + 1 has landed (counted vmcnt: the 24 instructions of
-//     the three younger stages may stay in flight) and the consumers that their reads of stage g are complete (stage g + 5 takes its slot).
+//   * one raw s_barrier per K-step.  At barrier g the loaders guarantee that stage g + 1 has landed (counted vmcnt: the instructions of the
+//     FLY younger stages may stay in flight) and the consumers that their reads of stage g are complete (stage g + RING takes its slot).
+//   * the 256-column form (NBW = 8: a consumer wave owns 64 pixels x 128 channels, 96 MFMAs per K-step) is the head towers' (Lambda_L2.py:44-51,
+//     85-103): up to four convolutions of one geometry share the grid (aod_conv2d_grouped), the tile index names the group.
 //
 // Same products in the same order per accumulator as conv_igemm_kernel<.., X3 = true> (K-steps in (chunk, tap) order for C >= 256, (tap, chunk)
 // otherwise; xh*wh, xl*wh, xh*wl per step) and the same fp32 epilogue arithmetic: IDENTICAL BITS (tests/test_gpu_x3p.py); only the fp32
@@ -27,12 +30,7 @@
 
 namespace {
 
-constexpr int XP_BM = 128, XP_BN = 128, XP_STAGE = 32768, XP_ABYTES = 16384;
-// ring: XP_RING slots, XP_FLY stages in flight.  Iteration k of a loader issues stage k, waits until all but the youngest XP_FLY stages'
-// instructions have landed (stage k - XP_FLY and older) and joins barrier k - XP_FLY - 1, behind which the consumers read stage k - XP_FLY;
-// stage k overwrites the slot of stage k - XP_RING, whose reads ended before barrier k - XP_RING <= k - XP_FLY - 2: XP_RING >= XP_FLY + 2.
-constexpr int XP_RING = 5, XP_FLY = 3;
-static_assert(XP_RING >= XP_FLY + 2, "ring depth");
+constexpr int XP_BM = 128, XP_XBYTES = 16384;
 constexpr unsigned XP_OOB = 0xf0000000u;
 
 __device__ __forceinline__ unsigned xp_udiv(unsigned n, unsigned d) {      // n / d for n < 2^22 (conv.hip udiv_small)
@@ -54,13 +52,23 @@ __device__ __forceinline__ T xp_sel8(const T* a, int sg) {      // a[sg] of a by
   for (int q = 1; q < 8; ++q) v = sg == q ? a[q] : v;
   return v;
 }
+#define XP_GSEL(f) (gi == 0 ? p.grp[0].f : (gi == 1 ? p.grp[1].f : (gi == 2 ? p.grp[2].f : p.grp[3].f)))
 
-template <int TAPS>
+// NBW: 16-channel blocks per consumer wave -- 4: 128-column tiles, 8: 256-column tiles
+template <int TAPS, int NBW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3p_kernel(const X3PArgs p) {
+  constexpr int BN = 32 * NBW, WBYTES = BN * 128, STAGE = XP_XBYTES + WBYTES;
+  // ring: RING slots, FLY stages in flight.  Iteration k of a loader issues stage k, waits until all but the youngest FLY stages'
+  // instructions have landed (stage k - FLY and older) and joins barrier k - FLY - 1, behind which the consumers read stage k - FLY;
+  // stage k overwrites the slot of stage k - RING, whose reads ended before barrier k - RING <= k - FLY - 2: RING >= FLY + 2.
+  constexpr int RING = NBW == 4 ? 5 : 3, FLY = RING - 2;
+  constexpr int NL = 4 + NBW;                                   // LDS-DMA instructions per loader wave and stage
+  static_assert(RING * STAGE <= 160 * 1024, "LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tpg = p.tiles_m * p.tiles_n;                       // tiles per group
+  const int ntiles = tpg * p.ngroups;
   const int G = (int)gridDim.x, bid = (int)blockIdx.x;
   const int nmine = (ntiles - bid + G - 1) / G;              // tiles bid, bid + G, ... (launcher: G <= ntiles)
   const int CC = p.C >> 6;                                    // 64-column (= 32-channel) chunks per tap
@@ -81,25 +89,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ======================================================================== loaders
     const int w = wave - 4;
     const int prow = lane >> 3;
-    const int kc = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);          // k-chunk this lane fetches: slot ^ ((row >> 1) & 7), the same for its 4 rows
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const int kc = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);          // k-chunk this lane fetches: slot ^ ((row >> 1) & 7), the same for all its rows
     // filter rows: LDS row R of the tile holds output channel n0 + perm(R), perm = the order in which the transposed product leaves eight
     // consecutive channels in one lane (block pair a = 2 x 16 rows -> channels 32a + 8q + {0..3 | 4..7}, see the consumers' epilogue)
-    unsigned wvo[4];
+    unsigned wvo[NBW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBW; ++i) {
       const int R = 8 * w + 32 * i + prow;
-      const int nrel = (R >> 6) * 64 + ((R >> 5) & 1) * 32 + ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3);
+      const int wv = R / (16 * NBW), nb = (R >> 4) % NBW;
+      const int nrel = wv * (16 * NBW) + (nb >> 1) * 32 + ((R >> 2) & 3) * 8 + (nb & 1) * 4 + (R & 3);
       wvo[i] = (unsigned)((nrel * p.K + kc * 8) * 2);
     }
     const int sgn = p.transposed ? -1 : 1;
-    int gi = 0, slot = 0;                                      // stages issued so far, ring slot of the next one
+    int gi_ = 0, slot = 0;                                     // stages issued so far, ring slot of the next one
     char* const lds_w = smem + (8 * w) * 128;
     for (int j = 0; j < nmine; ++j) {
       const int tile = tile_of(j);
-      const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-      const int m0 = tm * XP_BM, n0 = tn * XP_BN;
+      const int gi = tile / tpg, tl = tile - gi * tpg;
+      const int tm = tl / p.tiles_n, tn = tl - tm * p.tiles_n;
+      const int m0 = tm * XP_BM, n0 = tn * BN;
+      // (p.rot bits 8 / 9, timing experiments only: a zero-record descriptor drops every load of that operand at the range check)
+      const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)XP_GSEL(x), 0, (p.rot & 256) ? 0 : (int)p.x_bytes, 0x00020000);
+      const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)XP_GSEL(w), 0, (p.rot & 512) ? 0 : (int)p.w_bytes, 0x00020000);
       // the tile lies inside ONE segment (launcher): workgroup-uniform geometry
       const int sg = seg_of(m0);
       const unsigned mstart = sg ? (unsigned)xp_sel8(p.seg_mend, sg - 1) : 0u;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       const unsigned soff_w0 = (unsigned)n0 * (unsigned)(p.K * 2);
       auto issue = [&](const unsigned (&v)[4], int t, int cc) {
-        char* const sa = lds_w + slot * XP_STAGE;
+        char* const sa = lds_w + slot * STAGE;
         const unsigned soff_x = (unsigned)cc * 128u;
         const unsigned soff_w = soff_w0 + (unsigned)((t * p.C + cc * 64) * 2);
 #pragma unroll
@@ -142,20 +153,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, off, soff_x, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NBW; ++i) {
           const unsigned off = wvo[i];
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sa + XP_ABYTES + i * 4096), 16, off, soff_w, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sa + XP_XBYTES + i * 4096), 16, off, soff_w, 0, 0);
         }
-        ++gi;
-        slot = slot == XP_RING - 1 ? 0 : slot + 1;
-        if (gi > XP_FLY) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * XP_FLY) : "memory");
+        ++gi_;
+        slot = slot == RING - 1 ? 0 : slot + 1;
+        if (gi_ > FLY) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * FLY) : "memory");
           __builtin_amdgcn_s_barrier();
         }
       };
       if (TAPS == 1 || p.tapin) {
-        // (p.rot, timing experiments only: the chunk loop starts at a tile-dependent chunk -- another summation order)
-        int cc = p.rot ? (tm * p.rot) % CC : 0;
+        // (p.rot low bits, timing experiments only: the chunk loop starts at a tile-dependent chunk -- another summation order)
+        int cc = (p.rot & 255) ? (tm * (p.rot & 255)) % CC : 0;
         for (int c0 = 0; c0 < CC; ++c0) {
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) issue(vo[t], t, cc);
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // the barriers of the last stages: total + 1 in all (one opens the ring, one closes every K-step)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int done = total > XP_FLY ? total - XP_FLY : 0;
+    const int done = total > FLY ? total - FLY : 0;
     for (int k = done; k < total + 1; ++k) __builtin_amdgcn_s_barrier();
     return;
   }
@@ -179,169 +190,192 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lr = lane & 15, lq = lane >> 4;
   const int sw = (lr >> 1) & 7;
   const int oh = (lq ^ sw) << 4, ol = ((4 + lq) ^ sw) << 4;          // 16-B slot of this lane's head / tail k-chunk inside a 128-B tile row
-  const int xoff = (wm * 64 + lr) * 128, woff = XP_ABYTES + (wn * 64 + lr) * 128;
+  const int xoff = (wm * 64 + lr) * 128, woff = XP_XBYTES + (wn * 16 * NBW + lr) * 128;
   const int NP = ((p.N + 31) >> 5) << 6;                             // destination row pitch (X-layout, elements)
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_shift, 0, p.pre_shift ? p.N * 4 : 0, 0x00020000);     // empty descriptor -> zeros
-  const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_scale, 0, p.pre_scale ? p.N * 4 : 0, 0x00020000);
+  const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_scale, 0, p.pre_scale ? p.N * 4 : 0, 0x00020000);     // empty descriptor -> zeros
 
-  float csum[2][8];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) csum[a][q] = 0.f;
-  auto flush_colsum = [&](int n0) {
-    // the 16 lanes of a quarter (same lq) hold the same 16 channels: butterfly over lr, then lane lr sends channel (lr >> 3, lr & 7) of its
-    // quarter -- one atomic wave-instruction with 64 distinct, contiguous words
-    float mine = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float s = csum[a][q];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-        mine = lr == a * 8 + q ? s : mine;
-        csum[a][q] = 0.f;
-      }
-    atomicAdd(p.colsum + n0 + wn * 64 + 32 * (lr >> 3) + 8 * lq + (lr & 7), mine);
-  };
   __builtin_amdgcn_s_barrier();                                      // stage 0 is resident
-  int g = 0, cslot = 0;
+  int cslot = 0;
   for (int j = 0; j < nmine; ++j) {
     const int tile = tile_of(j);
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * XP_BM, n0 = tn * XP_BN;
-    f32x4 acc[4][4];
+    const int gi = tile / tpg, tl = tile - gi * tpg;
+    const int tm = tl / p.tiles_n, tn = tl - tm * p.tiles_n;
+    const int m0 = tm * XP_BM, n0 = tn * BN;
+    f32x4 acc[NBW][4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < nk; ++ks, ++g) {
-      const char* const st = smem + cslot * XP_STAGE;
-      cslot = cslot == XP_RING - 1 ? 0 : cslot + 1;
-      bf16x8 xh[4], xl[4], wh[4], wl[4];
+    for (int ks = 0; ks < nk; ++ks) {
+      const char* const st = smem + cslot * STAGE;
+      cslot = cslot == RING - 1 ? 0 : cslot + 1;
+      bf16x8 xh[4], xl[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        wh[q] = *reinterpret_cast<const bf16x8*>(st + woff + oh + q * 2048);
-        xh[q] = *reinterpret_cast<const bf16x8*>(st + xoff + oh + q * 2048);
+      for (int q = 0; q < 4; ++q) xh[q] = *reinterpret_cast<const bf16x8*>(st + xoff + oh + q * 2048);
+#pragma unroll
+      for (int h = 0; h < NBW / 4; ++h) {
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wh[q] = *reinterpret_cast<const bf16x8*>(st + woff + oh + (h * 4 + q) * 2048);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) acc[h * 4 + q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], xh[mb], acc[h * 4 + q][mb], 0, 0, 0);
+        if (h == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xl[q] = *reinterpret_cast<const bf16x8*>(st + xoff + ol + q * 2048);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) acc[h * 4 + q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[q], xl[mb], acc[h * 4 + q][mb], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wl[q] = *reinterpret_cast<const bf16x8*>(st + woff + ol + (h * 4 + q) * 2048);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) acc[h * 4 + q][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[q], xh[mb], acc[h * 4 + q][mb], 0, 0, 0);
       }
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nb], xh[mb], acc[nb][mb], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xl[q] = *reinterpret_cast<const bf16x8*>(st + xoff + ol + q * 2048);
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nb], xl[mb], acc[nb][mb], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wl[q] = *reinterpret_cast<const bf16x8*>(st + woff + ol + q * 2048);
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nb], xh[mb], acc[nb][mb], 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue, in registers.  acc[2a][mb][r] = channel cb + r, acc[2a + 1][mb][r] = channel cb + 4 + r of pixel m0 + wm * 64 + mb * 16 + lr,
-    // cb = n0 + wn * 64 + 32a + 8 * lq: head columns 2 * (cb - 8 lq) + 8 lq .. + 7 of the destination row, tails 32 columns further
+    // cb = n0 + wn * 16 NBW + 32a + 8 * lq: head columns 2 * (cb - 8 lq) + 8 lq .. + 7 of the destination row, tails 32 columns further
     const int sg = seg_of(m0);
     const long long drow0 = xp_sel8(p.seg_dst0, sg) - (long long)(sg ? xp_sel8(p.seg_mend, sg - 1) : 0);
-    float cs1[2][8], cb1[2][8];
-    bf16x8 rh[2][4], rl[2][4], mh[2][4];
-    long long eoff[2][4];
+    bf16_t* const gy = XP_GSEL(y);
+    const bf16_t* const gmask = XP_GSEL(mask);
+    float* const gcs = XP_GSEL(colsum);
+    const float* const gshift = XP_GSEL(shift);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)gshift, 0, gshift ? p.N * 4 : 0, 0x00020000);
     bool live[4];
-    // every operand of the tile is requested before the first one is used (two halves x four pixel blocks: 16 + 8 16-B loads per lane)
+    long long prow_[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int cb = n0 + wn * 64 + 32 * a + 8 * lq;
-      const u32x4_t b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4 + 16, 0, 0);
-      const u32x4_t s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4 + 16, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        cb1[a][q] = __uint_as_float(b0[q]); cb1[a][4 + q] = __uint_as_float(b1[q]);
-        cs1[a][q] = __uint_as_float(s0[q]); cs1[a][4 + q] = __uint_as_float(s1[q]);
-      }
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const int m = m0 + wm * 64 + mb * 16 + lr;
-        live[mb] = m < p.M;
-        // (rows past M read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes the
-        // compiler wait for each one where the paths merge; only the stores are predicated)
-        eoff[a][mb] = (drow0 + (live[mb] ? m : p.M - 1)) * NP + 2 * (cb - 8 * lq) + 8 * lq;
-        if (p.res) {
-          rh[a][mb] = *reinterpret_cast<const bf16x8*>(p.res + eoff[a][mb]);
-          rl[a][mb] = *reinterpret_cast<const bf16x8*>(p.res + eoff[a][mb] + 32);
-        }
-        if (p.mask) mh[a][mb] = *reinterpret_cast<const bf16x8*>(p.mask + eoff[a][mb]);
-      }
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wm * 64 + mb * 16 + lr;
+      live[mb] = m < p.M;
+      // (rows past M read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes the
+      // compiler wait for each one where the paths merge; only the stores are predicated)
+      prow_[mb] = (drow0 + (live[mb] ? m : p.M - 1)) * NP;
     }
+    // PG block pairs (32 channels each) at a time: all their operands are requested before the first is used.  Two pairs with 64 accumulator
+    // registers; one with 128 (the 256-column tile), where a second pair's 48 operand registers would spill
+    constexpr int PG = NBW == 4 ? 2 : 1;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int pg = 0; pg < NBW / 2 / PG; ++pg) {
+      float cs1[PG][8], cb1[PG][8], csum[PG][8];
+      bf16x8 rh[PG][4], rl[PG][4], mh[PG][4];
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        if (!live[mb]) continue;
-        float v[8];
+      for (int aa = 0; aa < PG; ++aa) {
+        const int cb = n0 + wn * 16 * NBW + 32 * (pg * PG + aa) + 8 * lq;
+        const int col = 2 * (cb - 8 * lq) + 8 * lq;
+        const u32x4_t b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4 + 16, 0, 0);
+        const u32x4_t s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4 + 16, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = acc[2 * a][mb][q]; v[4 + q] = acc[2 * a + 1][mb][q]; }
-        if (p.pre_scale) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] *= cs1[a][q];
+        for (int q = 0; q < 4; ++q) {
+          cb1[aa][q] = __uint_as_float(b0[q]); cb1[aa][4 + q] = __uint_as_float(b1[q]);
+          cs1[aa][q] = __uint_as_float(s0[q]); cs1[aa][4 + q] = __uint_as_float(s1[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += cb1[a][q];
-        if (p.res) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] += (float)rh[a][mb][q] + (float)rl[a][mb][q];
+        for (int mb = 0; mb < 4; ++mb) {
+          if (p.res) {
+            rh[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col);
+            rl[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col + 32);
+          }
+          if (gmask) mh[aa][mb] = *reinterpret_cast<const bf16x8*>(gmask + prow_[mb] + col);
         }
-        if (p.mask) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = ((float)mh[a][mb][q] > 0.f) ? v[q] : 0.f;
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-        bf16x8 ov, ovl;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { csum[a][q] += v[q]; ov[q] = (bf16_t)v[q]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ovl[q] = (bf16_t)(v[q] - (float)ov[q]);
-        *reinterpret_cast<bf16x8*>(p.y + eoff[a][mb]) = ov;
-        *reinterpret_cast<bf16x8*>(p.y + eoff[a][mb] + 32) = ovl;
       }
-    }
-    // column sums: the lane keeps adding its pixels' values for its 16 channels over ALL tiles of this workgroup that share the column tile
-    // (nearly always all of them: the grid stride is a multiple of tiles_n), and sends them once -- 64 four-lane atomics per TILE into the
-    // same 256 words from every CU ran the layer-3 dgrad 28 % slower than the general kernel's two full-wave atomics per tile
-    if (p.colsum) {
-      const int tn_next = j + 1 < nmine ? (tile_of(j + 1) % p.tiles_n) : -1;
-      if (tn_next != tn) flush_colsum(n0);
+#pragma unroll
+      for (int aa = 0; aa < PG; ++aa) {
+        const int a = pg * PG + aa;
+        const int col = 2 * (n0 + wn * 16 * NBW + 32 * a) + 8 * lq;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) csum[aa][q] = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          if (!live[mb]) continue;
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v[q] = acc[2 * a][mb][q]; v[4 + q] = acc[2 * a + 1][mb][q]; }
+          if (p.pre_scale) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= cs1[aa][q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] += cb1[aa][q];
+          if (p.res) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rh[aa][mb][q] + (float)rl[aa][mb][q];
+          }
+          if (gmask) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ((float)mh[aa][mb][q] > 0.f) ? v[q] : 0.f;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          bf16x8 ov, ovl;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { csum[aa][q] += v[q]; ov[q] = (bf16_t)v[q]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ovl[q] = (bf16_t)(v[q] - (float)ov[q]);
+          *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col) = ov;
+          *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col + 32) = ovl;
+        }
+      }
+      if (gcs) {
+        // column sums of these 32 PG channels: the 16 lanes of a quarter (same lq) hold the same 8 PG channels -- butterfly over lr, then lane lr
+        // sends channel (lr >> 3, lr & 7) of its quarter: ONE atomic wave-instruction with distinct, contiguous words per wave and pair group
+        // (four-lane atomics per channel -- 64 instructions per tile into the same 256 words from every CU -- ran the layer-3 dgrad 28 %
+        // slower than the general kernel, whose tile sends two full-wave atomics)
+        float mine = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < PG; ++aa)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float s = csum[aa][q];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            mine = lr == aa * 8 + q ? s : mine;
+          }
+        if (lr < 8 * PG) atomicAdd(gcs + n0 + wn * 16 * NBW + 32 * (pg * PG + (lr >> 3)) + 8 * lq + (lr & 7), mine);
+      }
     }
   }
 }
+#undef XP_GSEL
 
 int g_x3p_cus[64];
 long long g_x3p_count = 0;
 
+template <int TAPS, int NBW>
+int xp_launch(const X3PArgs& a, int grid, hipStream_t st) {
+  constexpr int STAGE = XP_XBYTES + 32 * NBW * 128, RING = NBW == 4 ? 5 : 3;
+  const size_t lds = (size_t)RING * STAGE;
+  static unsigned long long attr = 0;
+  if (aod_first_on_device(&attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<TAPS, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_x3p_kernel<TAPS, NBW>), dim3(grid), dim3(512), lds, st, a);
+  return 0;
+}
+
 }  // namespace
 
 int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
-  static const char* dbg = getenv("AOD_X3P");
   const char* now = getenv("AOD_X3P");                 // (read per call: tests switch it in-process)
-  (void)dbg;
   if (now && now[0] == '0') return 0;
   if (a.taps != 1 && a.taps != 9) return 0;
-  // 1x1 layers stay with the general kernel unless AOD_X3P_1X1=1: every K-step of theirs needs pixel bytes from beyond the L2 (nothing is
-  // re-read tap after tap), both kernels then run at the ~33 GB/s per CU that path delivers and the persistent form gains nothing
-  // (tools/dbg/x3p_micro.py, profiles/r06_x3p_micro.txt: 38 - 40 us either way on the stage-3 reduce conv, 50 vs 47 us on its expand conv)
-  { const char* pw = getenv("AOD_X3P_1X1"); if (a.taps == 1 && !(pw && pw[0] == '1')) return 0; }
+  // a tile needs a K loop long enough to amortise the one-workgroup-per-CU structure (its epilogue runs beside nothing but the loaders' next
+  // stages): from ~24 K-steps on the persistent form wins -- every 3x3 layer (36+ steps), the 1024 -> 256 reduce / lateral 1x1 convs (32 steps:
+  // 37.2 -> 29.2 us), retina_cls' dgrad (54: 236 -> 228 us) -- below that the general kernel's two workgroups per CU do (the expand 1x1 convs
+  // with 4 - 8 steps: 45.7 vs 50.6 us; retina_reg / retina_L dgrads with 18 / 9: 106 vs 116, 76 vs 88 us; profiles/r06_x3p_micro.txt).
+  // AOD_X3P_MIN_STEPS overrides the threshold.
+  { const char* ms = getenv("AOD_X3P_MIN_STEPS"); if (a.taps * (a.C >> 6) < (ms ? atoi(ms) : 24)) return 0; }
   if (a.taps == 9 && a.S != 3) return 0;
-  if (a.N % XP_BN != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
+  if (a.N % 128 != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
   if (a.transposed && a.stride != 1) return 0;
-  if (a.colsum && deterministic_colsum) return 0;      // ordered column sums stay with the general kernel (determinism.hip)
+  if (deterministic_colsum) return 0;                  // ordered column sums stay with the general kernel (determinism.hip)
   if ((long long)a.K * 2 * a.N >= 0x7fffffffll) return 0;
   long long prev = 0;
   for (int i = 0; i < a.nseg; ++i) {
@@ -353,15 +387,18 @@ int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
   }
   // one 8-wave workgroup per CU: worth it from ~ a round of the chip on; below that the general kernel's smaller tiles fill more CUs
   const char* mint = getenv("AOD_X3P_MIN_TILES");
-  const long long tiles = (long long)((a.M + XP_BM - 1) / XP_BM) * (a.N / XP_BN);
+  const int ng = a.ngroups > 1 ? a.ngroups : 1;
+  const long long tiles = (long long)((a.M + XP_BM - 1) / XP_BM) * (a.N / 128) * ng;
   if (tiles < (mint ? atoll(mint) : 192)) return 0;
   return 1;
 }
 
 int aod_conv_x3p_launch(const X3PArgs& a0, hipStream_t st) {
   X3PArgs a = a0;
-  a.tiles_m = (a.M + XP_BM - 1) / XP_BM;
-  a.tiles_n = a.N / XP_BN;
+  if (a.ngroups < 1) {
+    a.ngroups = 1;
+    a.grp[0].x = a.x; a.grp[0].w = a.w; a.grp[0].y = a.y; a.grp[0].shift = a.pre_shift; a.grp[0].mask = a.mask; a.grp[0].colsum = a.colsum;
+  }
   { const char* r = getenv("AOD_X3P_ROT"); a.rot = r ? atoi(r) : 0; }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
@@ -370,17 +407,17 @@ int aod_conv_x3p_launch(const X3PArgs& a0, hipStream_t st) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     g_x3p_cus[dev] = n;
   }
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = ntiles < g_x3p_cus[dev] ? ntiles : g_x3p_cus[dev];
-  const size_t lds = (size_t)XP_RING * XP_STAGE;
-  static unsigned long long attr1 = 0, attr9 = 0;
-  if (a.taps == 1) {
-    if (aod_first_on_device(&attr1)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(conv_x3p_kernel<1>, dim3(grid), dim3(512), lds, st, a);
-  } else {
-    if (aod_first_on_device(&attr9)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(conv_x3p_kernel<9>, dim3(grid), dim3(512), lds, st, a);
-  }
+  const int ncu = g_x3p_cus[dev];
+  a.tiles_m = (a.M + XP_BM - 1) / XP_BM;
+  // 256-column tiles (half the pixel bytes per MFMA, twice the MFMAs per barrier) when they still give every CU work; AOD_X3P_BN=128 / 256 forces
+  const char* fbn = getenv("AOD_X3P_BN");
+  bool wide = a.N % 256 == 0 && (long long)a.tiles_m * (a.N / 256) * a.ngroups >= (long long)ncu * 3 / 4;
+  if (fbn) wide = a.N % 256 == 0 && atoi(fbn) == 256;
+  a.tiles_n = a.N / (wide ? 256 : 128);
+  const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.ngroups;
+  const int grid = (int)(ntiles < ncu ? ntiles : ncu);
+  if (a.taps == 1) { if (wide) xp_launch<1, 8>(a, grid, st); else xp_launch<1, 4>(a, grid, st); }
+  else { if (wide) xp_launch<9, 8>(a, grid, st); else xp_launch<9, 4>(a, grid, st); }
   AOD_LAUNCH_CHECK();
   __atomic_add_fetch(&g_x3p_count, 1, __ATOMIC_RELAXED);
   return 0;

@@ -90,12 +90,14 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
                   aod_stream_t stream);
 
 /* Reference-precision (x3) launches of aod_conv2d(_ws) with an X-layout destination, N % 128 == 0, a 1x1 or 3x3 filter (forward at any
- * stride, dgrad at stride 1), segments that are whole multiples of 128 rows (but the last) and at least ~192 tiles of 128 x 128 -- the
- * conv1 / conv2 / conv3 / downsample convs of the trainable backbone stages and the neck's laterals / 3x3 convs
- * (mmdet/models/backbones/resnet.py:262-301, necks/fpn.py:151-202) and their dgrads -- run on a persistent producer / consumer kernel
+ * stride, dgrad at stride 1), segments that are whole multiples of 128 rows (but the last), at least ~192 tiles of 128 x 128 and at least
+ * 24 K-steps (of 32 channels x 1 tap) per tile -- the 3x3 convs and the deep reduce / lateral 1x1 convs of the trainable backbone stages and
+ * of the neck (mmdet/models/backbones/resnet.py:262-301, necks/fpn.py:151-202), their dgrads, and the dgrad of retina_cls
+ * (dense_heads/Lambda_L2.py:52) -- run on a persistent producer / consumer kernel
  * (csrc/conv_x3p.hip: loader waves stream the operand tiles through a four-slot LDS ring, consumer waves only issue MFMAs and finish the
  * tile from registers).  Results are bit-identical to the general kernel (the optional column sums are fp32 atomics in both).  Environment
- * AOD_X3P=0 keeps every launch on the general kernel, AOD_X3P_MIN_TILES overrides the fill threshold; with aod_set_deterministic(1) launches
+ * AOD_X3P=0 keeps every launch on the general kernel, AOD_X3P_MIN_TILES / AOD_X3P_MIN_STEPS override the two thresholds, AOD_X3P_GROUPED=1
+ * also sends the grouped tower launches of aod_conv2d_grouped there (128 x 256 tiles; level with the 256 x 256 tile); with aod_set_deterministic(1) launches
  * that carry column sums stay on the general kernel (ordered sums).  aod_conv_x3p_count(): launches the persistent kernel has taken in this
  * process (tests / bench bookkeeping). */
 int64_t aod_conv_x3p_count(void);

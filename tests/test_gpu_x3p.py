@@ -73,7 +73,7 @@ def test_x3p_forward_and_dgrad_equal_the_general_kernel(case, monkeypatch):
     res = rnd(B, O, oh, ow) if c['res'] else None
     gy = rnd(B, O, oh, ow)
     monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
-    monkeypatch.setenv('AOD_X3P_1X1', '1')          # (the product sends only the 3x3 layers here; the kernel itself takes both)
+    monkeypatch.setenv('AOD_X3P_MIN_STEPS', '1')      # (the product sends only tiles of >= 24 K-steps here; the kernel itself takes any)
     monkeypatch.setattr(ho, 'SPLITK', False)
     out = {}
     for mode in ('1', '0'):
@@ -123,6 +123,7 @@ def test_x3p_pyramid_segments_and_mask_epilogue(monkeypatch):
     g = torch.Generator(device='cuda').manual_seed(12)
     rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
     monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setenv('AOD_X3P_MIN_STEPS', '1')
     monkeypatch.setattr(ho, 'SPLITK', False)
     c1, c2 = Conv2d(256, 256, 3, padding=1).cuda(), Conv2d(256, 128, 3, padding=1).cuda()
     with torch.no_grad():
@@ -174,3 +175,59 @@ def test_x3p_repeated_launches_are_bit_stable(monkeypatch):
                 junk.random_(0, 255)                    # (evict the operands now and then: cold and warm loads take different times)
             y = AF.as_rows(AF.conv_bn_act(x, w, bias=bias, stride=1, pad=1, relu=True))
             assert torch.equal(y, first), i
+
+
+@pytest.mark.parametrize('bn_cols', ['256', '128'])
+def test_x3p_grouped_tower_launches_equal_the_256_tile(bn_cols, monkeypatch):
+    """The head towers' grouped launches (cls / reg convs of one depth in one grid, Lambda_L2.py:44-51,85-94; aod_conv2d_grouped) on the
+    persistent kernel -- 128 x 256 tiles, the tile index names the group -- against the 256 x 256 eight-wave tile they ran on: forward with bias +
+    ReLU, grouped dgrad with the producers' ReLU masks and column sums; a pyramid whose levels are multiples of 128 rows.  Identical bits (the
+    column sums to rounding), in both column-tile widths of the kernel."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import lib
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    g = torch.Generator(device='cuda').manual_seed(21)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    B, C = 4, 256
+    shapes = [(32, 32), (16, 16), (8, 8), (4, 8), (3, 5)]                 # 4 096 + 1 024 + 256 + 128 rows, and a ragged last level (60 rows)
+    convs = []
+    for _ in range(4):
+        c = Conv2d(C, C, 3, padding=1).cuda()
+        with torch.no_grad():
+            c.weight.copy_(rnd(C, C, 3, 3) * 0.02); c.bias.copy_(rnd(C) * 0.1)
+        convs.append(c)
+    _, slots = AF.pyramid_buffer([(B, h, w) for h, w in shapes], C, 'cuda')
+    feats = []
+    for sl, (h, w) in zip(slots, shapes):
+        sl.copy_(AF.as_nchw(_x(rnd(B, C, h, w)), B, h, w))
+        feats.append(sl)
+    monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setenv('AOD_X3P_BN', bn_cols)
+    monkeypatch.setenv('AOD_GROUP_TOWERS', '1')
+    monkeypatch.setenv('AOD_X3P_GROUPED', '1')         # (opt-in in the product: level with the 256 x 256 tile, see conv.hip)
+    monkeypatch.setattr(ho, 'SPLITK', False)
+
+    def run(mode):
+        monkeypatch.setenv('AOD_X3P', mode)
+        n0 = lib.aod_conv_x3p_count()
+        xs = [f.detach().requires_grad_() for f in feats]
+        a, b = zip(*[AF.fork(x, 2) for x in xs])
+        ya, yb = AF.conv_pair_act(list(a), list(b), convs[0], convs[1], sole_consumer=False)
+        za, zb = AF.conv_pair_act(ya, yb, convs[2], convs[3], sole_consumer=True)
+        for c in convs:
+            c.weight.grad = c.bias.grad = None
+        gs = [AF.as_nchw(_x(torch.randn(B, C, h, w, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5 + i))), B, h, w)
+              for i, (h, w) in enumerate(shapes)]
+        torch.autograd.backward(list(za) + list(zb), gs + gs)
+        torch.cuda.synchronize()
+        took = lib.aod_conv_x3p_count() - n0
+        return ([t.detach().clone() for t in list(za) + list(zb)], [x.grad.clone() for x in xs],
+                [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs], took)
+    o1, gx1, gw1, took1 = run('1')
+    o0, gx0, gw0, took0 = run('0')
+    assert took0 == 0 and took1 >= 3, (took0, took1)          # two grouped forwards + at least the grouped dgrad of the second depth
+    assert all(torch.equal(u, v) for u, v in zip(o1, o0))
+    assert all(torch.equal(u, v) for u, v in zip(gx1, gx0))
+    for u, v in zip(gw1, gw0):
+        assert _err(u, v) < 2e-6

@@ -77,32 +77,43 @@ for name, C, O, H, W, R, st, res in SHAPES:
         Mout, oh, ow = Mrows, 1, Mrows // B
     flop = 2.0 * Mout * O * C * R * R
     row = [f'{name:44s} M={Mout:6d}']
-    outs = {}
-    for mode in MODES:
+    outs, took = {}, {}
+
+    def setmode(mode):
         os.environ['AOD_X3P'] = mode[0]
         os.environ['AOD_X3P_ROT'] = mode[2:] if len(mode) > 1 else '0'
         os.environ['AOD_X3P_MIN_TILES'] = os.environ.get('MIN_TILES', '1')
-        os.environ['AOD_X3P_1X1'] = '1'
+        os.environ['AOD_X3P_MIN_STEPS'] = os.environ.get('MIN_STEPS', '1')
+    for mode in MODES:
+        setmode(mode)
         for _ in range(3):
             f()
         n0 = lib.aod_conv_x3p_count()
         f()
-        took = lib.aod_conv_x3p_count() - n0
+        took[mode] = lib.aod_conv_x3p_count() - n0
         outs[mode] = holder['y'].clone()
-        ts = {}
-        for kind in ('warm', 'cold'):
-            reps = 20
-            evs = []
-            for i in range(reps):
+    # GPU time per launch: N launches queued BEHIND a spinning kernel (the host's ~40 us per call would otherwise be what a short kernel's
+    # events measure), modes taking turns (clock / thermal drift), warm = operands just used, cold = a 512 MB write between the groups
+    ts = {m: {'warm': [], 'cold': []} for m in MODES}
+    NL = 8
+    for kind in ('warm', 'cold'):
+        for rep in range(7):
+            for mode in MODES:
+                setmode(mode)
                 if kind == 'cold':
                     junk.random_(0, 255)
+                torch.cuda._sleep(3_000_000)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); f(); e1.record()
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            t = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-            ts[kind] = t[len(t) // 2]
-        row.append(f'x3p={mode:4s}{"*" if took else " "} warm {ts["warm"]:7.1f} us ({flop / ts["warm"] * 1e-6:5.0f} TF) cold {ts["cold"]:7.1f} us')
+                e0.record()
+                for _ in range(NL if kind == 'warm' else 1):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:
+                    ts[mode][kind].append(e0.elapsed_time(e1) * 1e3 / (NL if kind == 'warm' else 1))
+    for mode in MODES:
+        med = {k: sorted(v)[len(v) // 2] for k, v in ts[mode].items()}
+        row.append(f'x3p={mode:5s}{"*" if took[mode] else " "} warm {med["warm"]:7.1f} us ({flop / med["warm"] * 1e-6:5.0f} TF) cold {med["cold"]:7.1f} us')
     row.append('bits equal' if all(torch.equal(outs[MODES[0]], o) for o in outs.values()) else 'BITS DIFFER')
     lines.append('  '.join(row))
     print(lines[-1], flush=True)
