@@ -64,6 +64,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--shapes', default=None, help='write the per-shape conv breakdown of the instrumented step to this file')
     ap.add_argument('--serial-scores', action='store_true', help='timed loop: read (and, for N > 1, all-gather) the scores after every step instead of once after the loop')
+    ap.add_argument('--rotate', type=int, default=4, help='distinct resident train batches / pool batches the timed loop cycles through (1: one batch, '
+                    'written straight into the graphs\' static input buffers)')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel from Python instead of replaying HIP graphs')
     return ap.parse_args()
 
@@ -299,11 +301,18 @@ def main():
     comm = dict(backend=None, ranks=1)
     if world > 1:
         # the number of ranks a COLLECTIVE actually spanned (one all-reduce of ones over the freshly initialised group), not the launcher's claim
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)
+        # -- and WHICH ranks: a presence vector summed over the group names the absent ones in the failure message (before any timing starts)
+        present = torch.zeros(max(args.gpus, dist.get_world_size()), device=dev)
+        present[rank] = 1
+        dist.all_reduce(present)
         torch.cuda.synchronize()
-        comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=int(ones.item()))
-        assert comm['ranks'] == args.gpus == dist.get_world_size(), (comm, args.gpus, dist.get_world_size())
+        seen = [i for i, v in enumerate(present.tolist()) if v > 0]
+        comm = dict(backend='gloo (debug: all ranks on one GPU)' if one_gpu else 'nccl (RCCL)', ranks=len(seen))
+        missing = sorted(set(range(args.gpus)) - set(seen))
+        if comm['ranks'] != args.gpus or dist.get_world_size() != args.gpus or missing or max(present.tolist()) > 1:
+            raise RuntimeError(f'bench.py --gpus {args.gpus}: the {comm["backend"]} group spans ranks {seen} (world size {dist.get_world_size()}); '
+                               f'missing ranks: {missing or "none"}; ranks counted twice: {[i for i, v in enumerate(present.tolist()) if v > 1] or "none"} '
+                               '-- launch one process per GPU (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)')
     from aod_meh_hua_amd import functional as AF
     from aod_meh_hua_amd import hipops as ho
     from aod_meh_hua_amd.parallel import GradSync, broadcast_model, gather_scores
@@ -314,7 +323,11 @@ def main():
     # The pool is scored with a FROZEN copy of the model whose classification head is "trained-like" (SURVEY 8d C3): the training phase
     # of the bench fits random labels, which flattens any synthetic confidence within a few SGD steps, and random-init confidence is
     # ~0.05 everywhere -- either way every image would score 0 and the HUA sampler would idle.  Same architecture, same kernels.
-    pool = synth_batch(B, H, W, dev, seed=1020 + rank, classes=cd['classes'])
+    R = max(1, args.rotate)
+    # (VERDICT r5 "bench realism": the loop cycles through R different batches -- other ground-truth counts / boxes, other confidence maps -- so
+    # that assignment, loss reductions and the HUA pair count do not see one pattern for the whole run)
+    pools = [synth_batch(B, H, W, dev, seed=1020 + rank + 1000 * k, classes=cd['classes']) for k in range(R)]
+    pool = pools[0]
     pool_model = copy.deepcopy(model)
     cal_k, cal_frac = calibrate_head(pool_model, pool['img'])
     broadcast_model(pool_model)               # every rank scores with rank 0's calibrated head
@@ -324,12 +337,13 @@ def main():
 
     opt, opt_L = make_optimizers(model, cfg)
     gsync = GradSync()
-    data = synth_batch(B, H, W, dev, seed=20 + rank, classes=cd['classes'])
+    datas = [synth_batch(B, H, W, dev, seed=20 + rank + 1000 * k, classes=cd['classes']) for k in range(R)]
+    data = datas[0]
     do_train, do_score = 'train' in args.mode, 'score' in args.mode
     phases = int(do_train) + int(do_score)
 
     from aod_meh_hua_amd.graphs import GraphedScore, GraphedTrainStep
-    data_dev = dict(data, gt_bboxes=[b.to(dev) for b in data['gt_bboxes']], gt_labels=[l.to(dev) for l in data['gt_labels']])
+    data_devs = [dict(d_, gt_bboxes=[b.to(dev) for b in d_['gt_bboxes']], gt_labels=[l.to(dev) for l in d_['gt_labels']]) for d_ in datas]
 
     def barrier():
         if world > 1:
@@ -350,29 +364,32 @@ def main():
             defer=True (score-only loops): like the pool loop of apis/test.py, the scores are not read before the loop's end, so the selection
             half of batch k (second stream) runs beside the conv half of batch k + 1 (graphs.GraphedScore)."""
             graph = state['graph_ok'] if graph is None else graph
+            k_ = it % R
             if graph:
                 if do_train:
-                    gstep(data)
+                    # R > 1: batch k_ is copied into the graph's static input buffer (one 50 MB device copy) and its ground truth packed and
+                    # uploaded, as for a loader's batch; R == 1: `data` IS the static buffer (see below)
+                    gstep(data if R == 1 else datas[k_])
                 if do_score:
                     ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                    # the synthetic pool batch is resident in HBM (contract): it sits in the static input buffer of EACH of the scoring graph's
-                    # alternating slots -- where the on-device pool generator / a loader's H2D copy writes a real batch (graphs.static_image) --
-                    # so no 50 MB device-to-device copy rides in the step
-                    img = pool['img']
-                    si = gscore.static_image(tuple(img.shape))
+                    # R == 1: the synthetic pool batch is resident in HBM (contract): it sits in the static input buffer of EACH of the scoring
+                    # graph's alternating slots -- where the on-device pool generator / a loader's H2D copy writes a real batch
+                    # (graphs.static_image) -- so no 50 MB device-to-device copy rides in the step; R > 1: batch k_ is copied in per step
+                    img = (pool if R == 1 else pools[k_])['img']
+                    si = gscore.static_image(tuple(img.shape)) if R == 1 else None
                     if si is not None:
                         if si.data_ptr() not in state['filled']:
                             si.copy_(img)
                             state['filled'].add(si.data_ptr())
                         img = si
-                    _, unc = gscore(img, pool['img_metas'], ids, defer=defer)
+                    _, unc = gscore(img, pools[k_]['img_metas'], ids, defer=defer)
                     if world > 1 and not defer:
                         gather_scores(unc, B * world)
                     return unc
                 return None
             if do_train:
                 model.train()
-                out, head_out, feat_out, prev = model.train_step(data_dev, Labeled=True, Pseudo=False)
+                out, head_out, feat_out, prev = model.train_step(data_devs[k_], Labeled=True, Pseudo=False)
                 opt.zero_grad()
                 out['loss'].backward()
                 pending = gsync.start(opt.param_groups[0]['params'])       # overlaps the MEH step (disjoint parameters, detached inputs)
@@ -387,7 +404,7 @@ def main():
                 pool_model.eval()
                 with torch.no_grad():
                     ids = torch.arange(B, device=dev) + (it * world + rank) * B
-                    _, unc = pool_model(img=[pool['img']], img_metas=[pool['img_metas']], image_ids=ids, **SCORE_KW)
+                    _, unc = pool_model(img=[pools[k_]['img']], img_metas=[pools[k_]['img_metas']], image_ids=ids, **SCORE_KW)
                     unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
                     if world > 1:
                         gather_scores(unc, B * world)
@@ -409,7 +426,7 @@ def main():
             # the synthetic batches are resident in HBM (contract); hand the graphs their OWN static input buffers as the batch -- what a loader
             # that fills graphs.static_image() directly does -- so that no 50 MB device-to-device copy per phase rides in the step
             nonlocal data, pool
-            if do_train and getattr(gstep, 'cur', None) and tuple(gstep.cur['static']['img'].shape) == tuple(data['img'].shape):
+            if R == 1 and do_train and getattr(gstep, 'cur', None) and tuple(gstep.cur['static']['img'].shape) == tuple(data['img'].shape):
                 data = dict(data, img=gstep.cur['static']['img'])
         # The timed loop calls the scoring graph the way the product's pool loop does (apis/test.py single_gpu_uncertainty): scores are
         # deferred -- the selection half of batch k (<= 16 workgroups) runs on its own stream beside whatever follows --, read after the
@@ -610,6 +627,9 @@ def main():
                                 global_batch=B * world, image_size=[H, W], num_classes=cd['classes'], backbone=f'ResNet-{cd["depth"]}',
                                 parallelism=f'dp{world}', collective_ranks=comm['ranks'], collective_backend=comm['backend'],
                                 phases=args.mode, launch='hip-graph replay' if use_graph else 'eager',
+                                data_rotation=(f'{R} distinct resident train batches and {R} pool batches, cycled step by step through the graphs\' static input '
+                                               'buffers (one 50 MB device copy + the ground-truth upload per phase and step, inside the timed region)' if R > 1
+                                               else 'one resident train batch and one pool batch, placed in the static input buffers once'),
                                 scores_read=('after the loop (the pool loop\'s deferred form: selection half of batch k on its own stream; one sync + one all-gather '
                                              'inside the timed region)' if main_m['deferred'] else 'after every step'),
                                 ms_per_step_scores_read_every_step=main_m['serial_ms'],

@@ -155,3 +155,56 @@ def test_deferred_scoring_survives_the_caller_recycling_its_inputs(pool_model, p
     for k in range(NB):
         assert torch.equal(got[k], ref[k]), (k, got[k], ref[k])
     assert float(torch.stack(ref).abs().sum()) > 0
+
+
+def test_512_image_pool_in_both_partitions_matches_one_rank_and_the_oracle(pool_model, monkeypatch):
+    """BASELINE configs[3] at a size the suite can afford (512 on-device images of 256 x 256 instead of 10 000 of 512 x 512; the 10 k run is
+    `bench.py --mode pool`, profiles/r06_bench_pool10k.json): the score vector of the product's pool loop is the SAME BYTES when one rank scores
+    the pool and when two ranks score it in the contiguous and in the interleaved partition (their shards concatenated / scattered like the
+    all-gather does: tests/test_distributed_cpu.py covers the collective), and eight images spread over the pool agree with the CPU oracle run
+    on the same weights, images and Philox stream (tolerances of tests/test_gpu_precision_end_to_end.py)."""
+    import hashlib
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd.apis import test as apis_test
+    from aod_meh_hua_amd.apis.test import single_gpu_uncertainty
+    from aod_meh_hua_amd.datasets import DevicePhiloxPool
+    from aod_meh_hua_amd.parallel import shard_range
+    from oracle import model as omodel
+    AF.set_precision('bf16x3')
+    N, S, bs = 512, 256, 16
+    dev = torch.device('cuda', 0)
+    ds = DevicePhiloxPool(N, (S, S), seed=20)
+    digest = lambda u: hashlib.sha256(np.ascontiguousarray(u, np.float32).tobytes()).hexdigest()[:16]
+    with torch.no_grad():
+        one = single_gpu_uncertainty(pool_model, Loader(ds, bs), **KW).cpu().numpy()
+        monkeypatch.setattr(apis_test, 'gather_scores', lambda local, n_total: local)
+        parts = []
+        for r in range(2):
+            monkeypatch.setattr(apis_test, 'get_dist_info', lambda r=r: (r, 2))
+            parts.append(single_gpu_uncertainty(pool_model, Loader(ds, bs), **KW).cpu().numpy())
+            lo, hi, _ = shard_range(N, r, 2)
+            assert parts[-1].shape == (hi - lo,)
+        monkeypatch.setenv('AOD_POOL_SHARD', 'interleaved')
+        monkeypatch.setattr(apis_test, 'gather_scores_indexed', lambda local, idx, n_total, per=None: (local, idx))
+        inter = np.full(N, np.nan, np.float32)
+        for r in range(2):
+            monkeypatch.setattr(apis_test, 'get_dist_info', lambda r=r: (r, 2))
+            v, idx = single_gpu_uncertainty(pool_model, Loader(ds, bs), **KW)
+            inter[np.array(idx)] = v.cpu().numpy()
+        monkeypatch.undo()
+    assert one.shape == (N,) and np.isfinite(one).all() and (one > 0).sum() >= N // 2
+    assert digest(one) == digest(np.concatenate(parts)) == digest(inter), (digest(one), digest(np.concatenate(parts)), digest(inter))
+    # ---- eight images against the oracle
+    ids = [0, 65, 130, 195, 260, 325, 390, 511]
+    imgs = ds.device_batch(ids, dev)['img'][0].cpu()
+    sd = {k: v.detach().float().cpu() for k, v in pool_model.state_dict().items()}
+    metas = [dict(img_shape=(S, S, 3), scale_factor=np.ones(4, np.float32)) for _ in ids]
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    o = omodel.score_images(sd, imgs, [m['img_shape'] for m in metas], [m['scale_factor'] for m in metas], sampler='philox', seed=20,
+                            image_ids=np.array(ids))
+    ref, got = np.array(o['unc'], np.float64), one[ids].astype(np.float64)
+    assert np.array_equal(ref == 0, got == 0), (ref, got)
+    nz = ref > 0
+    assert nz.sum() >= 4
+    dev_ = np.abs(got[nz] - ref[nz]) / ref[nz]
+    assert dev_.max() < 1e-2 and np.median(dev_) < 1e-3, dev_
