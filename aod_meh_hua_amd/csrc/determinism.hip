@@ -72,13 +72,22 @@ float* aod_det_scratch(size_t floats) {
   if (!g_det) return nullptr;
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return nullptr;
-  if (!g_scratch[d] && hipMalloc((void**)&g_scratch[d], SCRATCH_FLOATS * sizeof(float)) != hipSuccess) g_scratch[d] = nullptr;
+  if (!g_scratch[d]) {
+    // lazily, for a device that never saw aod_set_deterministic.  The first request may come from inside a stream capture, where a plain
+    // hipMalloc is an illegal call that invalidates the graph being built: the allocation runs under the RELAXED capture mode of
+    // this thread (what torch's caching allocator does around its own hipMalloc), which permits it and leaves the capture intact
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (hipMalloc((void**)&g_scratch[d], SCRATCH_FLOATS * sizeof(float)) != hipSuccess) g_scratch[d] = nullptr;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+  }
   if (!g_scratch[d] || floats > SCRATCH_FLOATS) {
-    static bool warned = false;
-    if (!warned) {
-      warned = true;
-      fprintf(stderr, "[libaodhip] deterministic mode: %zu partial sums do not fit the %zu-float scratch of device %d (or it could not be allocated): "
-                      "this launch falls back to fp32 atomics and the run is NOT bit-repeatable\n", floats, (size_t)SCRATCH_FLOATS, d);
+    static unsigned long long warned = 0;             // one bit per device
+    const unsigned long long bit = 1ull << d;
+    if (!(__atomic_fetch_or(&warned, bit, __ATOMIC_RELAXED) & bit)) {
+      fprintf(stderr, "[libaodhip] deterministic mode: %zu partial sums do not fit the %zu-float scratch of device %d (or it could not be allocated -- "
+                      "call aod_set_deterministic(1) on every device BEFORE capturing graphs): this launch falls back to fp32 atomics and the run is NOT "
+                      "bit-repeatable\n", floats, (size_t)SCRATCH_FLOATS, d);
     }
     return nullptr;
   }

@@ -1339,11 +1339,26 @@ class RetinaLossLevelsFn(Function):
         g_rows = None
         if g_noR is not None:              # (nobody on the training path differentiates the rows: train_step detaches them)
             g2 = g_sums[2] if div is None else g_sums[2] / div[2]
-            g_rows = (g_noR.float() + torch.repeat_interleave(g2, torch.tensor(level_rows, device=dev))).contiguous()
+            # (the per-level row counts as a cached DEVICE tensor and an explicit output size: no host-to-device copy, no host sync --
+            # the expression stays capturable in a HIP graph)
+            g_rows = (g_noR.float() + torch.repeat_interleave(g2, _level_rows_dev(level_rows, dev), output_size=sum(level_rows))).contiguous()
         gc = torch.empty(cls_rows.shape[0] // A, AC, dtype=torch.float32, device=dev)
         gb = torch.empty(cls_rows.shape[0] // A, A4, dtype=torch.float32, device=dev)
         ho.edl_focal_l1_levels_bwd(cls_rows, labels, label_w, box_rows, bbox_t, bbox_w, level_rows, g_sums, g_rows, gc, gb, A, gamma, alpha, divisors=div)
         return gc.view(cls_rows.shape), gb.view(box_rows.shape), None, None, None, None, None, None, None, None, None
+
+
+_LEVEL_ROWS_DEV = {}
+
+
+def _level_rows_dev(level_rows, dev):
+    key = (tuple(level_rows), dev)
+    t = _LEVEL_ROWS_DEV.get(key)
+    if t is None:
+        if len(_LEVEL_ROWS_DEV) > 64:
+            _LEVEL_ROWS_DEV.clear()
+        t = _LEVEL_ROWS_DEV[key] = torch.tensor(list(level_rows), device=dev)
+    return t
 
 
 class MEHLossLevelsFn(Function):

@@ -398,13 +398,28 @@ SLAB_WGRAD = os.environ.get('AOD_WGRAD_SLABS', '1') != '0'      # debug switch: 
 
 def _slab_scratch(n, device):
     """Scratch for the wgrad slabs (at most 512 workgroups x 64 KB = 33.5 MB per launch), one per (device, stream): a launch and the unpack
-    that reads its slabs are ordered by their stream, launches of two streams must not share one; need not be initialised."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _SLABS.get(key)
+    that reads its slabs are ordered by their stream, launches of two streams must not share one; need not be initialised.  A buffer first
+    requested DURING a graph capture lives in that graph's private pool: it is keyed by the capture as well and never handed to eager code or
+    to another capture; the cache is a small LRU -- streams come and go (capture side streams, the scoring pipeline)."""
+    cap = torch.cuda.is_current_stream_capturing()
+    key = (device, torch.cuda.current_stream(device).cuda_stream, _capture_tag() if cap else None)
+    buf = _SLABS.pop(key, None)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, (1 << 23) + (1 << 21)), dtype=torch.float32, device=device)
-        _SLABS[key] = buf
+    _SLABS[key] = buf                                   # (re-inserted: most recently used last)
+    while len(_SLABS) > 12:
+        # (graphs pin what their kernels captured -- graphs._pin_caches holds the dict's values at capture time -- so dropping the oldest
+        # entry here cannot free memory a live graph points at)
+        _SLABS.pop(next(iter(_SLABS)))
     return buf[:n]
+
+
+_CAPTURE_SEQ = [0]
+
+
+def _capture_tag():
+    """changes from one graph capture to the next: reset_zero_arena() brackets every capture in graphs.py and bumps it"""
+    return _CAPTURE_SEQ[0]
 
 
 def _dw_scratch(n, device):
@@ -435,8 +450,9 @@ def zeros_f32(n, device):
 
 def reset_zero_arena():
     """Drop the current arena: the next zeros_f32 call allocates (and fills) a fresh one.  Used around HIP-graph capture so that every
-    accumulator used by captured kernels is zeroed by a captured fill."""
+    accumulator used by captured kernels is zeroed by a captured fill.  (Also the boundary between captures for _slab_scratch.)"""
     _ZEROS.clear()
+    _CAPTURE_SEQ[0] += 1
 
 
 def unpack_wgrad(dw_orsi, O, I, grad_oihw=None, accumulate=False, clear=None, scale=None, w_oihw=None, want_wdot=False, bn=None, wdot=None):
