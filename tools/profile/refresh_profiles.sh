@@ -1,8 +1,8 @@
 #!/bin/bash
 # Every measured artefact the docs / the bench line cite, from ONE build on ONE GPU box:
-#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r05'
+#   gpurun --timeout 2400 -- 'bash tools/profile/refresh_profiles.sh r06'
 # then copy gpurun_out/profiles/* into profiles/ and commit.  (rocprofv3: kernel trace + stats in one pass; --pmc passes separately.)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles
@@ -24,6 +24,11 @@ python3 $R/bench.py --precision bf16 --mode pool --pool 10000 --no-cpu-baseline 
 python3 $R/bench.py --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-check --shapes $O/${TAG}_conv_shapes_one_step_bf16.txt > $O/${TAG}_bench_bf16.json 2>/dev/null
 python3 $R/bench.py --config r101coco --steps 6 --warmup 2 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_r101coco.json 2>/dev/null
 AOD_BENCH_ONE_GPU=1 python3 $R/bench.py --gpus 2 --steps 6 --warmup 2 --batch 8 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_2ranks_one_gpu.json 2>/dev/null
+AOD_BENCH_ONE_GPU=1 python3 $R/bench.py --gpus 2 --mode pool --pool 2000 --no-cpu-baseline --no-precision-check > $O/${TAG}_bench_2ranks_one_gpu_pool.json 2>/dev/null
+# 3b. the persistent x3 conv kernel against the general one, launch by launch (GPU-bound, interleaved); same-box step-level A/B
+python3 $R/tools/dbg/x3p_micro.py > /dev/null 2>&1; cp $R/gpurun_out/x3p_micro.txt $O/${TAG}_x3p_micro.txt
+MODES=0,1,1r768 python3 $R/tools/dbg/x3p_grouped_micro.py > $O/${TAG}_x3p_grouped_micro.txt 2>/dev/null
+for m in 0 1 0 1; do AOD_X3P=$m python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-precision-check 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']; print('AOD_X3P=$m', d['value'], 'img/s', d['ms_per_step'], 'ms/step  train', d['phase_rates']['train_ms_per_batch'], 'score', d['phase_rates']['score_ms_per_batch'], ' backbone_fpn ms', r['backbone_fpn']['total']['ms'], 'frac', r['backbone_fpn']['total']['frac'], ' heads ms', r['heads']['total']['ms'])" >> $O/${TAG}_x3p_step_ab.txt; done
 # 4. PMC passes (tagged with the build digest; bench.py merges them only for this build)
 bash $R/tools/profile/pmc_passes.sh > $O/${TAG}_pmc_passes.txt 2>&1
 ls -la $O
