@@ -1,6 +1,6 @@
 #!/bin/bash
 # What do the conv kernels' waves wait on?  Separate rocprofv3 --pmc passes (kernel trace only) of three eager bench steps; per kernel the averages of
-# the SQ wait / busy counters.   gpurun -- 'bash tools/profile/pmc_stalls.sh'  ->  gpurun_out/profiles/r05_pmc_stalls.txt
+# the SQ wait / busy counters.   gpurun -- 'bash tools/profile/pmc_stalls.sh'  ->  gpurun_out/profiles/r06_pmc_stalls.txt
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 D=$R/gpurun_out/pmc_stalls
@@ -14,7 +14,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
   rocprofv3 --pmc $grp --kernel-trace -d $D/p$i -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-precision-check --no-graph --phase-iters 2 > $D/bench$i.json 2> $D/err$i.txt
   tail -2 $D/err$i.txt | cut -c1-200
 done
-python3 - <<PY > $R/gpurun_out/profiles/r05_pmc_stalls.txt
+python3 - <<PY > $R/gpurun_out/profiles/r06_pmc_stalls.txt
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob('$D/p*/**/*counter_collection.csv', recursive=True):
@@ -23,7 +23,7 @@ for f in glob.glob('$D/p*/**/*counter_collection.csv', recursive=True):
         agg[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 names = sorted({c for d in agg.values() for c in d})
 print('per-launch averages of SQ counters (rocprofv3 --pmc, eager bench steps); ratios to SQ_WAVE_CYCLES where that makes sense')
-keep = [k for k in agg if any(x in k for x in ('conv_igemm', 'conv_wgrad', 'bottleneck', 'halo_x3', 'stem_pool'))]
+keep = [k for k in agg if any(x in k for x in ('conv_igemm', 'conv_wgrad', 'bottleneck', 'halo_x3', 'stem_pool', 'conv_x3p'))]
 for k in sorted(keep, key=lambda k: -agg[k].get('SQ_WAVE_CYCLES', 0)):
     d = {c: agg[k][c] / cnt[(k, c)] for c in agg[k]}
     wc = d.get('SQ_WAVE_CYCLES', 0) or 1
@@ -33,4 +33,4 @@ for k in sorted(keep, key=lambda k: -agg[k].get('SQ_WAVE_CYCLES', 0)):
         if c in d:
             print('   %-34s %16.0f   %6.3f of wave cycles' % (c, d[c], d[c] / wc))
 PY
-head -60 $R/gpurun_out/profiles/r05_pmc_stalls.txt
+head -60 $R/gpurun_out/profiles/r06_pmc_stalls.txt
