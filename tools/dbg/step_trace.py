@@ -27,10 +27,10 @@ for s, e in iv[1:]:
         ce = max(ce, e)
 busy += ce - cs
 print(f'busy {busy / 1e6:.3f} ms, idle {idle / 1e6:.3f} ms')
-CONV = ('conv_igemm', 'conv_wgrad', 'bottleneck', 'stem_pool', 'splitk', 'unpack_wgrad', 'halo_x3')
+CONV = ('conv_igemm', 'conv_x3p', 'conv_wgrad', 'bottleneck', 'stem_pool', 'splitk', 'unpack_wgrad', 'halo_x3')
 t_conv = sum(E[i] - S[i] for i in range(a, b) if any(x in names[i] for x in CONV))
 t_else = sum(E[i] - S[i] for i in range(a, b)) - t_conv
-print(f'conv-class kernels (igemm, wgrad, fused blocks, stem, halo, split-K finalize, unpack) {t_conv / 1e6:.3f} ms, everything else {t_else / 1e6:.3f} ms')
+print(f'conv-class kernels (igemm, x3p, wgrad, fused blocks, stem, halo, split-K finalize, unpack) {t_conv / 1e6:.3f} ms, everything else {t_else / 1e6:.3f} ms')
 other = collections.Counter()
 for i in range(a, b):
     if not any(x in names[i] for x in CONV):
