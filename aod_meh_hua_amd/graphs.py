@@ -96,10 +96,11 @@ class GraphedTrainStep:
         if d['img'].data_ptr() != st['img'].data_ptr():        # (a loader that filled static_image() directly has nothing to copy: 50 MB at 16 x 512^2)
             st['img'].copy_(d['img'], non_blocking=True)
         B, G = st['gts'].shape[:2]
-        # fresh pinned staging every call: the copies below are asynchronous, and torch's caching host allocator only recycles a pinned
-        # block once the copy that read it has completed (re-using one fixed buffer races with the next call's host writes)
-        hg, hl = torch.zeros(B, G, 4, pin_memory=True), torch.zeros(B, G, dtype=torch.long, pin_memory=True)
-        hc = torch.zeros(B, dtype=torch.int32, pin_memory=True)
+        # fresh pinned staging every call: the copy below is asynchronous, and torch's caching host allocator only recycles a pinned
+        # block once the copy that read it has completed (re-using one fixed buffer races with the next call's host writes).  Boxes, labels
+        # and counts travel as ONE upload: the three static tensors are views of one byte buffer (_alloc), three 5-us copy launches per step became one
+        host = torch.zeros(st['gt_pack'].numel(), dtype=torch.uint8, pin_memory=True)
+        hg, hl, hc = (host[o:o + n].view(dt).view(sh) for o, n, dt, sh in st['gt_views'])
         for b, (bb, ll) in enumerate(zip(d['gt_bboxes'], d['gt_labels'])):
             n = int(bb.shape[0])
             if n > G:
@@ -108,15 +109,19 @@ class GraphedTrainStep:
             if n:
                 hg[b, :n] = bb.detach().float().cpu() if bb.device.type != 'cpu' else bb.float()
                 hl[b, :n] = ll.detach().long().cpu() if ll.device.type != 'cpu' else ll.long()
-        st['gts'].copy_(hg, non_blocking=True), st['counts'].copy_(hc, non_blocking=True), st['labs'].copy_(hl, non_blocking=True)
+        st['gt_pack'].copy_(host, non_blocking=True)
         if st.get('valid_fn') is not None:            # valid-anchor flags of THIS batch's per-image pad shapes (cached per shape on the device)
             st['valid'].copy_(st['valid_fn'](d['img_metas']), non_blocking=True)
 
     def _alloc(self, d):
         B, dev, G = d['img'].shape[0], self.dev, self.gmax
-        return dict(img=torch.empty(tuple(d['img'].shape), dtype=torch.float32, device=dev),
-                    gts=torch.zeros(B, G, 4, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
-                    labs=torch.zeros(B, G, dtype=torch.long, device=dev), metas=[dict(m) for m in d['img_metas']])
+        # boxes [B, G, 4] fp32 | labels [B, G] int64 | counts [B] int32 in one byte buffer (16-B aligned pieces), see _load
+        nb, nl, nc = B * G * 16, B * G * 8, (B * 4 + 15) // 16 * 16
+        pack = torch.zeros(nb + nl + nc, dtype=torch.uint8, device=dev)
+        views = [(0, nb, torch.float32, (B, G, 4)), (nb, nl, torch.int64, (B, G)), (nb + nl, B * 4, torch.int32, (B,))]
+        gts, labs, counts = (pack[o:o + n].view(dt).view(sh) for o, n, dt, sh in views)
+        return dict(img=torch.empty(tuple(d['img'].shape), dtype=torch.float32, device=dev), gt_pack=pack, gt_views=views,
+                    gts=gts, counts=counts, labs=labs, metas=[dict(m) for m in d['img_metas']])
 
     # ------------------------------------------------------------------ the segments of run_iter
     def _seg_a(self, cuts=False):
@@ -439,7 +444,11 @@ class GraphedScore:
         # (value-keyed device copies of the sizes / scale factors: a pool re-uses a handful of them; device-to-device into the static buffers)
         hw, sc = scoring._meta_tensors([m['img_shape'] for m in img_metas], [m['scale_factor'] for m in img_metas], self.dev)
         sl['ids'].copy_(image_ids, non_blocking=True)
-        sl['hw'].copy_(hw, non_blocking=True), sl['sc'].copy_(sc, non_blocking=True)
+        # (the size / scale tensors are value-cached objects: a pool of one image size hands over the same two tensors batch after batch --
+        # the slot already holds their values then, two 5-us copy launches at the head of every conv half saved)
+        if sl.get('meta_src') != (id(hw), id(sc)):
+            sl['hw'].copy_(hw, non_blocking=True), sl['sc'].copy_(sc, non_blocking=True)
+            sl['meta_src'], sl['meta_keep'] = (id(hw), id(sc)), (hw, sc)          # (keep the objects alive: ids are only unique among live objects)
 
     def _capture(self, sl, fns):
         """warm-up runs on a side stream, then one graph per function of `fns` (they share nothing but the slot's tensors)"""

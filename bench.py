@@ -359,6 +359,15 @@ def main():
         gscore = GraphedScore(pool_model, **{k: v for k, v in SCORE_KW.items() if k != 'return_loss'})
         state = dict(graph_ok=use_graph, filled=set())
 
+        def id_table(it, tab={}):
+            """global image ids of scoring batch `it` as a slice of one resident arange (what the pool loop hands over: a slice of its id
+            vector) -- `arange + offset` per step were two 5-us launches in front of every scoring batch"""
+            lo = (it * world + rank) * B
+            t = tab.get('t')
+            if t is None or lo + B > t.numel():
+                t = tab['t'] = torch.arange(max(2 * (lo + B), 1 << 16), device=dev)
+            return t[lo:lo + B]
+
         def step(it=0, do_train=do_train, do_score=do_score, graph=None, defer=False):
             """One bench step.  graph=True replays the captured HIP graphs (same kernels, same work); graph=False enqueues from Python.
             defer=True (score-only loops): like the pool loop of apis/test.py, the scores are not read before the loop's end, so the selection
@@ -371,7 +380,7 @@ def main():
                     # uploaded, as for a loader's batch; R == 1: `data` IS the static buffer (see below)
                     gstep(data if R == 1 else datas[k_])
                 if do_score:
-                    ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                    ids = id_table(it)
                     # R == 1: the synthetic pool batch is resident in HBM (contract): it sits in the static input buffer of EACH of the scoring
                     # graph's alternating slots -- where the on-device pool generator / a loader's H2D copy writes a real batch
                     # (graphs.static_image) -- so no 50 MB device-to-device copy rides in the step; R > 1: batch k_ is copied in per step
@@ -403,7 +412,7 @@ def main():
             if do_score:
                 pool_model.eval()
                 with torch.no_grad():
-                    ids = torch.arange(B, device=dev) + (it * world + rank) * B
+                    ids = id_table(it)
                     _, unc = pool_model(img=[pools[k_]['img']], img_metas=[pools[k_]['img_metas']], image_ids=ids, **SCORE_KW)
                     unc = torch.as_tensor(unc, device=dev, dtype=torch.float32)
                     if world > 1:
@@ -493,6 +502,32 @@ def main():
         torch.cuda._sleep(int(0.6 * 2.0e9))
         step(warmup + steps, graph=False)              # EVERY rank (the step contains collectives); HIP events need the eager path
         barrier()
+        # ... twice, keeping the SHORTER time of every launch: a single instrumented step now and then contains one launch that took
+        # milliseconds (2.45 ms for a 224-us dgrad in one of this round's runs, never in the three repeats): a box hiccup, not a kernel time
+        first = None
+        if rank == 0:
+            first = ([(k_, sh, fl, e0.elapsed_time(e1), sc) for k_, sh, fl, e0, e1, sc in ho.PROFILE], [(n_, nb, e0.elapsed_time(e1)) for n_, nb, e0, e1 in ho.BYTES_PROFILE])
+            ho.PROFILE, ho.BYTES_PROFILE = [], []
+        torch.cuda._sleep(int(0.6 * 2.0e9))
+        step(warmup + steps, graph=False)
+        barrier()
+        if rank == 0:
+            second = ([(k_, sh, fl, e0.elapsed_time(e1), sc) for k_, sh, fl, e0, e1, sc in ho.PROFILE], [(n_, nb, e0.elapsed_time(e1)) for n_, nb, e0, e1 in ho.BYTES_PROFILE])
+
+            class _Ev:          # (the aggregation below reads e0.elapsed_time(e1))
+                def __init__(self, ms):
+                    self.ms = ms
+
+                def elapsed_time(self, other):
+                    return other.ms
+
+            def _merge(a, b, ti):
+                if len(a) != len(b) or any(x[:ti] != y[:ti] for x, y in zip(a, b)):
+                    return b          # (the two steps did not issue the same launches: keep the later one)
+                return [x[:ti] + (min(x[ti], y[ti]),) + x[ti + 1:] for x, y in zip(a, b)]
+            conv_m, bytes_m = _merge(first[0], second[0], 3), _merge(first[1], second[1], 2)
+            ho.PROFILE = [(k_, sh, fl, _Ev(0.0), _Ev(ms), sc) for k_, sh, fl, ms, sc in conv_m]
+            ho.BYTES_PROFILE = [(n_, nb, _Ev(0.0), _Ev(ms)) for n_, nb, ms in bytes_m]
         if rank == 0:
             mfma_per_product = PRECISIONS[precision][1]
             peak = PEAK_BF16_TFLOPS / mfma_per_product      # algorithmic (fp32-grade) FLOP/s the matrix pipe can deliver in this mode

@@ -26,6 +26,8 @@ SHAPES = [  # name, C, O, H, W, R, stride, res
     ('l3.0 down 1x1 s2 512->1024 @64', 512, 1024, 64, 64, 1, 2, False),
     ('l4 reduce 1x1 2048->512 @16', 2048, 512, 16, 16, 1, 1, False),
     ('l4 expand 1x1 512->2048 @16 +res', 512, 2048, 16, 16, 1, 1, True),
+    ('l4 conv2 3x3 512->512 @16 (split-K today)', 512, 512, 16, 16, 3, 1, False),
+    ('fpn P5 3x3 256->256 @16', 256, 256, 16, 16, 3, 1, False),
     ('fpn lateral 1x1 512->256 @64', 512, 256, 64, 64, 1, 1, False),
     ('fpn lateral 1x1 1024->256 @32', 1024, 256, 32, 32, 1, 1, False),
     ('fpn 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, False),
@@ -81,6 +83,7 @@ for name, C, O, H, W, R, st, res in SHAPES:
 
     def setmode(mode):
         os.environ['AOD_X3P'] = mode[0]
+        ho.SPLITK = not (mode[0] == '1' and os.environ.get('X3P_NO_SPLITK') == '1')      # (A/B: the persistent kernel instead of split-K)
         os.environ['AOD_X3P_ROT'] = mode[2:] if len(mode) > 1 else '0'
         os.environ['AOD_X3P_MIN_TILES'] = os.environ.get('MIN_TILES', '1')
         os.environ['AOD_X3P_MIN_STEPS'] = os.environ.get('MIN_STEPS', '1')
