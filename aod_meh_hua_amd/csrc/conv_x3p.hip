@@ -362,16 +362,39 @@ int xp_launch(const X3PArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
+// 256-column tiles (half the pixel bytes per MFMA, twice the MFMAs per barrier) when they still give at least three quarters of the CUs a
+// tile; AOD_X3P_BN=128 / 256 forces
+static bool xp_wide(const X3PArgs& a) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  if (!g_x3p_cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_x3p_cus[dev] = n;
+  }
+  if (a.N % 256 != 0) return false;
+  const char* fbn = getenv("AOD_X3P_BN");
+  if (fbn) return atoi(fbn) == 256;
+  const int ng = a.ngroups > 1 ? a.ngroups : 1;
+  return (long long)((a.M + XP_BM - 1) / XP_BM) * (a.N / 256) * ng >= (long long)g_x3p_cus[dev] * 3 / 4;
+}
+
 int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
   const char* now = getenv("AOD_X3P");                 // (read per call: tests switch it in-process)
   if (now && now[0] == '0') return 0;
   if (a.taps != 1 && a.taps != 9) return 0;
   // a tile needs a K loop long enough to amortise the one-workgroup-per-CU structure (its epilogue runs beside nothing but the loaders' next
-  // stages): from ~24 K-steps on the persistent form wins -- every 3x3 layer (36+ steps), the 1024 -> 256 reduce / lateral 1x1 convs (32 steps:
-  // 37.2 -> 29.2 us), retina_cls' dgrad (54: 236 -> 228 us) -- below that the general kernel's two workgroups per CU do (the expand 1x1 convs
-  // with 4 - 8 steps: 45.7 vs 50.6 us; retina_reg / retina_L dgrads with 18 / 9: 106 vs 116, 76 vs 88 us; profiles/r06_x3p_micro.txt).
-  // AOD_X3P_MIN_STEPS overrides the threshold.
-  { const char* ms = getenv("AOD_X3P_MIN_STEPS"); if (a.taps * (a.C >> 6) < (ms ? atoi(ms) : 24)) return 0; }
+  // stages): from ~24 K-steps of a 128-column tile on the persistent form wins -- every 3x3 layer (36+ steps), the 1024 -> 256 reduce / lateral
+  // 1x1 convs (32 steps: 37.0 -> 28.7 us), retina_cls' dgrad (54: 243 -> 230 us) -- and a 256-column tile's K-step carries twice the matrix
+  // work per barrier, so 12 of those do (the 512 -> 256 lateral and the 512 -> 1024 stride-2 downsample conv: 57.7 -> 55.0, 57.0 -> 54.3 us).
+  // Below that the general kernel's two workgroups per CU win (the expand 1x1 convs with their residual, 4 - 16 steps: 45.5 vs 49.9,
+  // 34.0 vs 36.8 us; retina_reg / retina_L dgrads with 18 / 9 steps of a 128-column tile: 106 vs 116, 76 vs 88 us) -- a residual epilogue is
+  // only taken from 24 steps on.  profiles/r06_x3p_micro.txt; AOD_X3P_MIN_STEPS overrides the threshold.
+  {
+    const char* ms = getenv("AOD_X3P_MIN_STEPS");
+    const int thr = ms ? atoi(ms) : 24, steps = a.taps * (a.C >> 6);
+    if (steps * (xp_wide(a) ? 2 : 1) < thr || (a.res && steps < thr)) return 0;
+  }
   if (a.taps == 9 && a.S != 3) return 0;
   if (a.N % 128 != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
   if (a.transposed && a.stride != 1) return 0;
@@ -400,19 +423,11 @@ int aod_conv_x3p_launch(const X3PArgs& a0, hipStream_t st) {
     a.grp[0].x = a.x; a.grp[0].w = a.w; a.grp[0].y = a.y; a.grp[0].shift = a.pre_shift; a.grp[0].mask = a.mask; a.grp[0].colsum = a.colsum;
   }
   { const char* r = getenv("AOD_X3P_ROT"); a.rot = r ? atoi(r) : 0; }
+  const bool wide = xp_wide(a);                 // (also resolves the CU count of the current device)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-  if (!g_x3p_cus[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    g_x3p_cus[dev] = n;
-  }
-  const int ncu = g_x3p_cus[dev];
+  const int ncu = g_x3p_cus[dev] ? g_x3p_cus[dev] : 256;
   a.tiles_m = (a.M + XP_BM - 1) / XP_BM;
-  // 256-column tiles (half the pixel bytes per MFMA, twice the MFMAs per barrier) when they still give every CU work; AOD_X3P_BN=128 / 256 forces
-  const char* fbn = getenv("AOD_X3P_BN");
-  bool wide = a.N % 256 == 0 && (long long)a.tiles_m * (a.N / 256) * a.ngroups >= (long long)ncu * 3 / 4;
-  if (fbn) wide = a.N % 256 == 0 && atoi(fbn) == 256;
   a.tiles_n = a.N / (wide ? 256 : 128);
   const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.ngroups;
   const int grid = (int)(ntiles < ncu ? ntiles : ncu);
