@@ -1179,7 +1179,7 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
   // a ragged last column tile (N = 180 -> 128 + 52) wastes MFMA work; 64-wide tiles trim it (192 instead of 256 columns)
   const int pad128 = (p.N + 127) / 128 * 128, pad64 = (p.N + 63) / 64 * 64;
   const bool ragged = p.N > 128 && (pad128 - pad64) * 5 >= pad128;
-  if (p.x3 && !p.out_f32 && !p.zraw && !p.post_scale && !p.perm && !p.up_w && !p.bigrows && p.R == p.S) {
+  if (p.x3 && !p.out_f32 && !p.zraw && !p.post_scale && !p.bigrows && p.R == p.S) {
     // the persistent producer / consumer kernel (conv_x3p.hip) for the 128-column-tileable 1x1 / 3x3 layers that fill at least ~ a round of
     // the CUs with 128 x 128 tiles and do NOT qualify for the 256 x 256 tile below (the head towers, FPN P3): identical bits, AOD_X3P=0 disables
     const long long t256 = ntiles(256, 256);
@@ -1188,6 +1188,9 @@ extern "C" int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const
     if (!big || (dbg_big && dbg_big[0] == '1')) {
       X3PArgs a;
       x3p_args(p, a);
+      // (the class-major stride-2 dgrad and the in-place 1x1 / stride-2 dgrad as lattice launches of the persistent kernel: X3PArgs.lat)
+      a.lat = p.perm ? 1 : (p.up_w ? 2 : 0);
+      a.up_w = p.up_w; a.up_hw = p.up_hw;
       if (aod_conv_x3p_wants(a, p.colsum && aod_get_deterministic())) return aod_conv_x3p_launch(a, st);
     }
   }

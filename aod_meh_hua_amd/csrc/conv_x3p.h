@@ -15,6 +15,11 @@ struct X3PArgs {
   int C, N, K, taps, S, stride, pad, dil, transposed, relu, tapin;
   int nseg, M, tiles_m, tiles_n;
   int rot;                  // debug (AOD_X3P_ROT): tile-dependent start chunk of the K loop / dropped operand loads (timing experiments)
+  int lat;                  // destination lattice: 0 dense; 1 CLASS-MAJOR stride-2 dgrad of a 3x3 / pad-1 conv (one segment, even OH / OW): the
+                            // tiles walk the four (y & 1, x & 1) classes of the destination pixels, a class's tile multiplies only the 1 / 2 / 2 / 4
+                            // taps that reach it; 2 the IN-PLACE 1x1 / stride-2 dgrad (conv.hip `up_w`): a plain GEMM over the dZ pixels whose row
+                            // (b, y, x) is stored at destination row b * up_hw + 2y * up_w + 2x
+  int up_w, up_hw;
   int ngroups;              // >= 1: grp[] holds the operands (the launcher fills grp[0] from the fields above for a plain launch)
   struct { const bf16_t* x; const bf16_t* w; bf16_t* y; const float* shift; const bf16_t* mask; float* colsum; } grp[4];
   long long x_bytes, w_bytes;

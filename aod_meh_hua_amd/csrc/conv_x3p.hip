@@ -54,9 +54,10 @@ __device__ __forceinline__ T xp_sel8(const T* a, int sg) {      // a[sg] of a by
 }
 #define XP_GSEL(f) (gi == 0 ? p.grp[0].f : (gi == 1 ? p.grp[1].f : (gi == 2 ? p.grp[2].f : p.grp[3].f)))
 
-// NBW: 16-channel blocks per consumer wave -- 4: 128-column tiles, 8: 256-column tiles
-template <int TAPS, int NBW>
+// NBW: 16-channel blocks per consumer wave -- 4: 128-column tiles, 8: 256-column tiles.  LAT: X3PArgs.lat (TAPS = 4 = the most taps a class has)
+template <int TAPS, int NBW, int LAT = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3p_kernel(const X3PArgs p) {
+  static_assert(LAT != 1 || TAPS == 4, "class-major form: up to four taps per class");
   constexpr int BN = 32 * NBW, WBYTES = BN * 128, STAGE = XP_XBYTES + WBYTES;
   // ring: RING slots, FLY stages in flight.  Iteration k of a loader issues stage k, waits until all but the youngest FLY stages'
   // instructions have landed (stage k - FLY and older) and joins barrier k - FLY - 1, behind which the consumers read stage k - FLY;
@@ -67,17 +68,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tpg = p.tiles_m * p.tiles_n;                       // tiles per group
+  const int tpc = p.tiles_m * p.tiles_n;                       // tiles per class (class-major form) = tiles per group otherwise
+  const int tpg = tpc * (LAT == 1 ? 4 : 1);                    // tiles per group
   const int ntiles = tpg * p.ngroups;
   const int G = (int)gridDim.x, bid = (int)blockIdx.x;
   const int nmine = (ntiles - bid + G - 1) / G;              // tiles bid, bid + G, ... (launcher: G <= ntiles)
   const int CC = p.C >> 6;                                    // 64-column (= 32-channel) chunks per tap
-  const int nk = TAPS * CC;                                   // K-steps per tile
-  const int total = nmine * nk;
   auto tile_of = [&](int j) {
     const int base = j * G, left = ntiles - base;
     return base + xp_swizzle(bid, left < G ? left : G);
   };
+  // K-steps of a tile: taps x chunks; in the class-major form the class (tile / tiles per class) decides the taps: 1, 2, 2, 4
+  auto taps_of = [&](int tile) {
+    if (LAT != 1) return TAPS;
+    const int cls = (tile % tpg) / tpc;
+    return ((cls >> 1) ? 2 : 1) * ((cls & 1) ? 2 : 1);
+  };
+  int total = 0;
+  if (LAT == 1) { for (int j = 0; j < nmine; ++j) total += taps_of(tile_of(j)) * CC; }
+  else total = nmine * TAPS * CC;
   auto seg_of = [&](int m) {
     int sg = 0;
 #pragma unroll
@@ -105,40 +114,59 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* const lds_w = smem + (8 * w) * 128;
     for (int j = 0; j < nmine; ++j) {
       const int tile = tile_of(j);
-      const int gi = tile / tpg, tl = tile - gi * tpg;
+      const int gi = tile / tpg, tl0 = tile - gi * tpg;
+      const int cls = LAT == 1 ? tl0 / tpc : 0, tl = tl0 - cls * tpc;
+      const int py = cls >> 1, px = cls & 1;                      // class-major form: parity of the destination pixels of this tile
       const int tm = tl / p.tiles_n, tn = tl - tm * p.tiles_n;
       const int m0 = tm * XP_BM, n0 = tn * BN;
       // (p.rot bits 8 / 9, timing experiments only: a zero-record descriptor drops every load of that operand at the range check)
       const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)XP_GSEL(x), 0, (p.rot & 256) ? 0 : (int)p.x_bytes, 0x00020000);
       const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)XP_GSEL(w), 0, (p.rot & 512) ? 0 : (int)p.w_bytes, 0x00020000);
       // the tile lies inside ONE segment (launcher): workgroup-uniform geometry
-      const int sg = seg_of(m0);
+      const int sg = LAT == 1 ? 0 : seg_of(m0);
       const unsigned mstart = sg ? (unsigned)xp_sel8(p.seg_mend, sg - 1) : 0u;
-      const unsigned OW = (unsigned)xp_sel8(p.segOW, sg), OH = (unsigned)xp_sel8(p.segOH, sg), ohw = OH * OW;
+      const unsigned OW = (unsigned)xp_sel8(p.segOW, sg), OH = (unsigned)xp_sel8(p.segOH, sg);
       const unsigned H = (unsigned)xp_sel8(p.segH, sg), W = (unsigned)xp_sel8(p.segW, sg);
+      // rows of the tile enumerate (image, y, x) over RH x RW: the destination map, or (class-major) the class's half-resolution lattice
+      const unsigned RH = LAT == 1 ? OH >> 1 : OH, RW = LAT == 1 ? OW >> 1 : OW, rhw = RH * RW;
+      const int mlim = LAT == 1 ? (int)(rhw * (unsigned)p.segB[0]) : p.M;
       const unsigned rowb = (unsigned)(p.C * 2);
       const unsigned src0b = (unsigned)((unsigned long long)xp_sel8(p.seg_src0, sg) * rowb);       // (32-bit byte offsets: x_bytes < 3.5 GiB)
       const unsigned imgb = H * W * rowb;
+      const int ntap = taps_of(tile);
       unsigned vo[TAPS][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + 8 * w + 32 * i + prow;
-        const bool live = m < p.M;
+        const bool live = m < mlim;
         const unsigned ml = (unsigned)m - mstart;
-        const unsigned b = xp_udiv(ml, ohw), rem = ml - b * ohw, oy = xp_udiv(rem, OW), ox = rem - oy * OW;
-        const int y0 = p.transposed ? (int)oy + p.pad : (int)oy * p.stride - p.pad;
-        const int x0 = p.transposed ? (int)ox + p.pad : (int)ox * p.stride - p.pad;
+        const unsigned b = xp_udiv(ml, rhw), rem = ml - b * rhw, oy = xp_udiv(rem, RW), ox = rem - oy * RW;
         const unsigned base = src0b + b * imgb + (unsigned)(kc * 16);
-        constexpr int RR = TAPS == 9 ? 3 : 1;
+        if constexpr (LAT == 1) {
+          // destination pixel (2 oy + py, 2 ox + px) of a 3x3 / stride-2 / pad-1 conv's input gradient: tap (r, s) reaches it from dZ pixel
+          // ((2 oy + py + 1 - r) / 2, (2 ox + px + 1 - s) / 2) when both are whole -- r = 1 for an even row, r in {0, 2} for an odd one -- i.e.
+          // from dZ row oy + 1 (r = 0), oy (r = 1 or 2); likewise the columns.  Taps in ascending (r, s) order like the general kernel's
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-          const int y = y0 + sgn * r * p.dil;
-          const bool yok = live && (unsigned)y < H;
+          for (int tq = 0; tq < 4; ++tq) {
+            const int ri = px ? tq >> 1 : tq, si = px ? tq & 1 : 0;            // tap tq of the class = (ri-th row tap, si-th column tap)
+            const int sy = (int)oy + ((py && ri == 0) ? 1 : 0), sx = (int)ox + ((px && si == 0) ? 1 : 0);
+            const bool ok = live && tq < ntap && (unsigned)sy < H && (unsigned)sx < W;
+            vo[tq][i] = ok ? base + (unsigned)(sy * (int)W + sx) * rowb : XP_OOB;
+          }
+        } else {
+          const int y0 = p.transposed ? (int)oy + p.pad : (int)oy * p.stride - p.pad;
+          const int x0 = p.transposed ? (int)ox + p.pad : (int)ox * p.stride - p.pad;
+          constexpr int RR = TAPS == 9 ? 3 : 1;
 #pragma unroll
-          for (int s = 0; s < RR; ++s) {
-            const int x = x0 + sgn * s * p.dil;
-            const bool ok = yok && (unsigned)x < W;
-            vo[r * RR + s][i] = ok ? base + (unsigned)(y * (int)W + x) * rowb : XP_OOB;
+          for (int r = 0; r < RR; ++r) {
+            const int y = y0 + sgn * r * p.dil;
+            const bool yok = live && (unsigned)y < H;
+#pragma unroll
+            for (int s_ = 0; s_ < RR; ++s_) {
+              const int x = x0 + sgn * s_ * p.dil;
+              const bool ok = yok && (unsigned)x < W;
+              vo[r * RR + s_][i] = ok ? base + (unsigned)(y * (int)W + x) * rowb : XP_OOB;
+            }
           }
         }
       }
@@ -164,7 +192,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_s_barrier();
         }
       };
-      if (TAPS == 1 || p.tapin) {
+      if constexpr (LAT == 1) {
+        // (tap, chunk) order over the class's taps; filter tap index of tap tq: (r, s) = (py ? 2 ri : 1, px ? 2 si : 1)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+          if (tq < ntap) {
+            const int ri = px ? tq >> 1 : tq, si = px ? tq & 1 : 0;
+            const int tapidx = (py ? 2 * ri : 1) * 3 + (px ? 2 * si : 1);
+            for (int cc = 0; cc < CC; ++cc) issue(vo[tq], tapidx, cc);
+          }
+        }
+      } else if (TAPS == 1 || p.tapin) {
         // (p.rot low bits, timing experiments only: the chunk loop starts at a tile-dependent chunk -- another summation order)
         int cc = (p.rot & 255) ? (tm * (p.rot & 255)) % CC : 0;
         for (int c0 = 0; c0 < CC; ++c0) {
@@ -199,9 +237,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int cslot = 0;
   for (int j = 0; j < nmine; ++j) {
     const int tile = tile_of(j);
-    const int gi = tile / tpg, tl = tile - gi * tpg;
+    const int gi = tile / tpg, tl0 = tile - gi * tpg;
+    const int cls = LAT == 1 ? tl0 / tpc : 0, tl = tl0 - cls * tpc;
     const int tm = tl / p.tiles_n, tn = tl - tm * p.tiles_n;
     const int m0 = tm * XP_BM, n0 = tn * BN;
+    const int nk = taps_of(tile) * CC;
     f32x4 acc[NBW][4];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -243,7 +283,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- epilogue, in registers.  acc[2a][mb][r] = channel cb + r, acc[2a + 1][mb][r] = channel cb + 4 + r of pixel m0 + wm * 64 + mb * 16 + lr,
     // cb = n0 + wn * 16 NBW + 32a + 8 * lq: head columns 2 * (cb - 8 lq) + 8 lq .. + 7 of the destination row, tails 32 columns further
-    const int sg = seg_of(m0);
+    const int sg = LAT == 1 ? 0 : seg_of(m0);
     const long long drow0 = xp_sel8(p.seg_dst0, sg) - (long long)(sg ? xp_sel8(p.seg_mend, sg - 1) : 0);
     bf16_t* const gy = XP_GSEL(y);
     const bf16_t* const gmask = XP_GSEL(mask);
@@ -252,13 +292,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)gshift, 0, gshift ? p.N * 4 : 0, 0x00020000);
     bool live[4];
     long long prow_[4];
+    const unsigned eOW = (unsigned)p.segOW[0], eOH = (unsigned)p.segOH[0];
+    const unsigned eRW = LAT == 1 ? eOW >> 1 : eOW, erhw = (LAT == 1 ? eOH >> 1 : eOH) * eRW;
+    const int mlim = LAT == 1 ? (int)(erhw * (unsigned)p.segB[0]) : p.M;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int m = m0 + wm * 64 + mb * 16 + lr;
-      live[mb] = m < p.M;
-      // (rows past M read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes the
-      // compiler wait for each one where the paths merge; only the stores are predicated)
-      prow_[mb] = (drow0 + (live[mb] ? m : p.M - 1)) * NP;
+      live[mb] = m < mlim;
+      // (rows past the end read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes
+      // the compiler wait for each one where the paths merge; only the stores are predicated)
+      const int mc = live[mb] ? m : mlim - 1;
+      if constexpr (LAT == 0) prow_[mb] = (drow0 + mc) * NP;
+      else {
+        // lattice destinations: row (image, y, x) of the tile's row space lands at (2y + py, 2x + px) of the full-resolution map
+        const unsigned b = xp_udiv((unsigned)mc, erhw), rem = (unsigned)mc - b * erhw, oy = xp_udiv(rem, eRW), ox = rem - oy * eRW;
+        const long long drow = LAT == 1 ? ((long long)b * eOH + 2 * oy + (unsigned)(cls >> 1)) * eOW + 2 * ox + (unsigned)(cls & 1)
+                                        : (long long)b * p.up_hw + (long long)(2 * oy) * p.up_w + 2 * ox;
+        prow_[mb] = (xp_sel8(p.seg_dst0, 0) + drow) * NP;
+      }
     }
     // PG block pairs (32 channels each) at a time: all their operands are requested before the first is used.  Two pairs with 64 accumulator
     // registers; one with 128 (the 256-column tile), where a second pair's 48 operand registers would spill
@@ -350,17 +401,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int g_x3p_cus[64];
 long long g_x3p_count = 0;
 
-template <int TAPS, int NBW>
+template <int TAPS, int NBW, int LAT = 0>
 int xp_launch(const X3PArgs& a, int grid, hipStream_t st) {
   constexpr int STAGE = XP_XBYTES + 32 * NBW * 128, RING = NBW == 4 ? 5 : 3;
   const size_t lds = (size_t)RING * STAGE;
   static unsigned long long attr = 0;
-  if (aod_first_on_device(&attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<TAPS, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_x3p_kernel<TAPS, NBW>), dim3(grid), dim3(512), lds, st, a);
+  if (aod_first_on_device(&attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<TAPS, NBW, LAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_x3p_kernel<TAPS, NBW, LAT>), dim3(grid), dim3(512), lds, st, a);
   return 0;
 }
 
 }  // namespace
+
+// GEMM rows a launch tiles: the destination pixels, or (class-major form) the pixels of ONE of the four classes
+static long long xp_rows(const X3PArgs& a) {
+  return a.lat == 1 ? (long long)a.segB[0] * (a.segOH[0] / 2) * (a.segOW[0] / 2) : a.M;
+}
 
 // 256-column tiles (half the pixel bytes per MFMA, twice the MFMAs per barrier) when they still give at least three quarters of the CUs a
 // tile; AOD_X3P_BN=128 / 256 forces
@@ -376,30 +432,43 @@ static bool xp_wide(const X3PArgs& a) {
   const char* fbn = getenv("AOD_X3P_BN");
   if (fbn) return atoi(fbn) == 256;
   const int ng = a.ngroups > 1 ? a.ngroups : 1;
-  return (long long)((a.M + XP_BM - 1) / XP_BM) * (a.N / 256) * ng >= (long long)g_x3p_cus[dev] * 3 / 4;
+  return ((xp_rows(a) + XP_BM - 1) / XP_BM) * (a.N / 256) * ng * (a.lat == 1 ? 4 : 1) >= (long long)g_x3p_cus[dev] * 3 / 4;
 }
 
 int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
   const char* now = getenv("AOD_X3P");                 // (read per call: tests switch it in-process)
   if (now && now[0] == '0') return 0;
   if (a.taps != 1 && a.taps != 9) return 0;
+  if (a.taps == 9 && a.S != 3) return 0;
+  if (a.N % 128 != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
+  if (a.lat == 1) {
+    // class-major stride-2 dgrad: 3x3, pad 1, no dilation, one segment with an even map whose halves are the dZ map
+    const char* lt = getenv("AOD_X3P_LATTICE");
+    if (lt && lt[0] == '0') return 0;
+    if (!(a.transposed && a.stride == 2 && a.taps == 9 && a.pad == 1 && a.dil == 1 && a.nseg == 1 && a.ngroups <= 1)) return 0;
+    if ((a.segOH[0] & 1) || (a.segOW[0] & 1) || a.segH[0] * 2 != a.segOH[0] || a.segW[0] * 2 != a.segOW[0]) return 0;
+  } else if (a.lat == 2) {
+    const char* lt = getenv("AOD_X3P_LATTICE");
+    if (lt && lt[0] == '0') return 0;
+    if (!(a.transposed && a.stride == 1 && a.taps == 1 && a.pad == 0 && a.nseg == 1 && a.ngroups <= 1 && a.up_w > 0)) return 0;
+  } else if (a.transposed && a.stride != 1) return 0;
+  if (deterministic_colsum) return 0;                  // ordered column sums stay with the general kernel (determinism.hip)
+  if ((long long)a.K * 2 * a.N >= 0x7fffffffll) return 0;
   // a tile needs a K loop long enough to amortise the one-workgroup-per-CU structure (its epilogue runs beside nothing but the loaders' next
   // stages): from ~24 K-steps of a 128-column tile on the persistent form wins -- every 3x3 layer (36+ steps), the 1024 -> 256 reduce / lateral
   // 1x1 convs (32 steps: 37.0 -> 28.7 us), retina_cls' dgrad (54: 243 -> 230 us) -- and a 256-column tile's K-step carries twice the matrix
   // work per barrier, so 12 of those do (the 512 -> 256 lateral and the 512 -> 1024 stride-2 downsample conv: 57.7 -> 55.0, 57.0 -> 54.3 us).
   // Below that the general kernel's two workgroups per CU win (the expand 1x1 convs with their residual, 4 - 16 steps: 45.5 vs 49.9,
   // 34.0 vs 36.8 us; retina_reg / retina_L dgrads with 18 / 9 steps of a 128-column tile: 106 vs 116, 76 vs 88 us) -- a residual epilogue is
-  // only taken from 24 steps on.  profiles/r06_x3p_micro.txt; AOD_X3P_MIN_STEPS overrides the threshold.
+  // only taken from 24 steps on.  The class-major form is judged by its average class (9 taps over 4 classes).
+  // profiles/r06_x3p_micro.txt; AOD_X3P_MIN_STEPS overrides the threshold.
   {
     const char* ms = getenv("AOD_X3P_MIN_STEPS");
-    const int thr = ms ? atoi(ms) : 24, steps = a.taps * (a.C >> 6);
-    if (steps * (xp_wide(a) ? 2 : 1) < thr || (a.res && steps < thr)) return 0;
+    const int thr = ms ? atoi(ms) : 24;
+    const int steps = a.lat == 1 ? 9 * (a.C >> 6) / 4 : a.taps * (a.C >> 6);
+    if (a.lat != 1 && (steps * (xp_wide(a) ? 2 : 1) < thr || (a.res && steps < thr))) return 0;
+    if (a.lat == 1 && steps * (xp_wide(a) ? 2 : 1) < thr / 2) return 0;          // (the general kernel's class-major launches are its slowest: 86 - 127 TFLOP/s)
   }
-  if (a.taps == 9 && a.S != 3) return 0;
-  if (a.N % 128 != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
-  if (a.transposed && a.stride != 1) return 0;
-  if (deterministic_colsum) return 0;                  // ordered column sums stay with the general kernel (determinism.hip)
-  if ((long long)a.K * 2 * a.N >= 0x7fffffffll) return 0;
   long long prev = 0;
   for (int i = 0; i < a.nseg; ++i) {
     const long long rows = a.seg_mend[i] - prev;
@@ -411,7 +480,7 @@ int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
   // one 8-wave workgroup per CU: worth it from ~ a round of the chip on; below that the general kernel's smaller tiles fill more CUs
   const char* mint = getenv("AOD_X3P_MIN_TILES");
   const int ng = a.ngroups > 1 ? a.ngroups : 1;
-  const long long tiles = (long long)((a.M + XP_BM - 1) / XP_BM) * (a.N / 128) * ng;
+  const long long tiles = ((xp_rows(a) + XP_BM - 1) / XP_BM) * (a.N / 128) * ng * (a.lat == 1 ? 4 : 1);
   if (tiles < (mint ? atoll(mint) : 192)) return 0;
   return 1;
 }
@@ -427,11 +496,13 @@ int aod_conv_x3p_launch(const X3PArgs& a0, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
   const int ncu = g_x3p_cus[dev] ? g_x3p_cus[dev] : 256;
-  a.tiles_m = (a.M + XP_BM - 1) / XP_BM;
+  a.tiles_m = (int)((xp_rows(a) + XP_BM - 1) / XP_BM);
   a.tiles_n = a.N / (wide ? 256 : 128);
-  const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.ngroups;
+  const long long ntiles = (long long)a.tiles_m * a.tiles_n * a.ngroups * (a.lat == 1 ? 4 : 1);
   const int grid = (int)(ntiles < ncu ? ntiles : ncu);
-  if (a.taps == 1) { if (wide) xp_launch<1, 8>(a, grid, st); else xp_launch<1, 4>(a, grid, st); }
+  if (a.lat == 1) { if (wide) xp_launch<4, 8, 1>(a, grid, st); else xp_launch<4, 4, 1>(a, grid, st); }
+  else if (a.lat == 2) { if (wide) xp_launch<1, 8, 2>(a, grid, st); else xp_launch<1, 4, 2>(a, grid, st); }
+  else if (a.taps == 1) { if (wide) xp_launch<1, 8>(a, grid, st); else xp_launch<1, 4>(a, grid, st); }
   else { if (wide) xp_launch<9, 8>(a, grid, st); else xp_launch<9, 4>(a, grid, st); }
   AOD_LAUNCH_CHECK();
   __atomic_add_fetch(&g_x3p_count, 1, __ATOMIC_RELAXED);

@@ -98,7 +98,8 @@ int aod_conv2d_ws(const aod_conv_desc_t* desc, const void* src, const void* w_pa
  * tile from registers).  Results are bit-identical to the general kernel (the optional column sums are fp32 atomics in both).  Environment
  * AOD_X3P=0 keeps every launch on the general kernel, AOD_X3P_MIN_TILES / AOD_X3P_MIN_STEPS override the two thresholds, AOD_X3P_GROUPED=1
  * also sends the grouped tower launches of aod_conv2d_grouped there (128 x 256 tiles; level with the 256 x 256 tile); with aod_set_deterministic(1) launches
- * that carry column sums stay on the general kernel (ordered sums).  aod_conv_x3p_count(): launches the persistent kernel has taken in this
+ * that carry column sums stay on the general kernel (ordered sums).  The class-major stride-2 dgrad of a 3x3 / pad-1 conv on an even map and the
+ * in-place 1x1 / stride-2 dgrad (res == dst) run there as lattice launches (AOD_X3P_LATTICE=0: general kernel).  aod_conv_x3p_count(): launches the persistent kernel has taken in this
  * process (tests / bench bookkeeping). */
 int64_t aod_conv_x3p_count(void);
 

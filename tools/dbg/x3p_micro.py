@@ -35,6 +35,9 @@ SHAPES = [  # name, C, O, H, W, R, stride, res
     # dgrads (stride 1): dX [M, C] = conv_T(dZ [M, O], W), with the producer's ReLU mask and column sums in the epilogue
     ('DGRAD l3 conv2 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, 'dgrad'),
     ('DGRAD fpn 3x3 256->256 @32', 256, 256, 32, 32, 3, 1, 'dgrad'),
+    ('DGRAD s2 l3.0 conv2 3x3 256->256 @64->32', 256, 256, 64, 64, 3, 2, 'dgrad'),
+    ('DGRAD s2 l2.0 conv2 3x3 128->128 @128->64', 128, 128, 128, 128, 3, 2, 'dgrad'),
+    ('DGRAD s2 l4.0 conv2 3x3 512->512 @32->16', 512, 512, 32, 32, 3, 2, 'dgrad'),
     ('DGRAD retina_cls 3x3 256->192 pyramid', 256, 192, 0, 0, 3, 1, 'dgrad'),
     ('DGRAD retina_reg 3x3 256->64 pyramid', 256, 64, 0, 0, 3, 1, 'dgrad'),
     ('DGRAD retina_L 3x3 256->32 pyramid', 256, 32, 0, 0, 3, 1, 'dgrad'),
@@ -70,12 +73,15 @@ for name, C, O, H, W, R, st, res in SHAPES:
     else:
         pi = AF.PREP.get(w, None, ho.xw(C), 0.0)
         AF.PREP.refresh_if_stale()
-        dz = ho.x3_split(torch.randn(Mrows, O, device='cuda', generator=g))
+        xsegs = segs
+        dsegs = ho.out_segs(segs, R, R, st, pad, 1) if st != 1 else segs
+        drows = sum(sg.rows for sg in dsegs)
+        dz = ho.x3_split(torch.randn(drows, O, device='cuda', generator=g))
         xmask = ho.x3_split(torch.randn(Mrows, C, device='cuda', generator=g))
         cs = torch.zeros(C, device='cuda')
 
         def f():
-            holder['y'] = ho.conv2d_dgrad_rows(dz, segs, segs, pi.wd, C, R, R, 1, pad, 1, mask=xmask, colsum=cs)
+            holder['y'] = ho.conv2d_dgrad_rows(dz, AF.dense_segs(dsegs), xsegs, pi.wd, C, R, R, st, pad, 1, mask=xmask, colsum=cs)
         Mout, oh, ow = Mrows, 1, Mrows // B
     flop = 2.0 * Mout * O * C * R * R
     row = [f'{name:44s} M={Mout:6d}']
