@@ -83,7 +83,7 @@ for name, C, O, H, W, R, st, res in SHAPES:
         def f():
             holder['y'] = ho.conv2d_dgrad_rows(dz, AF.dense_segs(dsegs), xsegs, pi.wd, C, R, R, st, pad, 1, mask=xmask, colsum=cs)
         Mout, oh, ow = Mrows, 1, Mrows // B
-    flop = 2.0 * Mout * O * C * R * R
+    flop = 2.0 * Mout * O * C * R * R / (st * st if dgrad else 1)      # (a stride-s dgrad multiplies over the dZ pixels: 1 / s^2 of the dX pixels)
     row = [f'{name:44s} M={Mout:6d}']
     outs, took = {}, {}
 
