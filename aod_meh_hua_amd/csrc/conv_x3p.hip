@@ -441,6 +441,11 @@ int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
   if (a.taps != 1 && a.taps != 9) return 0;
   if (a.taps == 9 && a.S != 3) return 0;
   if (a.N % 128 != 0 || a.C % 64 != 0 || a.M <= 0) return 0;
+  // AOD_X3P_DGRAD=0 (parallel.GradSync sets it when gradients are all-reduced under the backward pass): backward launches stay with the general
+  // kernel.  A persistent grid of one 160-KB-LDS workgroup per CU assumes every CU is free; RCCL's channel workgroups hold some for milliseconds,
+  // and the workgroups that cannot start then run AFTER the others -- a one-round launch takes twice as long -- where the general kernel's many
+  // small workgroups just lose those CUs' share.  Forward and scoring launches never run beside a collective.
+  if (a.transposed) { const char* dg = getenv("AOD_X3P_DGRAD"); if (dg && dg[0] == '0') return 0; }
   if (a.lat == 1) {
     // class-major stride-2 dgrad: 3x3, pad 1, no dilation, one segment with an even map whose halves are the dZ map
     const char* lt = getenv("AOD_X3P_LATTICE");

@@ -76,6 +76,12 @@ class GradSync:
     def __init__(self, bucket_mb=64):
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._ents = {}
+        # the all-reduces of this object run on RCCL's stream BESIDE the backward pass: keep the backward launches off the persistent
+        # one-workgroup-per-CU conv kernel (csrc/conv_x3p.hip, aod_conv_x3p_wants: a grid that assumes every CU free doubles its time when RCCL's
+        # channel workgroups hold a few); forward and scoring launches are not concerned.  An explicit AOD_X3P_DGRAD in the environment wins.
+        if is_dist() and dist.get_world_size() > 1:
+            import os
+            os.environ.setdefault('AOD_X3P_DGRAD', '0')
 
     def attach(self, params, segments=None):
         """segments: list of parameter lists (completion order of the backward segments); None keeps what an earlier attach() fixed."""
