@@ -52,6 +52,15 @@ __device__ __forceinline__ T xp_sel8(const T* a, int sg) {      // a[sg] of a by
   for (int q = 1; q < 8; ++q) v = sg == q ? a[q] : v;
   return v;
 }
+#ifdef AOD_TILE_TIMING
+// debug build only (tools/dbg/x3p_timing.py): per-workgroup stamps of consumer wave 0 -- kernel entry, ring primed, K loop done, epilogue
+// done (first tile), kernel exit -- shader clock (s_memtime) and 100 MHz wall clock
+__device__ unsigned long long* g_x3p_stamps = nullptr;
+extern "C" int aod_dbg_set_x3p_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3p_stamps), &buf, sizeof(buf)); }
+#define XSTAMP(k) do { if (g_x3p_stamps && threadIdx.x == 0) { g_x3p_stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); g_x3p_stamps[(size_t)blockIdx.x * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define XSTAMP(k) do {} while (0)
+#endif
 #define XP_GSEL(f) (gi == 0 ? p.grp[0].f : (gi == 1 ? p.grp[1].f : (gi == 2 ? p.grp[2].f : p.grp[3].f)))
 
 // NBW: 16-channel blocks per consumer wave -- 4: 128-column tiles, 8: 256-column tiles.  LAT: X3PArgs.lat (TAPS = 4 = the most taps a class has)
@@ -233,7 +242,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_scale, 0, p.pre_scale ? p.N * 4 : 0, 0x00020000);     // empty descriptor -> zeros
 
+  XSTAMP(0);
   __builtin_amdgcn_s_barrier();                                      // stage 0 is resident
+  XSTAMP(1);
   int cslot = 0;
   for (int j = 0; j < nmine; ++j) {
     const int tile = tile_of(j);
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_barrier();
     }
 
+    if (j == 0) XSTAMP(2);
     // ---- epilogue, in registers.  acc[2a][mb][r] = channel cb + r, acc[2a + 1][mb][r] = channel cb + 4 + r of pixel m0 + wm * 64 + mb * 16 + lr,
     // cb = n0 + wn * 16 NBW + 32a + 8 * lq: head columns 2 * (cb - 8 lq) + 8 lq .. + 7 of the destination row, tails 32 columns further
     const int sg = LAT == 1 ? 0 : seg_of(m0);
@@ -394,7 +406,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (lr < 8 * PG) atomicAdd(gcs + n0 + wn * 16 * NBW + 32 * (pg * PG + (lr >> 3)) + 8 * lq + (lr & 7), mine);
       }
     }
+    if (j == 0) XSTAMP(3);
   }
+  XSTAMP(4);
 }
 #undef XP_GSEL
 

@@ -90,7 +90,7 @@ for name, C, O, H, W, R, st, res in SHAPES:
     def setmode(mode):
         os.environ['AOD_X3P'] = mode[0]
         ho.SPLITK = not (mode[0] == '1' and os.environ.get('X3P_NO_SPLITK') == '1')      # (A/B: the persistent kernel instead of split-K)
-        os.environ['AOD_X3P_ROT'] = mode[2:] if len(mode) > 1 else '0'
+        os.environ['AOD_X3P_ROT'] = mode[2:] if len(mode) > 1 and mode[1] == 'r' else '0'
         os.environ['AOD_X3P_MIN_TILES'] = os.environ.get('MIN_TILES', '1')
         os.environ['AOD_X3P_MIN_STEPS'] = os.environ.get('MIN_STEPS', '1')
     for mode in MODES:
