@@ -139,3 +139,37 @@ def test_full_size_train_step_vs_oracle_in_the_reference_precision_mode(model):
             print(f'{tag}:{k:48s} rel err {err:.2e}  norm dev {nd:.2e}  1-cos {1 - cos:.2e}')
             assert cos > 1 - 1e-5 and nd < 1e-3 and err < 3e-3, (k, cos, nd, err)
     print('worst relative gradient error at full size:', worst)
+
+
+def test_full_size_step_with_the_products_own_kernel_dispatch_equals_the_general_kernels(model, monkeypatch):
+    """configs[1] at full size with the library's DEFAULT dispatch thresholds (tests/test_gpu_x3p.py lowers them to reach the persistent kernel
+    on small shapes): the persistent producer / consumer conv kernel takes its share of the launches -- forward, stride-1 dgrads, lattice
+    dgrads -- and the iteration's loss and every gradient equal the run with `AOD_X3P=0` (loss and conv-weight gradients of launches without a
+    column-sum operand upstream bit for bit; the rest to the rounding of fp32 atomics), in the reference-precision mode."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd._C import lib
+    if AF.get_precision() != 'bf16x3':
+        pytest.skip('the persistent kernel is a reference-precision kernel')
+    B, H = 16, 512
+    gtb, gtl = synth.random_gts(B, H, H, seed=5, gmin=1, gmax=5)
+    data = dict(img=synth.images(B, H, H, seed=6).cuda(), img_metas=synth.metas(B, H, H), gt_bboxes=[b.cuda() for b in gtb],
+                gt_labels=[l.cuda() for l in gtl])
+    model.train()
+    for k in ('AOD_X3P_MIN_TILES', 'AOD_X3P_MIN_STEPS', 'AOD_X3P_BN', 'AOD_X3P_DGRAD', 'AOD_X3P_LATTICE', 'AOD_X3P_GROUPED'):
+        monkeypatch.delenv(k, raising=False)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('AOD_X3P', mode)
+        n0 = lib.aod_conv_x3p_count()
+        model.zero_grad()
+        o, *_ = model.train_step(data, Labeled=True, Pseudo=False)
+        o['loss'].backward()
+        torch.cuda.synchronize()
+        took = lib.aod_conv_x3p_count() - n0
+        assert (took >= 20) == (mode == '1'), (mode, took)
+        out[mode] = (float(o['loss'].detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert out['1'][0] == out['0'][0]
+    for k, g1 in out['1'][1].items():
+        g0 = out['0'][1][k]
+        err = float((g1.double() - g0.double()).abs().max() / (g0.double().abs().max() + 1e-30))
+        assert err < 2e-6, (k, err)
