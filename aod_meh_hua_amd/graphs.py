@@ -111,7 +111,10 @@ class GraphedTrainStep:
                 hl[b, :n] = ll.detach().long().cpu() if ll.device.type != 'cpu' else ll.long()
         st['gt_pack'].copy_(host, non_blocking=True)
         if st.get('valid_fn') is not None:            # valid-anchor flags of THIS batch's per-image pad shapes (cached per shape on the device)
-            st['valid'].copy_(st['valid_fn'](d['img_metas']), non_blocking=True)
+            flags, key = st['valid_fn'](d['img_metas'])
+            if st.get('valid_key') != key:            # (fixed-size data: every batch has the same pad shapes, the buffer already holds them)
+                st['valid'].copy_(flags, non_blocking=True)
+                st['valid_key'] = key
 
     def _alloc(self, d):
         B, dev, G = d['img'].shape[0], self.dev, self.gmax

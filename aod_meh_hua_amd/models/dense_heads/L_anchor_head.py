@@ -127,8 +127,19 @@ class L_AnchorHead(BaseModule):
             # in their per-image pad shapes, not in the padded batch shape)
             if static.get('valid') is None:
                 static['valid'] = torch.stack(flags).to(torch.uint8).contiguous()
-                static['valid_fn'] = lambda metas: torch.stack(
-                    [ag.flat_valid_flags(featmap_sizes, tuple(int(v) for v in m['pad_shape'][:2]), device) for m in metas]).to(torch.uint8)
+                stacked = {}
+
+                def valid_fn(metas):
+                    """(flags [B, anchors] uint8 on the device, key): one stacked tensor per combination of per-image pad shapes, built once --
+                    a batch whose key equals the previous one's needs no refresh at all (graphs._load)"""
+                    key = tuple(tuple(int(v) for v in m['pad_shape'][:2]) for m in metas)
+                    t = stacked.get(key)
+                    if t is None:
+                        if len(stacked) >= 64:
+                            stacked.clear()
+                        t = stacked[key] = torch.stack([ag.flat_valid_flags(featmap_sizes, ps, device) for ps in key]).to(torch.uint8)
+                    return t, key
+                static['valid_fn'] = valid_fn
             valid = static['valid']
         gts, counts, labs = pack_gts(gt_bboxes, gt_labels, device)
         starts = [0]
