@@ -64,9 +64,14 @@ extern "C" int aod_dbg_set_x3p_stamps(void* buf) { return (int)hipMemcpyToSymbol
 #define XP_GSEL(f) (gi == 0 ? p.grp[0].f : (gi == 1 ? p.grp[1].f : (gi == 2 ? p.grp[2].f : p.grp[3].f)))
 
 // NBW: 16-channel blocks per consumer wave -- 4: 128-column tiles, 8: 256-column tiles.  LAT: X3PArgs.lat (TAPS = 4 = the most taps a class has)
-template <int TAPS, int NBW, int LAT = 0>
+// PRE (128-column tiles, dense destinations): the tile's epilogue operand -- 1: the residual rows (heads + tails, 64 registers), 2: the ReLU-mask
+// rows (heads, 32 registers) -- is requested BEFORE the K loop and waited for after it.  For the short-K layers that carry one (the expand 1 x 1
+// convs: 8 K-steps between 64 KB of residual reads and 64 KB of stores per tile; the dgrads of the reduce convs) the tile otherwise serialises
+// K loop -> operand latency + transfer -> stores with nothing else on the CU to run meanwhile.
+template <int TAPS, int NBW, int LAT = 0, int PRE = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3p_kernel(const X3PArgs p) {
   static_assert(LAT != 1 || TAPS == 4, "class-major form: up to four taps per class");
+  static_assert(PRE == 0 || (NBW == 4 && LAT == 0), "operand prefetch: 128-column dense tiles");
   constexpr int BN = 32 * NBW, WBYTES = BN * 128, STAGE = XP_XBYTES + WBYTES;
   // ring: RING slots, FLY stages in flight.  Iteration k of a loader issues stage k, waits until all but the youngest FLY stages'
   // instructions have landed (stage k - FLY and older) and joins barrier k - FLY - 1, behind which the consumers read stage k - FLY;
@@ -258,6 +263,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // destination rows of this lane's four pixels (used by the epilogue; PRE: already here, for the operand requests)
+    bool live[4];
+    long long prow_[4];
+    auto row_addresses = [&]() {
+      const int sg = LAT == 1 ? 0 : seg_of(m0);
+      const long long drow0 = xp_sel8(p.seg_dst0, sg) - (long long)(sg ? xp_sel8(p.seg_mend, sg - 1) : 0);
+      const unsigned eOW = (unsigned)p.segOW[0], eOH = (unsigned)p.segOH[0];
+      const unsigned eRW = LAT == 1 ? eOW >> 1 : eOW, erhw = (LAT == 1 ? eOH >> 1 : eOH) * eRW;
+      const int mlim = LAT == 1 ? (int)(erhw * (unsigned)p.segB[0]) : p.M;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int m = m0 + wm * 64 + mb * 16 + lr;
+        live[mb] = m < mlim;
+        // (rows past the end read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes
+        // the compiler wait for each one where the paths merge; only the stores are predicated)
+        const int mc = live[mb] ? m : mlim - 1;
+        if constexpr (LAT == 0) prow_[mb] = (drow0 + mc) * NP;
+        else {
+          // lattice destinations: row (image, y, x) of the tile's row space lands at (2y + py, 2x + px) of the full-resolution map
+          const unsigned b = xp_udiv((unsigned)mc, erhw), rem = (unsigned)mc - b * erhw, oy = xp_udiv(rem, eRW), ox = rem - oy * eRW;
+          const long long drow = LAT == 1 ? ((long long)b * eOH + 2 * oy + (unsigned)(cls >> 1)) * eOW + 2 * ox + (unsigned)(cls & 1)
+                                          : (long long)b * p.up_hw + (long long)(2 * oy) * p.up_w + 2 * ox;
+          prow_[mb] = (xp_sel8(p.seg_dst0, 0) + drow) * NP;
+        }
+      }
+    };
+    bf16x8 prh[PRE ? 2 : 1][4], prl[PRE == 1 ? 2 : 1][4];
+    if constexpr (PRE != 0) {
+      row_addresses();
+      const bf16_t* const src = PRE == 1 ? p.res : XP_GSEL(mask);
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const int col = 2 * (n0 + wn * 16 * NBW + 32 * aa) + 8 * lq;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          prh[aa][mb] = *reinterpret_cast<const bf16x8*>(src + prow_[mb] + col);
+          if constexpr (PRE == 1) prl[aa][mb] = *reinterpret_cast<const bf16x8*>(src + prow_[mb] + col + 32);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);       // (the requests leave here, not where hipcc would sink them: in front of their first use)
+    }
     for (int ks = 0; ks < nk; ++ks) {
       const char* const st = smem + cslot * STAGE;
       cslot = cslot == RING - 1 ? 0 : cslot + 1;
@@ -293,36 +339,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     if (j == 0) XSTAMP(2);
+    if (j == 1) XSTAMP(5);
     // ---- epilogue, in registers.  acc[2a][mb][r] = channel cb + r, acc[2a + 1][mb][r] = channel cb + 4 + r of pixel m0 + wm * 64 + mb * 16 + lr,
     // cb = n0 + wn * 16 NBW + 32a + 8 * lq: head columns 2 * (cb - 8 lq) + 8 lq .. + 7 of the destination row, tails 32 columns further
-    const int sg = LAT == 1 ? 0 : seg_of(m0);
-    const long long drow0 = xp_sel8(p.seg_dst0, sg) - (long long)(sg ? xp_sel8(p.seg_mend, sg - 1) : 0);
     bf16_t* const gy = XP_GSEL(y);
     const bf16_t* const gmask = XP_GSEL(mask);
     float* const gcs = XP_GSEL(colsum);
     const float* const gshift = XP_GSEL(shift);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)gshift, 0, gshift ? p.N * 4 : 0, 0x00020000);
-    bool live[4];
-    long long prow_[4];
-    const unsigned eOW = (unsigned)p.segOW[0], eOH = (unsigned)p.segOH[0];
-    const unsigned eRW = LAT == 1 ? eOW >> 1 : eOW, erhw = (LAT == 1 ? eOH >> 1 : eOH) * eRW;
-    const int mlim = LAT == 1 ? (int)(erhw * (unsigned)p.segB[0]) : p.M;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int m = m0 + wm * 64 + mb * 16 + lr;
-      live[mb] = m < mlim;
-      // (rows past the end read the last row's operands instead of branching per lane around the loads: a divergent branch per load makes
-      // the compiler wait for each one where the paths merge; only the stores are predicated)
-      const int mc = live[mb] ? m : mlim - 1;
-      if constexpr (LAT == 0) prow_[mb] = (drow0 + mc) * NP;
-      else {
-        // lattice destinations: row (image, y, x) of the tile's row space lands at (2y + py, 2x + px) of the full-resolution map
-        const unsigned b = xp_udiv((unsigned)mc, erhw), rem = (unsigned)mc - b * erhw, oy = xp_udiv(rem, eRW), ox = rem - oy * eRW;
-        const long long drow = LAT == 1 ? ((long long)b * eOH + 2 * oy + (unsigned)(cls >> 1)) * eOW + 2 * ox + (unsigned)(cls & 1)
-                                        : (long long)b * p.up_hw + (long long)(2 * oy) * p.up_w + 2 * ox;
-        prow_[mb] = (xp_sel8(p.seg_dst0, 0) + drow) * NP;
-      }
-    }
+    if constexpr (PRE == 0) row_addresses();
     // PG block pairs (32 channels each) at a time: all their operands are requested before the first is used.  Two pairs with 64 accumulator
     // registers; one with 128 (the 256-column tile), where a second pair's 48 operand registers would spill
     constexpr int PG = NBW == 4 ? 2 : 1;
@@ -335,7 +360,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cb = n0 + wn * 16 * NBW + 32 * (pg * PG + aa) + 8 * lq;
         const int col = 2 * (cb - 8 * lq) + 8 * lq;
         const u32x4_t b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, cb * 4 + 16, 0, 0);
-        const u32x4_t s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4 + 16, 0, 0);
+        // (the scale vector only where there is one: a load whose result is never used is never waited for either, and the registers it
+        // targets stay 'pending' into the next tile's K loop -- whose first fragment reads then wait for EVERY older memory operation of the
+        // wave, i.e. for the previous tile's stores to drain)
+        u32x4_t s0 = {0u, 0u, 0u, 0u}, s1 = {0u, 0u, 0u, 0u};
+        if (p.pre_scale) { s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4, 0, 0); s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, cb * 4 + 16, 0, 0); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           cb1[aa][q] = __uint_as_float(b0[q]); cb1[aa][4 + q] = __uint_as_float(b1[q]);
@@ -343,11 +372,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-          if (p.res) {
-            rh[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col);
-            rl[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col + 32);
+          if constexpr (PRE == 1) { rh[aa][mb] = prh[aa][mb]; rl[aa][mb] = prl[aa][mb]; }
+          else if constexpr (PRE == 2) mh[aa][mb] = prh[aa][mb];
+          else {
+            if (p.res) {
+              rh[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col);
+              rl[aa][mb] = *reinterpret_cast<const bf16x8*>(p.res + prow_[mb] + col + 32);
+            }
+            if (gmask) mh[aa][mb] = *reinterpret_cast<const bf16x8*>(gmask + prow_[mb] + col);
           }
-          if (gmask) mh[aa][mb] = *reinterpret_cast<const bf16x8*>(gmask + prow_[mb] + col);
         }
       }
 #pragma unroll
@@ -358,7 +391,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 8; ++q) csum[aa][q] = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-          if (!live[mb]) continue;
+          // (rows past the end are COMPUTED like the others, on the last row's operands, and only their stores / column sums are predicated:
+          // with the uses behind a per-lane branch hipcc's wait-count pass carries the operand loads as 'possibly pending' across the join
+          // into the next tile's K loop, whose first fragment read then waited vmcnt(0) -- i.e. for this tile's STORES to drain)
           float v[8];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { v[q] = acc[2 * a][mb][q]; v[4 + q] = acc[2 * a + 1][mb][q]; }
@@ -382,11 +417,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
           bf16x8 ov, ovl;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { csum[aa][q] += v[q]; ov[q] = (bf16_t)v[q]; }
+          for (int q = 0; q < 8; ++q) { csum[aa][q] += live[mb] ? v[q] : 0.f; ov[q] = (bf16_t)v[q]; }
 #pragma unroll
           for (int q = 0; q < 8; ++q) ovl[q] = (bf16_t)(v[q] - (float)ov[q]);
-          *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col) = ov;
-          *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col + 32) = ovl;
+          if (live[mb]) {
+            *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col) = ov;
+            *reinterpret_cast<bf16x8*>(gy + prow_[mb] + col + 32) = ovl;
+          }
         }
       }
       if (gcs) {
@@ -407,6 +444,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     if (j == 0) XSTAMP(3);
+    if (j == 1) XSTAMP(6);
   }
   XSTAMP(4);
 }
@@ -415,13 +453,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int g_x3p_cus[64];
 long long g_x3p_count = 0;
 
-template <int TAPS, int NBW, int LAT = 0>
+template <int TAPS, int NBW, int LAT = 0, int PRE = 0>
 int xp_launch(const X3PArgs& a, int grid, hipStream_t st) {
   constexpr int STAGE = XP_XBYTES + 32 * NBW * 128, RING = NBW == 4 ? 5 : 3;
   const size_t lds = (size_t)RING * STAGE;
   static unsigned long long attr = 0;
-  if (aod_first_on_device(&attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<TAPS, NBW, LAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_x3p_kernel<TAPS, NBW, LAT>), dim3(grid), dim3(512), lds, st, a);
+  if (aod_first_on_device(&attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3p_kernel<TAPS, NBW, LAT, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_x3p_kernel<TAPS, NBW, LAT, PRE>), dim3(grid), dim3(512), lds, st, a);
   return 0;
 }
 
@@ -432,9 +470,21 @@ static long long xp_rows(const X3PArgs& a) {
   return a.lat == 1 ? (long long)a.segB[0] * (a.segOH[0] / 2) * (a.segOW[0] / 2) : a.M;
 }
 
+// Operand-prefetch form (conv_x3p_kernel PRE): dense 1x1 launches with EXACTLY one of residual (-> 1) / ReLU mask (-> 2), else 0.
+// AOD_X3P_PRE=0 disables.
+static int xp_pre(const X3PArgs& a) {
+  const char* e = getenv("AOD_X3P_PRE");
+  if (e && e[0] == '0') return 0;
+  if (a.taps != 1 || a.lat != 0 || a.ngroups > 1 || a.stride != 1) return 0;
+  const bf16_t* mask = a.ngroups == 1 ? a.grp[0].mask : a.mask;
+  if ((a.res != nullptr) == (mask != nullptr)) return 0;
+  return a.res ? 1 : 2;
+}
+
 // 256-column tiles (half the pixel bytes per MFMA, twice the MFMAs per barrier) when they still give at least three quarters of the CUs a
 // tile; AOD_X3P_BN=128 / 256 forces
 static bool xp_wide(const X3PArgs& a) {
+  if (xp_pre(a)) return false;                  // (the prefetch form exists for the 128-column tile: 64 accumulators leave room for the operand)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
   if (!g_x3p_cus[dev]) {
@@ -485,6 +535,13 @@ int aod_conv_x3p_wants(const X3PArgs& a, int deterministic_colsum) {
     const char* ms = getenv("AOD_X3P_MIN_STEPS");
     const int thr = ms ? atoi(ms) : 24;
     const int steps = a.lat == 1 ? 9 * (a.C >> 6) / 4 : a.taps * (a.C >> 6);
+    // (the operand-prefetch form, xp_pre, does not change this: with the residual requested before the K loop the 8-step expand conv of
+    // layer 3 still takes 49.5 us against the general kernel's 44.9 -- its K loop is bound by what 96 KB of ring can keep in flight against
+    // the memory latency under the residual / store traffic, 1.08 us per K-step by the stamps -- and only the 4-step layer-2 expand conv wins,
+    // 73.8 against 80.0 us; AOD_X3P_PRE_MIN_STEPS lowers the threshold for launches that qualify for the form)
+    const char* pms = getenv("AOD_X3P_PRE_MIN_STEPS");
+    if (pms && xp_pre(a)) { if (steps < atoi(pms)) return 0; }
+    else
     if (a.lat != 1 && (steps * (xp_wide(a) ? 2 : 1) < thr || (a.res && steps < thr))) return 0;
     if (a.lat == 1 && steps * (xp_wide(a) ? 2 : 1) < thr / 2) return 0;          // (the general kernel's class-major launches are its slowest: 86 - 127 TFLOP/s)
   }
@@ -521,7 +578,13 @@ int aod_conv_x3p_launch(const X3PArgs& a0, hipStream_t st) {
   const int grid = (int)(ntiles < ncu ? ntiles : ncu);
   if (a.lat == 1) { if (wide) xp_launch<4, 8, 1>(a, grid, st); else xp_launch<4, 4, 1>(a, grid, st); }
   else if (a.lat == 2) { if (wide) xp_launch<1, 8, 2>(a, grid, st); else xp_launch<1, 4, 2>(a, grid, st); }
-  else if (a.taps == 1) { if (wide) xp_launch<1, 8>(a, grid, st); else xp_launch<1, 4>(a, grid, st); }
+  else if (a.taps == 1) {
+    const int pre = xp_pre(a);
+    if (wide) xp_launch<1, 8>(a, grid, st);
+    else if (pre == 1) xp_launch<1, 4, 0, 1>(a, grid, st);
+    else if (pre == 2) xp_launch<1, 4, 0, 2>(a, grid, st);
+    else xp_launch<1, 4>(a, grid, st);
+  }
   else { if (wide) xp_launch<9, 8>(a, grid, st); else xp_launch<9, 4>(a, grid, st); }
   AOD_LAUNCH_CHECK();
   __atomic_add_fetch(&g_x3p_count, 1, __ATOMIC_RELAXED);

@@ -158,6 +158,58 @@ def test_x3p_pyramid_segments_and_mask_epilogue(monkeypatch):
         assert _err(_f(res['1'][0][0], B, sizes[0][0], sizes[0][1], 128), ref) < 2e-4
 
 
+@pytest.mark.parametrize('shape', [(16, 256, 1024, 32, 32), (3, 128, 512, 24, 40), (5, 512, 256, 17, 23)])
+def test_x3p_operand_prefetch_forms_equal_the_general_kernel(shape, monkeypatch):
+    """1x1 launches with exactly one epilogue operand take the persistent kernel's PRE instances (the operand rows are requested before the
+    tile's K loop): PRE = 1, the residual of a bottleneck's expand conv (resnet.py:283-298), and PRE = 2, the ReLU mask in the dgrad of a 1x1
+    conv whose input is a ReLU output (functional.ActSlot: conv -> ReLU -> 1x1 conv).  Bits equal to the general kernel and to the persistent
+    kernel without the prefetch; repeated launches stay bit-stable (the waits on the operand are counted by the compiler, the ring's by hand)."""
+    from aod_meh_hua_amd import functional as AF
+    from aod_meh_hua_amd import hipops as ho
+    from aod_meh_hua_amd._C import lib
+    from aod_meh_hua_amd.mmcv_lite import Conv2d
+    B, C, O, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(21)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    monkeypatch.setenv('AOD_X3P_MIN_TILES', '1')
+    monkeypatch.setenv('AOD_X3P_MIN_STEPS', '1')
+    monkeypatch.setenv('AOD_X3P_PRE_MIN_STEPS', '1')
+    monkeypatch.setattr(ho, 'SPLITK', False)
+    c1, c2 = Conv2d(C, C, 1).cuda(), Conv2d(C, O, 1).cuda()
+    with torch.no_grad():
+        c1.weight.copy_(rnd(C, C, 1, 1) / C ** 0.5); c1.bias.copy_(rnd(C) * 0.1)
+        c2.weight.copy_(rnd(O, C, 1, 1) / C ** 0.5); c2.bias.copy_(rnd(O) * 0.1)
+    x, res, gy = rnd(B, C, H, W), rnd(B, O, H, W), rnd(B, O, H, W)
+    outs = {}
+    for mode in ('pre', 'nopre', 'general'):
+        monkeypatch.setenv('AOD_X3P', '0' if mode == 'general' else '1')
+        monkeypatch.setenv('AOD_X3P_PRE', '0' if mode == 'nopre' else '1')
+        runs = []
+        for rep in range(3 if mode == 'pre' else 1):
+            for m in (c1, c2):
+                m.weight.grad = m.bias.grad = None
+            n0 = lib.aod_conv_x3p_count()
+            xx = AF.as_nchw(_x(x), B, H, W).requires_grad_()
+            h = c1(xx, relu=True)                                            # producer: its ReLU output feeds c2 only
+            y = AF.conv_bn_act(h, c2.weight, bias=c2.bias, res=AF.as_nchw(_x(res), B, H, W), relu=True, sole_consumer=True)   # PRE = 1 forward, PRE = 2 dgrad
+            y.backward(AF.as_nchw(_x(gy), B, H, W))
+            torch.cuda.synchronize()
+            took = lib.aod_conv_x3p_count() - n0
+            assert (took > 0) == (mode != 'general'), (mode, took)
+            runs.append((AF.as_rows(y).detach().clone(), AF.as_rows(xx.grad).clone(), c1.weight.grad.clone(), c1.bias.grad.clone()))
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+        outs[mode] = runs[0]
+    for other in ('nopre', 'general'):
+        assert torch.equal(outs['pre'][0], outs[other][0]), (other, 'forward')
+        assert torch.equal(outs['pre'][1], outs[other][1]), (other, 'input gradient')
+        assert torch.equal(outs['pre'][2], outs[other][2]), (other, 'weight gradient of the producer')
+        assert _err(outs['pre'][3], outs[other][3]) < 2e-6
+    ref = F.conv2d(torch.relu(F.conv2d(x, c1.weight, c1.bias)), c2.weight, c2.bias) + res
+    yf = _f(outs['pre'][0], B, H, W, O)
+    assert _err(yf, ref * (yf > 0).float()) < 2e-4
+
+
 def test_x3p_repeated_launches_are_bit_stable(monkeypatch):
     """race screen: the ring's waits are counted by hand -- 40 launches of a multi-round shape, back to back, must all give the first one's bits"""
     from aod_meh_hua_amd import functional as AF

@@ -25,9 +25,16 @@ w = torch.randn(O, C, R, R, device='cuda', generator=g) / (C * R * R) ** 0.5
 bias = torch.randn(O, device='cuda', generator=g)
 
 
+RES = os.environ.get('RES', '0') == '1'            # RES=1: a residual operand (the expand 1x1 convs; PRE=0 switches the operand prefetch form off)
+if 'PRE' in os.environ:
+    os.environ['AOD_X3P_PRE'] = os.environ['PRE']
+os.environ['AOD_X3P_PRE_MIN_STEPS'] = '1'
+res = AF.as_nchw(ho.x3_split(torch.randn(B * H * W, O, device='cuda', generator=g)), B, H, W) if RES else None
+
+
 def f():
     with torch.no_grad():
-        return AF.conv_bn_act(x, w, bias=bias, stride=1, pad=R // 2, relu=True)
+        return AF.conv_bn_act(x, w, bias=bias, res=res, stride=1, pad=R // 2, relu=True)
 
 
 for _ in range(300):       # (clock readings need the steady state)
@@ -49,5 +56,10 @@ for k, name in enumerate(['ring primed (decode + first stage landed)', 'K loop o
     d = t[:, k + 1] - t[:, k]
     dc = c[:, k + 1] - c[:, k]
     print(f'  {name:44s} mean {d.mean():7.2f} us  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}   {dc.mean():9.0f} cycles  clock {np.median(dc / np.maximum(d, 1e-3)) / 1e3:.2f} GHz')
+if (s[:, 5] > 0).any():
+    # second tile of the workgroups that had one: K loop = epilogue of tile 0 done -> K loop of tile 1 done, then its epilogue
+    m = s[:, 5] > 0
+    t2 = s[m][:, [3, 5, 6]].astype(np.float64) * 0.01
+    print(f'  second tile ({int(m.sum())} workgroups): K loop {np.mean(t2[:, 1] - t2[:, 0]):7.2f} us   epilogue {np.mean(t2[:, 2] - t2[:, 1]):7.2f} us')
 kl = c[:, 2] - c[:, 1]
 print(f'  cycles per K-step in the loop: mean {kl.mean() / nk:.0f} (48 MFMAs = 768 matrix-pipe cycles per consumer wave)')
